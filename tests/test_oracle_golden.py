@@ -1,0 +1,107 @@
+"""CPU: the oracle restatement (oracle/unet_oracle.py) against the golden vectors produced by the real reference
+(tests/golden/make_goldens.py).  This is what pins the oracle; GPU parity tests then compare HIP vs oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from _util import digest, load_golden, digest_close
+
+CASES = [('net4_nf32_nopad', 'net4', False, 6, None), ('net4_nf32_pad', 'net4', True, 3, None),
+         ('full_nf32_nopad', 'full', False, 4, None), ('net4_nf32_rawrange4', 'net4', False, 3, 4),
+         ('1raw1of_nf32_nopad', '1raw1of', False, 3, None)]
+
+
+@pytest.mark.parametrize('name,kind,padding,n,rawRange', CASES)
+def test_oracle_matches_reference(name, kind, padding, n, rawRange):
+    torch.set_num_threads(8)
+    g = load_golden(name)
+    tot_of = {'net4': 1, 'full': 5, '1raw1of': 1}[kind]
+    sd = O.seeded_state_dict(kind, nf=32, padding=padding, seed=0)
+    spec = O.bank_spec(kind, 5, tot_of, 'predict', rawRange, True)
+    raw, flow = O.seeded_cubes(n, tot_of, 0)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    assert digest_close(digest(x), g['x_digest'], 1e-6)
+    assert digest_close(digest(x_of), g['xof_digest'], 1e-6)
+    with torch.no_grad():
+        of_o, raw_o, of_t, raw_t = O.bank_forward(sd, spec, x, x_of, False, padding)
+    assert list(raw_o.shape) == list(g['eval_raw_out_shape'])
+    assert list(of_o.shape) == list(g['eval_of_out_shape'])
+    np.testing.assert_allclose(O.cube_scores(raw_o, raw_t).numpy(), g['eval_raw_scores'], rtol=2e-5)
+    np.testing.assert_allclose(O.cube_scores(of_o, of_t).numpy(), g['eval_of_scores'], rtol=2e-5)
+    assert digest_close(digest(raw_o), g['eval_raw_out_digest'], 1e-5)
+    assert digest_close(digest(of_o), g['eval_of_out_digest'], 1e-5)
+    # three train steps with the restated Adam
+    names = O.param_names(sd)
+    opt = O.AdamState(names)
+    losses = []
+    for step in range(3):
+        l_raw, l_of, grads = O.train_step(sd, spec, x, x_of, opt, padding=padding)
+        losses.append([l_raw, l_of])
+        if step == 0:
+            gn = [str(s) for s in g['grad_names']]
+            for i, k in enumerate(gn):
+                if grads.get(k) is None:
+                    assert np.all(g['grad_digests'][i] == 0), k
+                    continue
+                gd = g['grad_digests'][i]
+                if gd[1] < 1e-6 * max(1.0, grads[k].numel()) * 1e-3:   # conv biases in front of BN: pure round-off
+                    continue
+                assert digest_close(digest(grads[k]), gd, 2e-3), k
+    np.testing.assert_allclose(np.array(losses), g['losses'], rtol=1e-4)
+    fn = [str(s) for s in g['final_names']]
+    bad = []
+    for i, k in enumerate(fn):
+        if k.endswith('num_batches_tracked'):
+            assert float(sd[k]) == g['final_digests'][i][0]
+            continue
+        if not digest_close(digest(sd[k]), g['final_digests'][i], 5e-3):
+            bad.append(k)
+    assert not bad, bad[:5]
+    with torch.no_grad():
+        of_o, raw_o, of_t, raw_t = O.bank_forward(sd, spec, x, x_of, False, padding)
+    np.testing.assert_allclose(O.cube_scores(raw_o, raw_t).numpy(), g['post_raw_scores'], rtol=2e-3)
+    np.testing.assert_allclose(O.cube_scores(of_o, of_t).numpy(), g['post_of_scores'], rtol=2e-3)
+
+
+def test_oracle_script_level():
+    """train.py:365-433 + test.py:251-357 + utils.py:29-39 restated with oracle pieces vs the golden run."""
+    torch.set_num_threads(8)
+    g = load_golden('script_net4')
+    sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
+    spec = O.bank_spec('net4')
+    raw, flow = O.seeded_cubes(24, 1, 1)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    opt = O.AdamState(O.param_names(sd))
+    losses = []
+    for ep in range(2):
+        for s in range(0, 24, 8):
+            l_raw, l_of, _ = O.train_step(sd, spec, x[s:s + 8], x_of[s:s + 8], opt)
+            losses.append([l_raw, l_of])
+    np.testing.assert_allclose(np.array(losses), g['losses'], rtol=2e-3)
+    raw_train, of_train = O.score_pass(sd, spec, x, x_of, 8)
+    np.testing.assert_allclose(raw_train, g['raw_train'], rtol=5e-3)
+    np.testing.assert_allclose(of_train, g['of_train'], rtol=5e-3)
+    rng = np.random.default_rng(77)
+    fs, cs = [], []
+    for f in range(10):
+        nc = f % 4
+        if nc == 0:
+            fs.append(-100000.0)
+            continue
+        rw, fl = O.seeded_cubes(nc, 1, 100 + f)
+        xt, xt_of = O.cubes_to_inputs(rw, fl)
+        if f % 2 == 1:
+            xt = xt.clone()
+            xt[:, 12:15] = 1.0 - xt[:, 12:15]
+        r, o = O.score_pass(sd, spec, xt, xt_of, nc)
+        sc = O.normalised_scores(r, o, raw_train, of_train)
+        cs.append(sc)
+        bbs = []
+        for m in range(nc):
+            x0, y0 = rng.uniform(0, 360 - 60), rng.uniform(0, 240 - 60)
+            bbs.append([x0, y0, x0 + rng.uniform(10, 50), y0 + rng.uniform(10, 50)])
+        fs.append(O.frame_score_map(sc, bbs, 240, 360).max())
+    np.testing.assert_allclose(np.concatenate(cs), g['cube_scores'], rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(np.array(fs), g['frame_scores'], rtol=1e-2, atol=1e-2)
+    assert abs(O.roc_auc(np.array(fs), g['labels']) - float(g['auc'])) < 1e-9
