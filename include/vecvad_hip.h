@@ -1,0 +1,239 @@
+/* vecvad_hip.h -- C ABI of libvecvad_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the VEC_VAD
+ * spatio-temporal-cube completion path (UNet bank forward / backward / Adam) and the FlowNet2 native ops.
+ *
+ * Conventions (the only C-ABI precedent in the reference is the cffi seam of the three
+ * FlowNet2 ops, FlowNet2_src/models/components/ops/correlation/src/correlation_cuda.h:1-8,
+ * correlation_cuda_kernel.h:5-39, resample2d/src/Resample2d_cuda.c:8-11, channelnorm/src/ChannelNorm_cuda.c:8-11):
+ *   - every entry point returns 0 on success and a non-zero vv_status otherwise; nothing aborts or prints;
+ *   - the caller owns every buffer (inputs, outputs, scratch); raw device pointers + explicit sizes, no torch types;
+ *   - launches are asynchronous on the hipStream_t passed in (pass PyTorch's current stream); no host sync;
+ *   - no global mutable state: re-entrant, safe with one process per GPU and with several streams;
+ *   - all tensors are fp32; activations are NHWC ("pixel-major, channel-minor"), grouped tensors are [G][...]
+ *     with an explicit element stride between the G independent UNets of a bank.
+ *
+ * Which reference code each entry point replaces is stated next to it (paths relative to the reference root).
+ */
+#ifndef VECVAD_HIP_H
+#define VECVAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vv_stream; /* hipStream_t */
+
+enum vv_status {
+  VV_OK = 0,
+  VV_ERR_BAD_ARG = 1,      /* unsupported shape / null pointer */
+  VV_ERR_LAUNCH = 2,       /* hipGetLastError() != hipSuccess after the launch */
+  VV_ERR_UNSUPPORTED = 3
+};
+
+/* ---- how a convolution reads its input ("transform on load"; replaces separate BN/ReLU/pool/cat kernels) ---- */
+enum vv_in_mode {
+  VV_IN_PLAIN = 0, /* x                                                       */
+  VV_IN_ACT = 1,   /* relu(a[c]*x + b[c])      nn.BatchNorm2d + nn.ReLU  model/unet.py:11-12,14-15 */
+  VV_IN_POOL = 2,  /* 2x2 max of relu(a*x+b)   + nn.MaxPool2d(2)         model/unet.py:38          */
+  VV_IN_CAT = 3,   /* [relu(a*x0+b) , x1]      torch.cat([x2, x1], 1)    model/unet.py:59          */
+  VV_IN_CUBE = 4   /* channel gather through chmap (frame erasure)       model/unet.py:178-183     */
+};
+
+enum vv_conv_kind {
+  VV_CONV3 = 0,     /* 3x3, stride 1, pad 1 (forward, or data-gradient with flipped packed weights)     */
+  VV_CONVT_FWD = 1, /* ConvTranspose2d(k3,s2,p1,op1) forward as 4 output-parity phases  model/unet.py:54 */
+  VV_CONVT_DGRAD = 2 /* its data gradient = 3x3 stride-2 gather over the 2Hx2W gradient                 */
+};
+
+/* Source/destination tensor view: NHWC, channel slice [coff, coff+C) of pixels with `cstride` floats each. */
+typedef struct vv_view {
+  float* ptr;        /* group 0 base */
+  int64_t gstride;   /* floats between groups (0: shared by all groups) */
+  int32_t cstride;   /* floats per pixel */
+  int32_t coff;      /* first channel of the slice */
+} vv_view;
+
+/* MFMA implicit-GEMM convolution (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces nn.Conv2d(k3,p1) / nn.ConvTranspose2d(k3,s2,p1,op1) forward and their autograd data-gradients
+ * (cuDNN in the reference: model/unet.py:10,13,54) with BatchNorm/ReLU/MaxPool/cat of the producer fused into
+ * the load, bias + per-channel sum / sum-of-squares partials (BatchNorm batch statistics) fused into the store. */
+typedef struct vv_conv_params {
+  int32_t kind;      /* vv_conv_kind */
+  int32_t in_mode;   /* vv_in_mode */
+  int32_t G, B;      /* groups (UNets), cubes */
+  int32_t H, W;      /* CONV3: image size; CONVT_FWD: INPUT size (output is 2H x 2W); CONVT_DGRAD: OUTPUT size
+                        (= the transposed conv's input size; the gradient read is 2H x 2W) */
+  int32_t Cin;       /* GEMM-K channels actually present */
+  int32_t CinP;      /* Cin rounded up to the packing granule (multiple of 16; 8 for CONVT_DGRAD) */
+  int32_t Cout;      /* GEMM-N channels (multiple of 32) */
+  vv_view src0;      /* primary input */
+  const float* a;    /* per-channel scale of src0's BatchNorm (VV_IN_ACT/POOL/CAT), [G][Cact] */
+  const float* b;    /* per-channel shift */
+  int64_t ab_gstride;
+  vv_view src1;      /* VV_IN_CAT: second input (plain) */
+  int32_t csplit;    /* VV_IN_CAT: channels [0,csplit) come from src0 */
+  int32_t pad0;
+  const int32_t* chmap; /* VV_IN_CUBE: [G][CinP] source channel or -1 (zero) */
+  const float* w;    /* packed weights [9][CinP/8][2][Cout][4]  (see vv_pack_weights) */
+  int64_t w_gstride;
+  const float* bias; /* [G][Cout] or NULL */
+  int64_t bias_gstride;
+  vv_view out;       /* output */
+  float* stats;      /* NULL or [G][ntiles][2][Cout] partial sums (sum, sum of squares) over valid pixels */
+} vv_conv_params;
+
+int vv_conv_mfma(const vv_conv_params* p, vv_stream stream);
+/* number of pixel tiles the kernel uses for this (B,H,W): rows of the `stats` partial array */
+int vv_conv_ntiles(int32_t B, int32_t H, int32_t W);
+
+/* Weight-gradient (autograd of nn.Conv2d / nn.ConvTranspose2d wrt weight; cuDNN in the reference).
+ * dW[tap][ci][co] = sum_pixels act[pixel+tap][ci] * dy[pixel][co]  (CONV3)
+ * dW[tap][ci][co] = sum_pixels act[pixel][ci] * dy[2*pixel-1+tap][co] (CONVT)
+ * Deterministic split-K: each workgroup-wave writes its own partial slab, vv_wgrad_reduce sums them in fixed order. */
+typedef struct vv_wgrad_params {
+  int32_t kind;      /* VV_CONV3 or VV_CONVT_FWD (meaning: weight gradient of the transposed conv) */
+  int32_t in_mode;   /* how the layer input (act) is read, as in the forward */
+  int32_t G, B, H, W; /* H,W: resolution of `act` pixels the GEMM-K runs over (CONVT: the transposed conv's input) */
+  int32_t Cin, CinP, Cout;
+  int32_t ksplit;    /* pixel-tile split factor */
+  vv_view src0; const float* a; const float* b; int64_t ab_gstride;
+  vv_view src1; int32_t csplit; int32_t pad0;
+  const int32_t* chmap;
+  vv_view dy;        /* gradient wrt the conv output (CONV3: HxW; CONVT: 2Hx2W) */
+  float* partial;    /* [G][nslab][9][32][32] with nslab = (CinP/32... see vv_wgrad_nslab) */
+  int64_t partial_gstride;
+} vv_wgrad_params;
+
+int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream);
+int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W);
+/* slabs written per (ci-tile, co-tile): ksplit * 4 (one per wave) */
+
+/* Sum the slabs and scatter into PyTorch parameter layout:
+ * CONV3 : grad[co][ci][ky][kx]   (nn.Conv2d.weight  [Cout,Cin,3,3])
+ * CONVT : grad[ci][co][ky][kx]   (nn.ConvTranspose2d.weight [Cin,Cout,3,3]) */
+int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t CinP, int32_t Cout, int32_t nslab_per_tile,
+                    const float* partial, int64_t partial_gstride, float* grad, int64_t grad_gstride,
+                    vv_stream stream);
+
+/* ---- weight packing: PyTorch OIHW -> MFMA B-operand panels ----
+ * mode 0: conv forward      Wp[t=ky*3+kx][k=ci][n=co] = W[co][ci][ky][kx]
+ * mode 1: conv data-grad    Wp[t=(2-ky)*3+(2-kx)][k=co][n=ci] = W[co][ci][ky][kx]
+ * mode 2: convT forward     Wp[t=ky*3+kx][k=ci][n=co] = Wt[ci][co][ky][kx]
+ * mode 3: convT data-grad   Wp[t=ky*3+kx][k=co][n=ci] = Wt[ci][co][ky][kx]
+ * packed element (t,k,n) lives at (((t*KP/8 + k/8)*2 + (k%8)/4)*N + n)*4 + k%4 ; rows k >= K are zero. */
+typedef struct vv_pack_entry {
+  int64_t src_off;   /* floats from the group's parameter base */
+  int64_t dst_off;   /* floats from the group's packed base */
+  int32_t mode, K, KP, N;
+} vv_pack_entry;
+int vv_pack_weights(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params,
+                    int64_t params_gstride, float* packed, int64_t packed_gstride, int32_t max_elems,
+                    vv_stream stream);
+
+/* ---- BatchNorm (nn.BatchNorm2d(eps=1e-5, momentum=0.1), model/unet.py:11,14) ----
+ * train != 0: batch statistics from the conv's partial sums; writes scale/shift a,b for the consumer's load,
+ *             mean / invstd for the backward pass, and updates running_mean / running_var (unbiased) in place.
+ * train == 0: a,b from the running statistics. */
+int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t train, float momentum, float eps,
+                   const float* stats, int64_t stats_gstride, const float* gamma, const float* beta,
+                   int64_t param_gstride, float* running_mean, float* running_var, int64_t buf_gstride,
+                   float* a, float* b, float* mean, float* invstd, int64_t ab_gstride, vv_stream stream);
+
+/* BatchNorm + ReLU (+ MaxPool, + skip fan-in) backward, phase 1:
+ * dz = (dA0 [+ route(dPool)]) * [a*y+b > 0]; writes dz and per-block partial sums of dz and dz*xhat. */
+typedef struct vv_bnbwd_params {
+  int32_t G, B, H, W, C;
+  const float* y; int64_t y_gstride;             /* pre-BN conv output [B,H,W,C] */
+  const float* a; const float* b; const float* mean; const float* invstd; int64_t ab_gstride;
+  vv_view dA;                                    /* gradient wrt the post-ReLU activation (same resolution) */
+  const float* dpool; int64_t dpool_gstride;     /* NULL or gradient wrt maxpool2(act) [B,H/2,W/2,C] */
+  float* dz; int64_t dz_gstride;                 /* out [B,H,W,C] */
+  float* partial;                                /* [G][nblk][2][C] */
+} vv_bnbwd_params;
+int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream);
+int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C);
+/* phase 2: sums the partials (fixed order), writes dgamma/dbeta, then dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
+ * in place over dz. */
+int vv_bn_bwd_apply(int32_t G, int64_t M, int32_t C, int32_t nblk, const float* partial,
+                    const float* y, int64_t y_gstride, const float* gamma, int64_t param_gstride,
+                    const float* mean, const float* invstd, int64_t ab_gstride,
+                    float* dgamma, float* dbeta, int64_t grad_gstride,
+                    float* dz, int64_t dz_gstride, float* scratch /* [G][2][C] */, vv_stream stream);
+
+/* ---- output 1x1 conv + squared error (model/unet.py:63-70 ; train.py:385-392,421-426 ; test.py:330-335) ----
+ * out[p][co] = bias[co] + sum_c relu(a*y+b)[p][c] * W[co][c];  score[g][cube] = sum (out - target)^2;
+ * optional dout[p][co] = gscale[g] * (out - target)  (gradient of lambda * MSELoss(mean)). */
+typedef struct vv_outconv_params {
+  int32_t G, B, HW, C;           /* HW pixels per cube (1024), C = features_root */
+  const float* y; int64_t y_gstride; const float* a; const float* b; int64_t ab_gstride;
+  const float* w; const float* bias; int64_t param_gstride;   /* W [oc][C], bias [oc] inside the parameter block */
+  const int32_t* oc;             /* [G] output channels (3 raw / 2 flow) */
+  const float* tgt0; int32_t tgt0_cstride; int32_t pad0;   /* cube NHWC [B,HW,15] */
+  const float* tgt1; int32_t tgt1_cstride; int32_t pad1;   /* flow NHWC [B,HW,2*T_of] */
+  const int32_t* tgt_src;        /* [G] 0: tgt0, 1: tgt1 */
+  const int32_t* tgt_coff;       /* [G] first target channel */
+  float* out4;                   /* [G][B*HW][4] reconstruction (channels >= oc are 0) */
+  float* score;                  /* [G][B] */
+  const float* gscale;           /* NULL or [G] */
+  float* dout4;                  /* NULL or [G][B*HW][4] */
+} vv_outconv_params;
+int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream);
+
+/* backward of the 1x1 conv: dA[p][c] = sum_co dout[p][co] W[co][c]; dW[co][c] = sum_p dout[p][co] act[p][c];
+ * db[co] = sum_p dout[p][co].  partial: [G][nblk][132]; reduced by vv_outconv_bwd_reduce. */
+int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
+                   int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
+                   int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial, vv_stream stream);
+int vv_outconv_bwd_nblk(int32_t B, int32_t HW);
+int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
+                          float* dW, float* db, int64_t grad_gstride, vv_stream stream);
+
+/* bias gradient of the transposed conv: db[co] = sum_pixels dy[p][co] (two-stage, deterministic) */
+int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, int64_t dy_gstride, int32_t cstride,
+                 int32_t coff, float* scratch, float* db, int64_t grad_gstride, vv_stream stream);
+
+/* ---- fused Adam over one flat buffer (torch.optim.Adam(eps=1e-7), train.py:376,400-402) ---- */
+int vv_adam(int64_t n, float* param, const float* grad, float* m, float* v, float lr, float beta1, float beta2,
+            float eps, float bias_corr1, float bias_corr2_sqrt, float grad_scale, vv_stream stream);
+
+/* ---- cube adapter (vad_datasets.py:130-168: [T,H,W,C] -> [H,W,T*C], uint8 -> float/255) ----
+ * raw  uint8 [N][T][HW][3]  -> x   fp32 NHWC [B][HW][3T]   for the cubes idx[0..B)
+ * flow fp32  [N][Tf][HW][2] -> xof fp32 NHWC [B][HW][2Tf]                                      */
+int vv_cube_gather(int32_t B, int32_t T, int32_t Tf, int32_t HW, const int64_t* idx, const uint8_t* raw,
+                   const float* flow, float* x, float* xof, vv_stream stream);
+
+/* NCHW <-> NHWC for the module surface (forward(x, x_of) takes NCHW like the reference) */
+int vv_nchw_to_nhwc(int32_t B, int32_t C, int32_t HW, const float* src, float* dst, vv_stream stream);
+/* gathers channels [0,oc) of out4[g] into NCHW dst[b][choff + ...] ; dst has Ctot channels */
+int vv_out4_to_nchw(int32_t B, int32_t HW, int32_t oc, const float* out4, float* dst, int32_t Ctot,
+                    int32_t choff, vv_stream stream);
+int vv_nchw_to_out4(int32_t B, int32_t HW, int32_t oc, const float* src, int32_t Ctot, int32_t choff,
+                    float* out4, vv_stream stream);
+
+/* ---- FlowNet2 native ops (forward only; FlowNet2 is inference-only in VEC_VAD, calc_optical_flow.py:56-57) ----
+ * Same argument meaning as the reference's cffi functions, NCHW fp32 contiguous, stream = current stream.
+ * Correlation_forward_cuda  (ops/correlation/src/correlation_cuda.c:11-93, correlation_cuda_kernel.cu:10-106):
+ *   no rInput scratch is needed (bounds are predicated instead of materialising zero-padded NHWC copies). */
+int vv_correlation_fwd(const float* in1, const float* in2, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                       int32_t pad_size, int32_t kernel_size, int32_t max_displacement, int32_t stride1,
+                       int32_t stride2, int32_t corr_type_multiply, vv_stream stream);
+int vv_correlation_out_shape(int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
+                             int32_t max_displacement, int32_t stride1, int32_t stride2, int32_t* oC, int32_t* oH,
+                             int32_t* oW);
+/* Resample2d_cuda_forward (ops/resample2d/src/Resample2d_cuda.c:8-11, Resample2d_kernel.cu:20-66) */
+int vv_resample2d_fwd(const float* img, const float* flow, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                      int32_t fH, int32_t fW, int32_t kernel_size, vv_stream stream);
+/* ChannelNorm_cuda_forward (ops/channelnorm/src/ChannelNorm_cuda.c:8-11, ChannelNorm_kernel.cu:19-51) */
+int vv_channelnorm_fwd(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t norm_deg,
+                       vv_stream stream);
+
+/* library self-description */
+const char* vv_version(void);
+int vv_device_arch_ok(void); /* 1 when the current device is gfx950 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VECVAD_HIP_H */

@@ -1,0 +1,134 @@
+"""ctypes binding of libvecvad_hip.so (the C ABI declared in include/vecvad_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call returns a non-zero status this module
+raises.  The reference's equivalent seam is the cffi glue of the FlowNet2 ops
+(FlowNet2_src/models/components/ops/*/functions/*.py) -- python allocates tensors, C launches on the current stream.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libvecvad_hip.so')
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+IN_PLAIN, IN_ACT, IN_POOL, IN_CAT, IN_CUBE = 0, 1, 2, 3, 4
+CONV3, CONVT_FWD, CONVT_DGRAD = 0, 1, 2
+
+
+class View(C.Structure):
+    _fields_ = [('ptr', c_vp), ('gstride', c_i64), ('cstride', c_i32), ('coff', c_i32)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [('kind', c_i32), ('in_mode', c_i32), ('G', c_i32), ('B', c_i32), ('H', c_i32), ('W', c_i32),
+                ('Cin', c_i32), ('CinP', c_i32), ('Cout', c_i32),
+                ('src0', View), ('a', c_vp), ('b', c_vp), ('ab_gstride', c_i64),
+                ('src1', View), ('csplit', c_i32), ('pad0', c_i32), ('chmap', c_vp),
+                ('w', c_vp), ('w_gstride', c_i64), ('bias', c_vp), ('bias_gstride', c_i64),
+                ('out', View), ('stats', c_vp)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [('kind', c_i32), ('in_mode', c_i32), ('G', c_i32), ('B', c_i32), ('H', c_i32), ('W', c_i32),
+                ('Cin', c_i32), ('CinP', c_i32), ('Cout', c_i32), ('ksplit', c_i32),
+                ('src0', View), ('a', c_vp), ('b', c_vp), ('ab_gstride', c_i64),
+                ('src1', View), ('csplit', c_i32), ('pad0', c_i32), ('chmap', c_vp),
+                ('dy', View), ('partial', c_vp), ('partial_gstride', c_i64)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [('src_off', c_i64), ('dst_off', c_i64), ('mode', c_i32), ('K', c_i32), ('KP', c_i32), ('N', c_i32)]
+
+
+class BnBwdParams(C.Structure):
+    _fields_ = [('G', c_i32), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32),
+                ('y', c_vp), ('y_gstride', c_i64),
+                ('a', c_vp), ('b', c_vp), ('mean', c_vp), ('invstd', c_vp), ('ab_gstride', c_i64),
+                ('dA', View), ('dpool', c_vp), ('dpool_gstride', c_i64),
+                ('dz', c_vp), ('dz_gstride', c_i64), ('partial', c_vp)]
+
+
+class OutconvParams(C.Structure):
+    _fields_ = [('G', c_i32), ('B', c_i32), ('HW', c_i32), ('C', c_i32),
+                ('y', c_vp), ('y_gstride', c_i64), ('a', c_vp), ('b', c_vp), ('ab_gstride', c_i64),
+                ('w', c_vp), ('bias', c_vp), ('param_gstride', c_i64), ('oc', c_vp),
+                ('tgt0', c_vp), ('tgt0_cstride', c_i32), ('pad0', c_i32),
+                ('tgt1', c_vp), ('tgt1_cstride', c_i32), ('pad1', c_i32),
+                ('tgt_src', c_vp), ('tgt_coff', c_vp), ('out4', c_vp), ('score', c_vp), ('gscale', c_vp),
+                ('dout4', c_vp)]
+
+
+_SIGS = {
+    'vv_conv_mfma': (c_i32, [C.POINTER(ConvParams), c_vp]),
+    'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
+    'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
+    'vv_wgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    'vv_wgrad_reduce': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'vv_pack_weights': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
+    'vv_bn_finalize': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp, c_i64,
+                               c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'vv_bn_bwd_reduce': (c_i32, [C.POINTER(BnBwdParams), c_vp]),
+    'vv_bn_bwd_nblk': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    'vv_bn_bwd_apply': (c_i32, [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64,
+                                c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'vv_outconv_fwd': (c_i32, [C.POINTER(OutconvParams), c_vp]),
+    'vv_outconv_bwd': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
+                               c_vp, c_i64, c_vp, c_vp]),
+    'vv_outconv_bwd_nblk': (c_i32, [c_i32, c_i32]),
+    'vv_outconv_bwd_reduce': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'vv_bias_grad': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    'vv_adam': (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    'vv_cube_gather': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vv_nchw_to_nhwc': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'vv_out4_to_nchw': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    'vv_nchw_to_out4': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    'vv_correlation_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                   c_i32, c_vp]),
+    'vv_correlation_out_shape': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                         C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
+    'vv_resample2d_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_channelnorm_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_version': (C.c_char_p, []),
+    'vv_device_arch_ok': (c_i32, []),
+}
+
+EXPORTS = sorted(_SIGS)
+_lib = None
+
+
+class VecVadHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built -- there is no CPU/PyTorch fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VecVadHipError('libvecvad_hip.so is missing (%s). Build it with `python -m vec_vad_amd.build` '
+                                 '(hipcc --offload-arch=gfx950); vec_vad_amd has no fallback path.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(l, name)      # AttributeError if the symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+_STATUS = {1: 'VV_ERR_BAD_ARG', 2: 'VV_ERR_LAUNCH', 3: 'VV_ERR_UNSUPPORTED'}
+
+
+def check(status, what=''):
+    if status != 0:
+        raise VecVadHipError('%s failed: %s' % (what or 'libvecvad_hip call', _STATUS.get(status, status)))
+
+
+def view(t, cstride, coff=0, gstride=0):
+    """vv_view over a torch tensor (or raw pointer)."""
+    ptr = t if isinstance(t, int) else t.data_ptr()
+    return View(ptr, int(gstride), int(cstride), int(coff))
+
+
+NULL_VIEW = View(None, 0, 0, 0)

@@ -1,0 +1,576 @@
+"""UNet-bank engine: the 6 / 10 independent completion UNets of VEC_VAD run as ONE grouped sequence of gfx950 kernels.
+
+This is the host side of the hot path.  It owns
+  * the flat parameter / gradient / Adam-moment buffers ([G][U] fp32, PyTorch OIHW order inside each UNet block, so a
+    reference ``state_dict`` maps 1:1 and Adam is a single fused launch and a single RCCL bucket per UNet),
+  * the NHWC activation workspace for a given batch size,
+  * a pre-built *launch plan* (ctypes argument blocks created once per batch size) for forward, backward and Adam,
+and it calls nothing but the C ABI of libvecvad_hip.so (include/vecvad_hip.h).  No torch.nn op runs on this path.
+
+Reference semantics implemented (paths relative to the reference root):
+  model/unet.py:4-70     double_conv / inconv / down / up / outconv
+  model/unet.py:172-267  SelfCompleteNet4.forward        model/unet.py:410-556  SelfCompleteNetFull.forward
+  train.py:385-402       loss = l_raw*MSE + l_of*MSE, backward, Adam(eps=1e-7)
+  train.py:421-426       per-cube squared-error scores (also test.py:330-335)
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+
+RAW_C, OF_C = 3, 2
+HW0 = 32           # cube side (patch_size, config.cfg)
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class UnitSpec:
+    """One UNet of the bank: which frame it erases from the input and what it predicts."""
+
+    def __init__(self, role, erase, tgt):
+        self.role, self.erase, self.tgt = role, erase, tgt
+        self.out_c = RAW_C if role == 'raw' else OF_C
+
+
+class ConvLayer:
+    def __init__(self, idx, H, cin, cout, mode, src, skip=None, up=None):
+        self.idx, self.H, self.cin, self.cout, self.mode, self.src, self.skip, self.up = idx, H, cin, cout, mode, src, skip, up
+        self.cinp = _ceil(cin, 16)
+
+
+class BankLayout:
+    """Per-UNet block layout (identical for every UNet; the 1x1 output conv is padded to 4 output rows)."""
+
+    def __init__(self, nf, in_ch):
+        self.nf, self.in_ch = nf, in_ch
+        c = nf
+        Ls = [ConvLayer(0, 32, in_ch, nf, L.IN_CUBE, 'cube'), ConvLayer(1, 32, nf, nf, L.IN_ACT, 0)]
+        H = 32
+        for d in range(3):
+            H //= 2
+            Ls.append(ConvLayer(len(Ls), H, c, 2 * c, L.IN_POOL, len(Ls) - 1))
+            Ls.append(ConvLayer(len(Ls), H, 2 * c, 2 * c, L.IN_ACT, len(Ls) - 1))
+            c *= 2
+        self.convT = []   # (src conv idx, Hin, cin, cout)
+        skips = [5, 3, 1]
+        for u in range(3):
+            self.convT.append((len(Ls) - 1, H, c, c // 2))
+            H *= 2
+            Ls.append(ConvLayer(len(Ls), H, c, c // 2, L.IN_CAT, None, skip=skips[u], up=u))
+            Ls.append(ConvLayer(len(Ls), H, c // 2, c // 2, L.IN_ACT, len(Ls) - 1))
+            c //= 2
+        self.convs = Ls
+        # ---- parameter block
+        off = 0
+        self.p = OrderedDict()      # key -> (offset, shape)
+        for l in Ls:
+            self.p['c%d.w' % l.idx] = (off, (l.cout, l.cin, 3, 3)); off += _ceil(l.cout * l.cin * 9, 4)
+            self.p['c%d.b' % l.idx] = (off, (l.cout,)); off += l.cout
+            self.p['c%d.g' % l.idx] = (off, (l.cout,)); off += l.cout
+            self.p['c%d.beta' % l.idx] = (off, (l.cout,)); off += l.cout
+        for u, (_, _, ci, co) in enumerate(self.convT):
+            self.p['t%d.w' % u] = (off, (ci, co, 3, 3)); off += ci * co * 9
+            self.p['t%d.b' % u] = (off, (co,)); off += co
+        self.p['o.w'] = (off, (4, nf, 1, 1)); off += 4 * nf      # rows >= out_c stay zero
+        self.p['o.b'] = (off, (4,)); off += 4
+        self.U = _ceil(off, 4)
+        # ---- buffer block (running statistics)
+        off = 0
+        self.b = OrderedDict()
+        for l in Ls:
+            self.b['c%d.rm' % l.idx] = (off, (l.cout,)); off += l.cout
+            self.b['c%d.rv' % l.idx] = (off, (l.cout,)); off += l.cout
+        self.UB = _ceil(off, 4)
+        # ---- packed (MFMA B-operand) block
+        off = 0
+        self.pk = OrderedDict()     # key -> (offset, mode, K, KP, N, src key)
+        for l in Ls:
+            self.pk['c%d.f' % l.idx] = (off, 0, l.cin, l.cinp, l.cout, 'c%d.w' % l.idx); off += 9 * l.cinp * l.cout
+            if l.idx > 0:
+                self.pk['c%d.d' % l.idx] = (off, 1, l.cout, l.cout, l.cin, 'c%d.w' % l.idx); off += 9 * l.cout * l.cin
+        for u, (_, _, ci, co) in enumerate(self.convT):
+            self.pk['t%d.f' % u] = (off, 2, ci, ci, co, 't%d.w' % u); off += 9 * ci * co
+            self.pk['t%d.d' % u] = (off, 3, co, co, ci, 't%d.w' % u); off += 9 * ci * co
+        self.UP = _ceil(off, 4)
+        self.cmax = 8 * nf
+
+
+def conv_key_to_state_name(stems, key):
+    """local key ('c5.w', 't1.b', 'o.w', 'c3.rm' ...) -> reference state_dict name (model/unet.py module tree)."""
+    kind, field = key.split('.')
+    if kind[0] == 'c':
+        l = int(kind[1:])
+        if l < 2:
+            prefix = stems['inc'] + '.conv.conv'
+        elif l < 8:
+            prefix = stems['down'][(l - 2) // 2] + '.mpconv.1.conv'
+        else:
+            prefix = stems['up'][(l - 8) // 2] + '.conv.conv'
+        ci, bi = (0, 1) if l % 2 == 0 else (3, 4)
+        return {'w': '%s.%d.weight' % (prefix, ci), 'b': '%s.%d.bias' % (prefix, ci),
+                'g': '%s.%d.weight' % (prefix, bi), 'beta': '%s.%d.bias' % (prefix, bi),
+                'rm': '%s.%d.running_mean' % (prefix, bi), 'rv': '%s.%d.running_var' % (prefix, bi)}[field]
+    if kind[0] == 't':
+        return stems['up'][int(kind[1:])] + '.up.' + {'w': 'weight', 'b': 'bias'}[field]
+    return stems['outc'] + '.conv.' + {'w': 'weight', 'b': 'bias'}[field]
+
+
+class _Plan:
+    def __init__(self):
+        self.calls = []     # (fn, args tuple without stream, label)
+        self.keep = []      # ctypes objects that must stay alive
+
+    def add(self, fn, args, label):
+        self.calls.append((fn, args, label))
+
+    def run(self, stream):
+        for fn, args, label in self.calls:
+            rc = fn(*args, stream)
+            if rc:
+                L.check(rc, label)
+
+
+class UNetBank:
+    def __init__(self, units, nf=32, tot_raw_num=5, tot_of_num=1, padding=False, active=None, device='cuda',
+                 lambda_raw=1.0, lambda_of=1.0):
+        self.lib = L.lib()
+        self.units = list(units)
+        self.G = len(self.units)
+        self.nf, self.tot_raw, self.tot_of, self.padding = nf, tot_raw_num, tot_of_num, padding
+        if nf % 32:
+            raise L.VecVadHipError('features_root must be a multiple of 32 for the MFMA tiles (got %d)' % nf)
+        self.in_ch = RAW_C * (tot_raw_num if padding else tot_raw_num - 1)
+        self.lay = BankLayout(nf, self.in_ch)
+        self.g0, self.Ga = active if active is not None else (0, self.G)
+        self.lambda_raw, self.lambda_of = lambda_raw, lambda_of
+        self.device = torch.device(device)
+        self._alloc_state()
+        self.ws = {}
+        self.adam_t = 0
+
+    # ------------------------------------------------------------------------------------------ persistent state
+    def _alloc_state(self):
+        d, lay, G = self.device, self.lay, self.G
+        self.params = torch.zeros(G, lay.U, device=d)
+        self.bufs = torch.zeros(G, lay.UB, device=d)
+        self.grads = torch.zeros(G, lay.U, device=d)
+        self.adam_m = None
+        self.adam_v = None
+        self.nbt = torch.zeros(G, len(lay.convs), dtype=torch.long, device=d)
+        self.packed = torch.zeros(G, lay.UP, device=d)
+        cin_p = lay.convs[0].cinp
+        chmap = torch.full((G, cin_p), -1, dtype=torch.int32)
+        oc = torch.zeros(G, dtype=torch.int32)
+        tsrc = torch.zeros(G, dtype=torch.int32)
+        tcoff = torch.zeros(G, dtype=torch.int32)
+        for g, u in enumerate(self.units):
+            if self.padding:      # model/unet.py:179-181: zero the erased frame, keep 15 channels
+                for k in range(self.in_ch):
+                    chmap[g, k] = -1 if u.erase * RAW_C <= k < (u.erase + 1) * RAW_C else k
+            else:                 # model/unet.py:183: drop the erased frame, keep temporal order
+                for k in range(self.in_ch):
+                    chmap[g, k] = k if k < u.erase * RAW_C else k + RAW_C
+            oc[g] = u.out_c
+            tsrc[g] = 0 if u.role == 'raw' else 1
+            tcoff[g] = u.tgt * (RAW_C if u.role == 'raw' else OF_C)
+        self.chmap, self.oc, self.tsrc, self.tcoff = chmap.to(d), oc.to(d), tsrc.to(d), tcoff.to(d)
+        ents = (L.PackEntry * len(lay.pk))()
+        mx = 0
+        for i, (k, (off, mode, K, KP, N, src)) in enumerate(lay.pk.items()):
+            ents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
+            mx = max(mx, 9 * KP * N)
+        self.pack_table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(d)
+        self.pack_n, self.pack_max = len(lay.pk), mx
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        for n in ('params', 'bufs', 'grads', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table'):
+            setattr(self, n, getattr(self, n).to(device))
+        if self.adam_m is not None:
+            self.adam_m, self.adam_v = self.adam_m.to(device), self.adam_v.to(device)
+        self.device = device
+        self.ws = {}
+        return self
+
+    def param_view(self, g, key):
+        off, shape = self.lay.p[key]
+        n = 1
+        for s in shape:
+            n *= s
+        return self.params[g, off:off + n].view(shape)
+
+    def grad_view(self, g, key, grads=None):
+        off, shape = self.lay.p[key]
+        n = 1
+        for s in shape:
+            n *= s
+        return (self.grads if grads is None else grads)[g, off:off + n].view(shape)
+
+    def buf_view(self, g, key):
+        off, shape = self.lay.b[key]
+        return self.bufs[g, off:off + shape[0]]
+
+    # ------------------------------------------------------------------------------------------ workspace + plans
+    def _p(self, t, off=0):
+        return t.data_ptr() + 4 * off
+
+    def workspace(self, B):
+        ws = self.ws.get(B)
+        if ws is None:
+            ws = self._build_ws(B)
+            if len(self.ws) > 3:
+                self.ws = {}
+            self.ws[B] = ws
+        return ws
+
+    def _build_ws(self, B):
+        lib, lay, d, Ga = self.lib, self.lay, self.device, self.Ga
+        nf = self.nf
+        f = lambda *s: torch.empty(*s, device=d, dtype=torch.float32)
+        ws = type('WS', (), {})()
+        ws.B = B
+        HWp = HW0 * HW0
+        ws.cube = f(B, HWp, RAW_C * self.tot_raw)
+        ws.flow = f(B, HWp, OF_C * self.tot_of)
+        ws.y = [f(Ga, B * l.H * l.H, l.cout) for l in lay.convs]
+        ws.t = [f(Ga, B * (2 * H) * (2 * H), co) for (_, H, ci, co) in lay.convT]
+        nt = [lib.vv_conv_ntiles(B, l.H, l.H) for l in lay.convs]
+        ws.stats = f(Ga, max(n * 2 * l.cout for n, l in zip(nt, lay.convs)))
+        ws.ab = torch.zeros(4, len(lay.convs), Ga, lay.cmax, device=d)
+        ws.out4 = f(Ga, B * HWp, 4)
+        ws.score = f(Ga, B)
+        ws.dout4 = torch.zeros(Ga, B * HWp, 4, device=d)
+        ws.gscale = torch.zeros(Ga, device=d)
+        n_raw = sum(1 for u in self.units[self.g0:self.g0 + Ga] if u.role == 'raw')
+        n_of = Ga - n_raw
+        gs = []
+        for u in self.units[self.g0:self.g0 + Ga]:
+            if u.role == 'raw':
+                gs.append(2.0 * self.lambda_raw / (B * n_raw * RAW_C * HWp))
+            else:
+                gs.append(2.0 * self.lambda_of / (B * n_of * OF_C * HWp))
+        ws.gscale.copy_(torch.tensor(gs))
+        ws.n_raw, ws.n_of = n_raw, n_of
+        ws.fwd = {True: self._plan_forward(ws, B, True), False: self._plan_forward(ws, B, False)}
+        ws.bwd = None
+        return ws
+
+    def _src_for(self, ws, l):
+        """(src0 view, a, b, src1 view, csplit, chmap) of conv layer l's input."""
+        lay, Ga = self.lay, self.Ga
+        abg = lay.cmax
+        if l.mode == L.IN_CUBE:
+            return (L.view(ws.cube, ws.cube.shape[2], 0, 0), None, None, L.NULL_VIEW, 0,
+                    self._p(self.chmap, self.g0 * l.cinp))
+        if l.mode in (L.IN_ACT, L.IN_POOL):
+            s = lay.convs[l.src]
+            y = ws.y[s.idx]
+            return (L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]), L.NULL_VIEW, 0, None)
+        s = lay.convs[l.skip]
+        y, t = ws.y[s.idx], ws.t[l.up]
+        return (L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]),
+                L.view(t, t.shape[2], 0, t.stride(0)), s.cout, None)
+
+    def _plan_forward(self, ws, B, train):
+        lib, lay, Ga, g0 = self.lib, self.lay, self.Ga, self.g0
+        U, UB, UP = lay.U, lay.UB, lay.UP
+        P = _Plan()
+        pbase, bbase, kbase = self._p(self.params, g0 * U), self._p(self.bufs, g0 * UB), self._p(self.packed, g0 * UP)
+        P.add(lib.vv_pack_weights, (self.pack_table.data_ptr(), self.pack_n, Ga, pbase, U, kbase, UP, self.pack_max), 'pack')
+        abg = lay.cmax
+
+        def conv(l):
+            s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
+            y = ws.y[l.idx]
+            cp = L.ConvParams(L.CONV3, l.mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, 0, chmap,
+                              kbase + 4 * lay.pk['c%d.f' % l.idx][0], UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
+                              L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
+            P.keep.append(cp)
+            P.add(lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
+            nt = lib.vv_conv_ntiles(B, l.H, l.H)
+            P.add(lib.vv_bn_finalize,
+                  (Ga, l.cout, nt, B * l.H * l.H, 1 if train else 0, 0.1, 1e-5, ws.stats.data_ptr(), nt * 2 * l.cout,
+                   pbase + 4 * lay.p['c%d.g' % l.idx][0], pbase + 4 * lay.p['c%d.beta' % l.idx][0], U,
+                   bbase + 4 * lay.b['c%d.rm' % l.idx][0], bbase + 4 * lay.b['c%d.rv' % l.idx][0], UB,
+                   self._p(ws.ab[0, l.idx]), self._p(ws.ab[1, l.idx]), self._p(ws.ab[2, l.idx]), self._p(ws.ab[3, l.idx]), abg),
+                  'bn%d' % l.idx)
+
+        def convT(u):
+            sidx, H, ci, co = lay.convT[u]
+            y, t = ws.y[sidx], ws.t[u]
+            cp = L.ConvParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, L.view(y, ci, 0, y.stride(0)),
+                              self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, 0, None,
+                              kbase + 4 * lay.pk['t%d.f' % u][0], UP, pbase + 4 * lay.p['t%d.b' % u][0], U,
+                              L.view(t, co, 0, t.stride(0)), None)
+            P.keep.append(cp)
+            P.add(lib.vv_conv_mfma, (C.byref(cp),), 'convT%d' % u)
+
+        for l in lay.convs:
+            if l.mode == L.IN_CAT:
+                convT(l.up)
+            conv(l)
+        last = lay.convs[-1]
+        y = ws.y[last.idx]
+        op = L.OutconvParams(Ga, B, HW0 * HW0, self.nf, y.data_ptr(), y.stride(0), self._p(ws.ab[0, last.idx]),
+                             self._p(ws.ab[1, last.idx]), abg, pbase + 4 * lay.p['o.w'][0], pbase + 4 * lay.p['o.b'][0], U,
+                             self._p(self.oc, g0), ws.cube.data_ptr(), ws.cube.shape[2], 0, ws.flow.data_ptr(),
+                             ws.flow.shape[2], 0, self._p(self.tsrc, g0), self._p(self.tcoff, g0), ws.out4.data_ptr(),
+                             ws.score.data_ptr(), ws.gscale.data_ptr() if train else None,
+                             ws.dout4.data_ptr() if train else None)
+        P.keep.append(op)
+        P.add(lib.vv_outconv_fwd, (C.byref(op),), 'outconv')
+        return P
+
+    def _plan_backward(self, ws, B):
+        lib, lay, Ga, g0, d = self.lib, self.lay, self.Ga, self.g0, self.device
+        U, UB, UP = lay.U, lay.UB, lay.UP
+        nf = self.nf
+        f = lambda *s: torch.empty(*s, device=d, dtype=torch.float32)
+        P = _Plan()
+        pbase, kbase = self._p(self.params, g0 * U), self._p(self.packed, g0 * UP)
+        gbase = self._p(self.grads, g0 * U)
+        abg = lay.cmax
+        HWp = HW0 * HW0
+        last = lay.convs[-1]
+        # buffers
+        ws.gA_last = f(Ga, B * HWp, nf)
+        ws.D = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.idx > 0}
+        ws.DT = [f(Ga, B * H * H, ci) for (_, H, ci, co) in lay.convT]
+        ws.dz = f(Ga, B * HWp * nf)
+        nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
+        ws.bnpart = f(Ga, max(n * 2 * l.cout for n, l in zip(nblk, lay.convs)))
+        ws.bnscr = f(Ga, 2 * lay.cmax)
+        ws.ocpart = f(Ga, B, 132)
+        ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
+        # wgrad split-K choice: ~1024 workgroups per launch
+        wplan = {}
+        wmax = 0
+        for l in lay.convs:
+            nci, nco = (l.cinp + 31) // 32, l.cout // 32
+            nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
+            ks = max(1, min(nt, 1024 // max(1, Ga * nci * nco)))
+            wplan['c%d' % l.idx] = (ks, nci * nco * ks * 4)
+            wmax = max(wmax, nci * nco * ks * 4)
+        for u, (_, H, ci, co) in enumerate(lay.convT):
+            nci, nco = ci // 32, co // 32
+            nt = lib.vv_wgrad_ntiles(L.CONVT_FWD, B, H, H)
+            ks = max(1, min(nt, 1024 // max(1, Ga * nci * nco)))
+            wplan['t%d' % u] = (ks, nci * nco * ks * 4)
+            wmax = max(wmax, nci * nco * ks * 4)
+        ws.wpart = f(Ga, wmax * 9 * 1024)
+        wpg = ws.wpart.stride(0)
+
+        # 1x1 output conv
+        y = ws.y[last.idx]
+        P.add(lib.vv_outconv_bwd, (Ga, B, HWp, nf, ws.dout4.data_ptr(), y.data_ptr(), y.stride(0), self._p(ws.ab[0, last.idx]),
+                                   self._p(ws.ab[1, last.idx]), abg, pbase + 4 * lay.p['o.w'][0], U, ws.gA_last.data_ptr(),
+                                   ws.gA_last.stride(0), ws.ocpart.data_ptr()), 'outconv_bwd')
+        P.add(lib.vv_outconv_bwd_reduce, (Ga, nf, B, ws.ocpart.data_ptr(), self._p(self.oc, g0), gbase + 4 * lay.p['o.w'][0],
+                                          gbase + 4 * lay.p['o.b'][0], U), 'outconv_bwd_reduce')
+
+        def dA_for(l):
+            """(dA view, dpool ptr, dpool gstride) feeding the BN backward of conv layer l."""
+            i = l.idx
+            if i == last.idx:
+                return L.view(ws.gA_last, nf, 0, ws.gA_last.stride(0)), None, 0
+            nxt = lay.convs[i + 1] if i + 1 < len(lay.convs) else None
+            # who consumes act(y_i)?
+            cons_t = [u for u, (sidx, _, _, _) in enumerate(lay.convT) if sidx == i]
+            skip_of = [m for m in lay.convs if m.mode == L.IN_CAT and m.skip == i]
+            pool_of = [m for m in lay.convs if m.mode == L.IN_POOL and m.src == i]
+            if cons_t:
+                t = ws.DT[cons_t[0]]
+                return L.view(t, t.shape[2], 0, t.stride(0)), None, 0
+            if skip_of:
+                m = skip_of[0]
+                dcat = ws.D[m.idx]
+                dp = ws.D[pool_of[0].idx] if pool_of else None
+                return (L.view(dcat, m.cin, 0, dcat.stride(0)), dp.data_ptr() if dp is not None else None,
+                        dp.stride(0) if dp is not None else 0)
+            m = nxt
+            dn = ws.D[m.idx]
+            return L.view(dn, m.cin, 0, dn.stride(0)), None, 0
+
+        def conv_bwd(l):
+            i = l.idx
+            y = ws.y[i]
+            dA, dpool, dpg = dA_for(l)
+            bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout, y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
+                               self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, ws.dz.data_ptr(), ws.dz.stride(0),
+                               ws.bnpart.data_ptr())
+            P.keep.append(bp)
+            P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i)
+            nb = lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout)
+            P.add(lib.vv_bn_bwd_apply, (Ga, B * l.H * l.H, l.cout, nb, ws.bnpart.data_ptr(), y.data_ptr(), y.stride(0),
+                                        pbase + 4 * lay.p['c%d.g' % i][0], U, self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg,
+                                        gbase + 4 * lay.p['c%d.g' % i][0], gbase + 4 * lay.p['c%d.beta' % i][0], U,
+                                        ws.dz.data_ptr(), ws.dz.stride(0), ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i)
+            # weight gradient
+            s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
+            ks, nslab = wplan['c%d' % i]
+            wp = L.WgradParams(L.CONV3, l.mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit, 0, chmap,
+                               L.View(ws.dz.data_ptr(), ws.dz.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
+            P.keep.append(wp)
+            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i)
+            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * 4, ws.wpart.data_ptr(), wpg,
+                                        gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i)
+            # data gradient
+            if i > 0:
+                Dl = ws.D[i]
+                cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
+                                  L.View(ws.dz.data_ptr(), ws.dz.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, 0, None,
+                                  kbase + 4 * lay.pk['c%d.d' % i][0], UP, None, 0, L.view(Dl, l.cin, 0, Dl.stride(0)), None)
+                P.keep.append(cp)
+                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i)
+
+        def convT_bwd(u, m):
+            """m: the CAT conv layer that consumed convT u; its data gradient holds d(convT out) in channels [skipC, cin)."""
+            sidx, H, ci, co = lay.convT[u]
+            dcat = ws.D[m.idx]
+            skipc = lay.convs[m.skip].cout
+            dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
+            P.add(lib.vv_bias_grad, (Ga, B * (2 * H) * (2 * H), co, dcat.data_ptr(), dcat.stride(0), m.cin, skipc,
+                                     ws.bscr.data_ptr(), gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u)
+            y = ws.y[sidx]
+            ks, nslab = wplan['t%d' % u]
+            wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
+                               self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, 0, None, dy,
+                               ws.wpart.data_ptr(), wpg)
+            P.keep.append(wp)
+            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u)
+            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * 4, ws.wpart.data_ptr(), wpg,
+                                        gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u)
+            DT = ws.DT[u]
+            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, 0, None,
+                              kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
+            P.keep.append(cp)
+            P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u)
+
+        for l in reversed(lay.convs):
+            conv_bwd(l)
+            if l.mode == L.IN_CAT:
+                convT_bwd(l.up, l)
+        return P
+
+    # ------------------------------------------------------------------------------------------ public operations
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def set_input_nchw(self, x, x_of):
+        """x [B,3T,32,32], x_of [B,2Tf,32,32] fp32 NCHW (the reference's forward(x, x_of) arguments)."""
+        B = x.shape[0]
+        ws = self.workspace(B)
+        x = x.contiguous().float()
+        L.check(self.lib.vv_nchw_to_nhwc(B, x.shape[1], HW0 * HW0, x.data_ptr(), ws.cube.data_ptr(), self._stream()), 'nchw_to_nhwc')
+        if x_of is not None and ws.flow.numel():
+            x_of = x_of.contiguous().float()
+            L.check(self.lib.vv_nchw_to_nhwc(B, x_of.shape[1], HW0 * HW0, x_of.data_ptr(), ws.flow.data_ptr(), self._stream()),
+                    'nchw_to_nhwc')
+        return ws
+
+    def set_input_cubes(self, raw_u8, flow, idx=None, B=None):
+        """Device-resident cube store: raw uint8 [N,T,32,32,3], flow fp32 [N,Tf,32,32,2]; idx int64 [B] (or first B)."""
+        B = int(idx.numel()) if idx is not None else (B if B is not None else raw_u8.shape[0])
+        ws = self.workspace(B)
+        L.check(self.lib.vv_cube_gather(B, self.tot_raw, self.tot_of, HW0 * HW0, idx.data_ptr() if idx is not None else None,
+                                        raw_u8.data_ptr(), flow.data_ptr() if flow is not None else None, ws.cube.data_ptr(),
+                                        ws.flow.data_ptr(), self._stream()), 'cube_gather')
+        return ws
+
+    def forward(self, ws, train):
+        """Runs the grouped forward.  train=True: batch statistics, running-stat update, dout4 = d(loss)/d(out)."""
+        ws.fwd[bool(train)].run(self._stream())
+        if train:
+            self.nbt[self.g0:self.g0 + self.Ga] += 1
+        return ws.score
+
+    def backward(self, ws):
+        """Gradients of everything wrt ws.dout4 into self.grads (conv biases in front of BatchNorm get exact zeros)."""
+        if ws.bwd is None:
+            ws.bwd = self._plan_backward(ws, ws.B)
+        ws.bwd.run(self._stream())
+
+    def losses(self, ws):
+        """(loss_raw, loss_of) as device scalars from the per-cube squared errors (train.py:385-392)."""
+        HWp = HW0 * HW0
+        sc = ws.score
+        units = self.units[self.g0:self.g0 + self.Ga]
+        raw_rows = [i for i, u in enumerate(units) if u.role == 'raw']
+        of_rows = [i for i, u in enumerate(units) if u.role == 'of']
+        l_raw = sc[raw_rows].sum() / (ws.B * len(raw_rows) * RAW_C * HWp)
+        l_of = sc[of_rows].sum() / (ws.B * len(of_rows) * OF_C * HWp) if of_rows else None
+        return l_raw, l_of
+
+    def cube_scores(self, ws):
+        """per-cube raw / flow squared-error sums ([B] each), train.py:421-426."""
+        units = self.units[self.g0:self.g0 + self.Ga]
+        raw_rows = [i for i, u in enumerate(units) if u.role == 'raw']
+        of_rows = [i for i, u in enumerate(units) if u.role == 'of']
+        r = ws.score[raw_rows].sum(0)
+        o = ws.score[of_rows].sum(0) if of_rows else None
+        return r, o
+
+    def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, grads=None):
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+        self.adam_t += 1
+        bc1 = 1.0 - beta1 ** self.adam_t
+        bc2 = 1.0 - beta2 ** self.adam_t
+        g = self.grads if grads is None else grads
+        L.check(self.lib.vv_adam(self.params.numel(), self.params.data_ptr(), g.data_ptr(), self.adam_m.data_ptr(),
+                                 self.adam_v.data_ptr(), lr, beta1, beta2, eps, bc1, math.sqrt(bc2), grad_scale,
+                                 self._stream()), 'adam')
+
+    def outputs_nchw(self, ws):
+        """(of_out [B,2*n_of,32,32], raw_out [B,3*n_raw,32,32]) in the reference's channel order."""
+        B, HWp = ws.B, HW0 * HW0
+        units = self.units[self.g0:self.g0 + self.Ga]
+        raw_o = torch.empty(B, RAW_C * ws.n_raw, HW0, HW0, device=self.device)
+        of_o = torch.empty(B, OF_C * ws.n_of, HW0, HW0, device=self.device) if ws.n_of else None
+        ri = oi = 0
+        for i, u in enumerate(units):
+            src = ws.out4[i].data_ptr()
+            if u.role == 'raw':
+                L.check(self.lib.vv_out4_to_nchw(B, HWp, RAW_C, src, raw_o.data_ptr(), raw_o.shape[1], ri * RAW_C, self._stream()), 'out4')
+                ri += 1
+            else:
+                L.check(self.lib.vv_out4_to_nchw(B, HWp, OF_C, src, of_o.data_ptr(), of_o.shape[1], oi * OF_C, self._stream()), 'out4')
+                oi += 1
+        return of_o, raw_o
+
+    def set_dout_nchw(self, ws, d_of, d_raw):
+        """Load upstream gradients (NCHW, same shapes as outputs_nchw) into ws.dout4."""
+        B, HWp = ws.B, HW0 * HW0
+        units = self.units[self.g0:self.g0 + self.Ga]
+        ri = oi = 0
+        for i, u in enumerate(units):
+            dst = ws.dout4[i].data_ptr()
+            if u.role == 'raw':
+                if d_raw is None:
+                    ws.dout4[i].zero_()
+                else:
+                    L.check(self.lib.vv_nchw_to_out4(B, HWp, RAW_C, d_raw.data_ptr(), d_raw.shape[1], ri * RAW_C, dst, self._stream()), 'to_out4')
+                ri += 1
+            else:
+                if d_of is None:
+                    ws.dout4[i].zero_()
+                else:
+                    L.check(self.lib.vv_nchw_to_out4(B, HWp, OF_C, d_of.data_ptr(), d_of.shape[1], oi * OF_C, dst, self._stream()), 'to_out4')
+                oi += 1
+
+    def train_step(self, ws, lr=1e-3, eps=1e-7, grad_scale=1.0, allreduce=None):
+        """Fused fast path: forward (train) -> backward -> [gradient all-reduce] -> Adam.  No host sync."""
+        self.forward(ws, True)
+        self.backward(ws)
+        if allreduce is not None:
+            allreduce(self.grads)
+        self.adam_step(lr=lr, eps=eps, grad_scale=grad_scale)
+        return ws.score

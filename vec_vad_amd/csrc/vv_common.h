@@ -1,0 +1,129 @@
+// Shared device helpers for the gfx950 kernels of libvecvad_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vecvad_hip.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define VV_WG 256
+
+#define VV_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return VV_ERR_LAUNCH;            \
+  } while (0)
+
+// XCD-aware work-item remap: the dispatcher places block b on XCD b%8 (observed, MI355X_MICROARCH.md);
+// give every XCD one contiguous chunk of the work list so that workgroups sharing a UNet's weight panel
+// share an L2.  nper = ceil(total/8); grid = 8*nper; caller drops w >= total.
+__device__ __forceinline__ int vv_xcd_remap(int bid, int nper) { return (bid & 7) * nper + (bid >> 3); }
+
+__device__ __forceinline__ float4 vv_relu4(float4 v) {
+  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  return v;
+}
+__device__ __forceinline__ float4 vv_act4(float4 v, float4 a, float4 b) {
+  v.x = fmaxf(fmaf(a.x, v.x, b.x), 0.f);
+  v.y = fmaxf(fmaf(a.y, v.y, b.y), 0.f);
+  v.z = fmaxf(fmaf(a.z, v.z, b.z), 0.f);
+  v.w = fmaxf(fmaf(a.w, v.w, b.w), 0.f);
+  return v;
+}
+__device__ __forceinline__ float4 vv_max4(float4 p, float4 q) {
+  p.x = fmaxf(p.x, q.x); p.y = fmaxf(p.y, q.y); p.z = fmaxf(p.z, q.z); p.w = fmaxf(p.w, q.w);
+  return p;
+}
+
+// Resolved (per group) description of how a convolution reads its input.
+struct VVSrc {
+  const float* p0; int cs0, co0;
+  const float* a; const float* b;
+  const float* p1; int cs1, co1;
+  const int* chmap;
+  int csplit;
+  int mode;
+  int SH, SW;   // resolution of the conv-input coordinate space (for VV_IN_POOL the tensor itself is 2SH x 2SW)
+  int B;
+};
+
+template <typename P>
+__device__ __forceinline__ VVSrc vv_make_src(const P& p, int g, int SH, int SW) {
+  VVSrc s;
+  s.p0 = p.src0.ptr + (int64_t)g * p.src0.gstride; s.cs0 = p.src0.cstride; s.co0 = p.src0.coff;
+  s.a = p.a ? p.a + (int64_t)g * p.ab_gstride : nullptr;
+  s.b = p.b ? p.b + (int64_t)g * p.ab_gstride : nullptr;
+  s.p1 = p.src1.ptr ? p.src1.ptr + (int64_t)g * p.src1.gstride : nullptr; s.cs1 = p.src1.cstride; s.co1 = p.src1.coff;
+  s.chmap = p.chmap ? p.chmap + (int64_t)g * p.CinP : nullptr;
+  s.csplit = p.csplit; s.mode = p.in_mode; s.SH = SH; s.SW = SW; s.B = p.B;
+  return s;
+}
+
+// 4 consecutive input channels [c, c+4) of conv-input pixel (img, y, x); caller guarantees in-bounds coordinates.
+__device__ __forceinline__ float4 vv_fetch4(const VVSrc& s, int img, int y, int x, int c) {
+  switch (s.mode) {
+    case VV_IN_PLAIN: {
+      const float* q = s.p0 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs0 + s.co0 + c;
+      return *reinterpret_cast<const float4*>(q);
+    }
+    case VV_IN_ACT: {
+      const float* q = s.p0 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs0 + s.co0 + c;
+      return vv_act4(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(s.a + c),
+                     *reinterpret_cast<const float4*>(s.b + c));
+    }
+    case VV_IN_POOL: {
+      const int W2 = 2 * s.SW;
+      const float* q = s.p0 + ((int64_t)(img * 2 * s.SH + 2 * y) * W2 + 2 * x) * s.cs0 + s.co0 + c;
+      const float4 a = *reinterpret_cast<const float4*>(s.a + c);
+      const float4 b = *reinterpret_cast<const float4*>(s.b + c);
+      float4 v00 = vv_act4(*reinterpret_cast<const float4*>(q), a, b);
+      float4 v01 = vv_act4(*reinterpret_cast<const float4*>(q + s.cs0), a, b);
+      float4 v10 = vv_act4(*reinterpret_cast<const float4*>(q + (int64_t)W2 * s.cs0), a, b);
+      float4 v11 = vv_act4(*reinterpret_cast<const float4*>(q + (int64_t)(W2 + 1) * s.cs0), a, b);
+      return vv_max4(vv_max4(v00, v01), vv_max4(v10, v11));
+    }
+    case VV_IN_CAT: {
+      if (c < s.csplit) {
+        const float* q = s.p0 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs0 + s.co0 + c;
+        return vv_act4(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(s.a + c),
+                       *reinterpret_cast<const float4*>(s.b + c));
+      }
+      const float* q = s.p1 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs1 + s.co1 + (c - s.csplit);
+      return *reinterpret_cast<const float4*>(q);
+    }
+    default: {  // VV_IN_CUBE
+      const float* q = s.p0 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs0 + s.co0;
+      float4 v;
+      int m0 = s.chmap[c], m1 = s.chmap[c + 1], m2 = s.chmap[c + 2], m3 = s.chmap[c + 3];
+      v.x = m0 >= 0 ? q[m0] : 0.f;
+      v.y = m1 >= 0 ? q[m1] : 0.f;
+      v.z = m2 >= 0 ? q[m2] : 0.f;
+      v.w = m3 >= 0 ? q[m3] : 0.f;
+      return v;
+    }
+  }
+}
+
+// Cooperative load of a [NI][HH][HW][NCH] tile (NCH channels starting at c0, LDS pixel stride S floats) whose
+// top-left conv-input coordinate is (y0, x0) for images img0..img0+NI-1.  Out-of-image pixels are zero
+// (the convolution's zero padding applies to the post-activation tensor).
+template <int NI, int HH, int HW, int S, int NCH>
+__device__ __forceinline__ void vv_stage_tile(float* lds, const VVSrc& s, int img0, int y0, int x0, int c0, int tid,
+                                              int cmax = 1 << 30) {
+  constexpr int Q = NCH / 4;
+  constexpr int NITEMS = NI * HH * HW * Q;
+#pragma unroll 2
+  for (int it = tid; it < NITEMS; it += VV_WG) {
+    const int q = it % Q;
+    const int hp = it / Q;
+    const int hx = hp % HW;
+    const int t = hp / HW;
+    const int hy = t % HH;
+    const int im = t / HH;
+    const int img = img0 + im, y = y0 + hy, x = x0 + hx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (img < s.B && (unsigned)y < (unsigned)s.SH && (unsigned)x < (unsigned)s.SW && c0 + q * 4 < cmax)
+      v = vv_fetch4(s, img, y, x, c0 + q * 4);
+    *reinterpret_cast<float4*>(lds + hp * S + q * 4) = v;
+  }
+}

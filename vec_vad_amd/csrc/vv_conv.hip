@@ -1,0 +1,244 @@
+// MFMA implicit-GEMM convolutions for the UNet bank (gfx950, v_mfma_f32_32x32x2_f32 -> exact fp32).
+//
+// One workgroup = 256 threads (4 waves) = one tile of 256 output pixels x TN (32|64) output channels of one UNet.
+//   GEMM view:  M = pixels (B*H*W), N = Cout, K = taps * Cin.
+//   A operand : input activations, staged global -> registers -> LDS as a halo tile [NI][HH][HW][CK+4] with the
+//               producer's BatchNorm+ReLU (+2x2 max-pool, +skip concat, +frame erasure) applied on the way in,
+//               read back as ds_read_b128: lane l gets 4 consecutive channels of pixel (l&31), channel group (l>>5).
+//   B operand : pre-packed weight panels [tap][Cin/8][2][Cout][4] read straight from global/L2 as one
+//               global_load_dwordx4 per lane (fully coalesced 512 B per half-wave), no LDS.
+//   One float4 of A and one of B feed 4 MFMAs (k-pairs (j, j+4) of an 8-channel group).
+//   Epilogue  : + bias, NHWC store (128 B contiguous per half-wave), per-channel sum / sum^2 partials for BatchNorm.
+//
+// Replaces: nn.Conv2d(k3,p1) forward (model/unet.py:10,13), its data gradient, nn.ConvTranspose2d(k3,s2,p1,op1)
+// forward (model/unet.py:54) and its data gradient; cuDNN calls in the reference.
+#include "vv_common.h"
+
+namespace {
+
+template <int KIND, int TH, int TW>
+struct Geo {
+  static constexpr int HH = KIND == VV_CONV3 ? TH + 2 : (KIND == VV_CONVT_FWD ? TH + 1 : 2 * TH + 1);
+  static constexpr int HW = KIND == VV_CONV3 ? TW + 2 : (KIND == VV_CONVT_FWD ? TW + 1 : 2 * TW + 1);
+  static constexpr int SP = KIND == VV_CONVT_DGRAD ? 2 : 1;  // lane pixel stride inside the halo tile
+};
+
+template <int TH, int TW, int NI, int NR, int KIND, int CK>
+__global__ void __launch_bounds__(VV_WG, 2)
+conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
+  using G_ = Geo<KIND, TH, TW>;
+  constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
+  constexpr int S = CK + 4;             // LDS pixel stride (floats): S/4 odd -> conflict-free ds_read_b128
+  constexpr int MR = 2;                 // 2 x 32 pixels per wave
+  constexpr int TN = NR * 32;
+  __shared__ float lds[NI * HH * HW * S];
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int pt = w % NT; w /= NT;
+  const int nn = w % NN; w /= NN;
+  constexpr int NPH = KIND == VV_CONVT_FWD ? 4 : 1;
+  const int ph = w % NPH;
+  const int g = w / NPH;
+  const int py = ph >> 1, px = ph & 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int H = p.H, W = p.W;
+  const int tilesX = W / TW, tilesY = H / TH;
+  const int tpi = tilesX * tilesY;
+  const int img0 = (pt / tpi) * NI;
+  const int trem = pt % tpi;
+  const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+
+  // conv-input coordinate space + tile origin in it
+  const int SH = KIND == VV_CONVT_DGRAD ? 2 * H : H, SW = KIND == VV_CONVT_DGRAD ? 2 * W : W;
+  const int oy0 = KIND == VV_CONV3 ? ty0 - 1 : (KIND == VV_CONVT_FWD ? ty0 : 2 * ty0 - 1);
+  const int ox0 = KIND == VV_CONV3 ? tx0 - 1 : (KIND == VV_CONVT_FWD ? tx0 : 2 * tx0 - 1);
+
+  const VVSrc s = vv_make_src(p, g, SH, SW);
+  const int Cout = p.Cout, CinP = p.CinP, KQ = CinP >> 3;
+  const int co0 = nn * TN;
+  const float* __restrict__ wg = p.w + (int64_t)g * p.w_gstride;
+
+  int abase[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int pp = wave * 64 + m * 32 + l31;
+    const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+    abase[m] = ((im * HH + r * SP) * HW + c * SP) * S + half * 4;
+  }
+
+  v16f acc[MR][NR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  // tap ranges
+  const int nty = KIND == VV_CONVT_FWD ? (py ? 2 : 1) : 3;
+  const int ntx = KIND == VV_CONVT_FWD ? (px ? 2 : 1) : 3;
+
+  for (int c0 = 0; c0 < CinP; c0 += CK) {
+    if (c0) __syncthreads();
+    vv_stage_tile<NI, HH, HW, S, CK>(lds, s, img0, oy0, ox0, c0, tid);
+    __syncthreads();
+
+    auto mma_tap = [&](const int aoff, const int wt) {
+#pragma unroll
+      for (int kg = 0; kg < CK / 8; ++kg) {
+        float4 a[MR], b[NR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + aoff + kg * 8);
+        const float* wp = wg + ((int64_t)((wt * KQ + (c0 >> 3) + kg) * 2 + half) * Cout + co0 + l31) * 4;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) b[n] = *reinterpret_cast<const float4*>(wp + n * 128);
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
+    };
+
+    if constexpr (KIND == VV_CONVT_FWD) {
+      // output parity phase (py,px): oy = 2*iy - 1 + ky  ->  py=0: ky=1 (iy=r) ; py=1: ky=2 (iy=r), ky=0 (iy=r+1)
+      for (int ty = 0; ty < nty; ++ty)
+        for (int tx = 0; tx < ntx; ++tx) {
+          const int ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1;
+          mma_tap((ty * HW + tx) * S, ky * 3 + kx);
+        }
+    } else {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) mma_tap((ky * HW + kx) * S, ky * 3 + kx);
+    }
+  }
+
+  // ---- epilogue: bias, store, BatchNorm partial statistics
+  const int OH = KIND == VV_CONVT_FWD ? 2 * H : H, OW = KIND == VV_CONVT_FWD ? 2 * W : W;
+  float* __restrict__ outg = p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff;
+  const int ocs = p.out.cstride;
+  float bias[NR], s1[NR], s2[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    bias[n] = p.bias ? p.bias[(int64_t)g * p.bias_gstride + co0 + n * 32 + l31] : 0.f;
+    s1[n] = 0.f; s2[n] = 0.f;
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+      const int pp = wave * 64 + m * 32 + row;
+      const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+      const int img = img0 + im;
+      if (img < p.B) {
+        const int oy = KIND == VV_CONVT_FWD ? 2 * (ty0 + r) + py : ty0 + r;
+        const int ox = KIND == VV_CONVT_FWD ? 2 * (tx0 + c) + px : tx0 + c;
+        float* o = outg + ((int64_t)(img * OH + oy) * OW + ox) * ocs + co0 + l31;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const float v = acc[m][n][i] + bias[n];
+          o[n * 32] = v;
+          s1[n] += v; s2[n] = fmaf(v, v, s2[n]);
+        }
+      }
+    }
+
+  if (p.stats) {
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      s1[n] += __shfl_xor(s1[n], 32);
+      s2[n] += __shfl_xor(s2[n], 32);
+      if (half == 0) {
+        lds[(wave * NR + n) * 32 + l31] = s1[n];
+        lds[4 * TN + (wave * NR + n) * 32 + l31] = s2[n];
+      }
+    }
+    __syncthreads();
+    if (tid < TN) {
+      const int n = tid >> 5, l = tid & 31;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        t1 += lds[(wv * NR + n) * 32 + l];
+        t2 += lds[4 * TN + (wv * NR + n) * 32 + l];
+      }
+      float* st = p.stats + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
+      st[0] = t1;
+      st[Cout] = t2;
+    }
+  }
+}
+
+struct TileGeo { int TH, TW, NI; };
+inline bool tile_geo(int H, int W, TileGeo* t) {
+  if (H != W) return false;
+  if (H == 32) { *t = {8, 32, 1}; return true; }
+  if (H == 16) { *t = {16, 16, 1}; return true; }
+  if (H == 8) { *t = {8, 8, 4}; return true; }
+  if (H == 4) { *t = {4, 4, 16}; return true; }
+  return false;
+}
+
+template <int TH, int TW, int NI, int NR, int KIND, int CK>
+int launch(const vv_conv_params* p, hipStream_t st) {
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
+  const int NN = p->Cout / (NR * 32);
+  const int NPH = KIND == VV_CONVT_FWD ? 4 : 1;
+  const int total = p->G * NPH * NN * NT;
+  const int nper = (total + 7) / 8;
+  hipLaunchKernelGGL((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
+                     total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+template <int KIND, int CK>
+int dispatch(const vv_conv_params* p, hipStream_t st) {
+  TileGeo t;
+  if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
+  const bool wide = (p->Cout % 64) == 0;
+  switch (p->H) {
+    case 32: return wide ? launch<8, 32, 1, 2, KIND, CK>(p, st) : launch<8, 32, 1, 1, KIND, CK>(p, st);
+    case 16: return wide ? launch<16, 16, 1, 2, KIND, CK>(p, st) : launch<16, 16, 1, 1, KIND, CK>(p, st);
+    case 8: return wide ? launch<8, 8, 4, 2, KIND, CK>(p, st) : launch<8, 8, 4, 1, KIND, CK>(p, st);
+    case 4: return wide ? launch<4, 4, 16, 2, KIND, CK>(p, st) : launch<4, 4, 16, 1, KIND, CK>(p, st);
+  }
+  return VV_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int vv_conv_ntiles(int32_t B, int32_t H, int32_t W) {
+  TileGeo t;
+  if (!tile_geo(H, W, &t)) return -1;
+  return ((B + t.NI - 1) / t.NI) * (H / t.TH) * (W / t.TW);
+}
+
+extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
+  if (!p || !p->src0.ptr || !p->w || !p->out.ptr) return VV_ERR_BAD_ARG;
+  if (p->G <= 0 || p->B <= 0) return VV_ERR_BAD_ARG;
+  if (p->Cout % 32) return VV_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  switch (p->kind) {
+    case VV_CONV3:
+      if (p->CinP % 16) return VV_ERR_BAD_ARG;
+      return dispatch<VV_CONV3, 16>(p, st);
+    case VV_CONVT_FWD:
+      if (p->CinP % 16) return VV_ERR_BAD_ARG;
+      return dispatch<VV_CONVT_FWD, 16>(p, st);
+    case VV_CONVT_DGRAD:
+      if (p->CinP % 8) return VV_ERR_BAD_ARG;
+      return dispatch<VV_CONVT_DGRAD, 8>(p, st);
+  }
+  return VV_ERR_BAD_ARG;
+}

@@ -1,0 +1,661 @@
+// HBM-bound kernels of the UNet bank: weight packing, BatchNorm finalise / backward, 1x1 output conv + squared
+// error (loss / per-cube score), fused Adam, cube adapter and layout converters.  All are grouped over the G
+// independent UNets (blockIdx.y or .z = group), vectorised to 16 B per lane and use fixed-order reductions
+// (wave shuffles + LDS + a second pass), never float atomics, so results are bitwise reproducible.
+#include "vv_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ pack
+__global__ void __launch_bounds__(VV_WG)
+pack_weights_kernel(const vv_pack_entry* __restrict__ table, const float* __restrict__ params,
+                    const int64_t params_gstride, float* __restrict__ packed, const int64_t packed_gstride) {
+  const vv_pack_entry e = table[blockIdx.y];
+  const int g = blockIdx.z;
+  const int total = 9 * e.KP * e.N;
+  const float* src = params + (int64_t)g * params_gstride + e.src_off;
+  float* dst = packed + (int64_t)g * packed_gstride + e.dst_off;
+  const int KQ = e.KP >> 3;
+  for (int d = blockIdx.x * VV_WG + threadIdx.x; d < total; d += gridDim.x * VV_WG) {
+    const int j = d & 3;
+    int t = d >> 2;
+    const int n = t % e.N; t /= e.N;
+    const int half = t & 1; t >>= 1;
+    const int kq = t % KQ;
+    const int tap = t / KQ;
+    const int k = kq * 8 + half * 4 + j;
+    float v = 0.f;
+    if (k < e.K) {
+      int64_t si;
+      switch (e.mode) {
+        case 0: si = ((int64_t)n * e.K + k) * 9 + tap; break;          // W[co=n][ci=k][tap]
+        case 1: si = ((int64_t)k * e.N + n) * 9 + (8 - tap); break;    // W[co=k][ci=n][flipped tap]
+        case 2: si = ((int64_t)k * e.N + n) * 9 + tap; break;          // Wt[ci=k][co=n][tap]
+        default: si = ((int64_t)n * e.K + k) * 9 + tap; break;         // Wt[ci=n][co=k][tap]
+      }
+      v = src[si];
+    }
+    dst[d] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalise
+// grid (C/32, G); 256 threads = 32 channels x 8 partial-sum lanes; fp64 accumulation of the fp32 tile partials.
+__global__ void __launch_bounds__(VV_WG)
+bn_finalize_kernel(const int C, const int ntiles, const double count, const int train, const float momentum,
+                   const float eps, const float* __restrict__ stats, const int64_t stats_gstride,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, const int64_t param_gstride,
+                   float* __restrict__ rmean, float* __restrict__ rvar, const int64_t buf_gstride,
+                   float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd,
+                   const int64_t ab_gstride) {
+  __shared__ double sh[2][8][32];
+  const int g = blockIdx.y;
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (train) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+      const float* st = stats + (int64_t)g * stats_gstride + c;
+      for (int t = part; t < ntiles; t += 8) {
+        s1 += (double)st[(int64_t)t * 2 * C];
+        s2 += (double)st[(int64_t)t * 2 * C + C];
+      }
+    }
+    sh[0][part][cl] = s1;
+    sh[1][part][cl] = s2;
+  }
+  __syncthreads();
+  if (part != 0 || c >= C) return;
+  const float gm = gamma[(int64_t)g * param_gstride + c], bt = beta[(int64_t)g * param_gstride + c];
+  float* rm = rmean + (int64_t)g * buf_gstride + c;
+  float* rv = rvar + (int64_t)g * buf_gstride + c;
+  double mu, var;
+  if (train) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+    mu = s1 / count;
+    var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    *rm = (float)((1.0 - (double)momentum) * (double)*rm + (double)momentum * mu);
+    *rv = (float)((1.0 - (double)momentum) * (double)*rv + (double)momentum * unb);
+  } else {
+    mu = (double)*rm;
+    var = (double)*rv;
+  }
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const int64_t o = (int64_t)g * ab_gstride + c;
+  a[o] = (float)((double)gm * is);
+  b[o] = (float)((double)bt - mu * (double)gm * is);
+  mean[o] = (float)mu;
+  invstd[o] = (float)is;
+}
+
+// ------------------------------------------------------------------------------------------------ BN backward
+// phase 1: dz = (dA [+ maxpool-routed dPool]) * [z > 0], partial sums of dz and dz * xhat per block of 256 pixels.
+template <bool POOL>
+__global__ void __launch_bounds__(VV_WG)
+bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk) {
+  __shared__ float sh[2][VV_WG * 4];
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int C = p.C, Q4 = C >> 2, PL = VV_WG / Q4;
+  const int q = threadIdx.x % Q4, pl = threadIdx.x / Q4;
+  const int c = q * 4;
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  const float* __restrict__ y = p.y + (int64_t)g * p.y_gstride;
+  float* __restrict__ dz = p.dz + (int64_t)g * p.dz_gstride;
+  const float* __restrict__ dA = p.dA.ptr + (int64_t)g * p.dA.gstride + p.dA.coff;
+  const int dcs = p.dA.cstride;
+  const int64_t abo = (int64_t)g * p.ab_gstride + c;
+  const float4 a4 = *reinterpret_cast<const float4*>(p.a + abo), b4 = *reinterpret_cast<const float4*>(p.b + abo);
+  const float4 m4 = *reinterpret_cast<const float4*>(p.mean + abo), i4 = *reinterpret_cast<const float4*>(p.invstd + abo);
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+
+  auto one = [&](const int64_t pix, float4 d) {
+    const float4 yv = *reinterpret_cast<const float4*>(y + pix * C + c);
+    float4 z;
+    z.x = fmaf(a4.x, yv.x, b4.x); z.y = fmaf(a4.y, yv.y, b4.y); z.z = fmaf(a4.z, yv.z, b4.z); z.w = fmaf(a4.w, yv.w, b4.w);
+    d.x = z.x > 0.f ? d.x : 0.f; d.y = z.y > 0.f ? d.y : 0.f; d.z = z.z > 0.f ? d.z : 0.f; d.w = z.w > 0.f ? d.w : 0.f;
+    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+    s2.x = fmaf(d.x, (yv.x - m4.x) * i4.x, s2.x); s2.y = fmaf(d.y, (yv.y - m4.y) * i4.y, s2.y);
+    s2.z = fmaf(d.z, (yv.z - m4.z) * i4.z, s2.z); s2.w = fmaf(d.w, (yv.w - m4.w) * i4.w, s2.w);
+    *reinterpret_cast<float4*>(dz + pix * C + c) = d;
+  };
+
+  if constexpr (!POOL) {
+    for (int i = pl; i < 256; i += PL) {
+      const int64_t pix = (int64_t)blk * 256 + i;
+      if (pix < M) one(pix, *reinterpret_cast<const float4*>(dA + pix * dcs + c));
+    }
+  } else {
+    // unit of work = one 2x2 pooling window (first maximum wins ties, like at::max_pool2d)
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+    const int64_t MW = M >> 2;
+    const float* __restrict__ dP = p.dpool + (int64_t)g * p.dpool_gstride;
+    for (int i = pl; i < 64; i += PL) {
+      const int64_t wi = (int64_t)blk * 64 + i;
+      if (wi >= MW) continue;
+      const int wx = (int)(wi % W2);
+      const int64_t t = wi / W2;
+      const int wy = (int)(t % H2);
+      const int64_t img = t / H2;
+      const int64_t p00 = (img * p.H + 2 * wy) * p.W + 2 * wx;
+      const int64_t px[4] = {p00, p00 + 1, p00 + p.W, p00 + p.W + 1};
+      float4 zz[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + px[k] * C + c);
+        zz[k].x = fmaxf(fmaf(a4.x, yv.x, b4.x), 0.f); zz[k].y = fmaxf(fmaf(a4.y, yv.y, b4.y), 0.f);
+        zz[k].z = fmaxf(fmaf(a4.z, yv.z, b4.z), 0.f); zz[k].w = fmaxf(fmaf(a4.w, yv.w, b4.w), 0.f);
+      }
+      int ix = 0, iy = 0, iz = 0, iw = 0;
+      float bx = zz[0].x, by = zz[0].y, bz = zz[0].z, bw = zz[0].w;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        if (zz[k].x > bx) { bx = zz[k].x; ix = k; }
+        if (zz[k].y > by) { by = zz[k].y; iy = k; }
+        if (zz[k].z > bz) { bz = zz[k].z; iz = k; }
+        if (zz[k].w > bw) { bw = zz[k].w; iw = k; }
+      }
+      const float4 dp = *reinterpret_cast<const float4*>(dP + wi * C + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4 d = *reinterpret_cast<const float4*>(dA + px[k] * dcs + c);
+        d.x += ix == k ? dp.x : 0.f; d.y += iy == k ? dp.y : 0.f; d.z += iz == k ? dp.z : 0.f; d.w += iw == k ? dp.w : 0.f;
+        one(px[k], d);
+      }
+    }
+  }
+  // block reduction over the PL pixel lanes in fixed order
+  float* r1 = sh[0];
+  float* r2 = sh[1];
+  *reinterpret_cast<float4*>(r1 + (pl * Q4 + q) * 4) = s1;
+  *reinterpret_cast<float4*>(r2 + (pl * Q4 + q) * 4) = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < PL; ++k) { t1 += r1[k * C + threadIdx.x]; t2 += r2[k * C + threadIdx.x]; }
+    float* o = p.partial + ((int64_t)(g * nblk + blk) * 2) * C + threadIdx.x;
+    o[0] = t1;
+    o[C] = t2;
+  }
+}
+
+// phase 2a: sum partials -> dbeta, dgamma, c1 = mean(dz), c2 = mean(dz*xhat)
+__global__ void __launch_bounds__(VV_WG)
+bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __restrict__ partial,
+                  float* __restrict__ dgamma, float* __restrict__ dbeta, const int64_t grad_gstride,
+                  float* __restrict__ scratch) {
+  __shared__ double sh[2][8][32];
+  const int g = blockIdx.y;
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    const float* st = partial + (int64_t)g * nblk * 2 * C + c;
+    for (int t = part; t < nblk; t += 8) {
+      s1 += (double)st[(int64_t)t * 2 * C];
+      s2 += (double)st[(int64_t)t * 2 * C + C];
+    }
+  }
+  sh[0][part][cl] = s1;
+  sh[1][part][cl] = s2;
+  __syncthreads();
+  if (part != 0 || c >= C) return;
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+  dbeta[(int64_t)g * grad_gstride + c] = (float)s1;
+  dgamma[(int64_t)g * grad_gstride + c] = (float)s2;
+  scratch[(int64_t)g * 2 * C + c] = (float)(s1 / M);
+  scratch[(int64_t)g * 2 * C + C + c] = (float)(s2 / M);
+}
+
+// phase 2b: dy = gamma*invstd*(dz - c1 - xhat*c2), in place
+__global__ void __launch_bounds__(VV_WG)
+bn_bwd_apply_kernel(const int64_t n4, const int C, const float* __restrict__ y, const int64_t y_gstride,
+                    const float* __restrict__ gamma, const int64_t param_gstride, const float* __restrict__ mean,
+                    const float* __restrict__ invstd, const int64_t ab_gstride, const float* __restrict__ scratch,
+                    float* __restrict__ dz, const int64_t dz_gstride) {
+  const int g = blockIdx.y;
+  const int Q4 = C >> 2;
+  const float* yg = y + (int64_t)g * y_gstride;
+  float* dg = dz + (int64_t)g * dz_gstride;
+  for (int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x; e < n4; e += (int64_t)gridDim.x * VV_WG) {
+    const int c = (int)(e % Q4) * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + (int64_t)g * param_gstride + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)g * ab_gstride + c);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + (int64_t)g * ab_gstride + c);
+    const float4 c1 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + c);
+    const float4 c2 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + C + c);
+    const float4 yv = *reinterpret_cast<const float4*>(yg + e * 4);
+    float4 d = *reinterpret_cast<const float4*>(dg + e * 4);
+    d.x = gm.x * is.x * (d.x - c1.x - (yv.x - mu.x) * is.x * c2.x);
+    d.y = gm.y * is.y * (d.y - c1.y - (yv.y - mu.y) * is.y * c2.y);
+    d.z = gm.z * is.z * (d.z - c1.z - (yv.z - mu.z) * is.z * c2.z);
+    d.w = gm.w * is.w * (d.w - c1.w - (yv.w - mu.w) * is.w * c2.w);
+    *reinterpret_cast<float4*>(dg + e * 4) = d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ output conv
+// grid (B, G): one block = one cube (HW pixels) of one UNet; 8 lanes per pixel, 4 channels per lane (C = 32).
+__global__ void __launch_bounds__(VV_WG)
+outconv_fwd_kernel(const vv_outconv_params p) {
+  __shared__ float red[4];
+  const int g = blockIdx.y, cube = blockIdx.x;
+  const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
+  const int c = sub * 4;
+  const int C = p.C, oc = p.oc[g];
+  const int64_t abo = (int64_t)g * p.ab_gstride + c;
+  const float4 a4 = *reinterpret_cast<const float4*>(p.a + abo), b4 = *reinterpret_cast<const float4*>(p.b + abo);
+  float4 wv[4];
+  float bias[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    if (co < oc) {
+      wv[co] = *reinterpret_cast<const float4*>(p.w + (int64_t)g * p.param_gstride + co * C + c);
+      bias[co] = p.bias[(int64_t)g * p.param_gstride + co];
+    } else {
+      wv[co] = make_float4(0, 0, 0, 0);
+      bias[co] = 0.f;
+    }
+  }
+  const int tsrc = p.tgt_src[g], tco = p.tgt_coff[g];
+  const float* tgt = tsrc == 0 ? p.tgt0 : p.tgt1;
+  const int tcs = tsrc == 0 ? p.tgt0_cstride : p.tgt1_cstride;
+  const float gs = p.gscale ? p.gscale[g] : 0.f;
+  const float* __restrict__ y = p.y + (int64_t)g * p.y_gstride;
+  const int64_t MB = (int64_t)p.B * p.HW;
+  float sse = 0.f;
+  for (int i = pg; i < p.HW; i += 32) {
+    const int64_t pix = (int64_t)cube * p.HW + i;
+    const float4 v = vv_act4(*reinterpret_cast<const float4*>(y + pix * C + c), a4, b4);
+    float o[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      float d = v.x * wv[co].x;
+      d = fmaf(v.y, wv[co].y, d); d = fmaf(v.z, wv[co].z, d); d = fmaf(v.w, wv[co].w, d);
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      o[co] = d + bias[co];
+    }
+    if (sub == 0) {
+      float4 ov = make_float4(0, 0, 0, 0), dv = make_float4(0, 0, 0, 0);
+      float e[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        if (co < oc) {
+          e[co] = o[co] - tgt[pix * tcs + tco + co];
+          sse = fmaf(e[co], e[co], sse);
+        } else {
+          o[co] = 0.f;
+        }
+      ov = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(p.out4 + ((int64_t)g * MB + pix) * 4) = ov;
+      if (p.dout4) {
+        dv = make_float4(gs * e[0], gs * e[1], gs * e[2], gs * e[3]);
+        *reinterpret_cast<float4*>(p.dout4 + ((int64_t)g * MB + pix) * 4) = dv;
+      }
+    }
+  }
+  // block reduce sse (only sub==0 lanes hold data): wave reduce then 4 waves
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sse += __shfl_xor(sse, off);
+  if ((tid & 63) == 0) red[tid >> 6] = sse;
+  __syncthreads();
+  if (tid == 0) p.score[(int64_t)g * p.B + cube] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// backward: grid (B, G); partial [G][B][132]
+__global__ void __launch_bounds__(VV_WG)
+outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restrict__ dout4, const float* __restrict__ y,
+                   const int64_t y_gstride, const float* __restrict__ a, const float* __restrict__ b,
+                   const int64_t ab_gstride, const float* __restrict__ w, const int64_t param_gstride,
+                   float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial) {
+  __shared__ float sh[32][8 * 16 + 4];
+  const int g = blockIdx.y, cube = blockIdx.x;
+  const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
+  const int c = sub * 4;
+  const int64_t abo = (int64_t)g * ab_gstride + c;
+  const float4 a4 = *reinterpret_cast<const float4*>(a + abo), b4 = *reinterpret_cast<const float4*>(b + abo);
+  float4 wv[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) wv[co] = *reinterpret_cast<const float4*>(w + (int64_t)g * param_gstride + co * C + c);
+  // NOTE: rows co >= oc of `w` belong to the next parameter (bias) -- harmless because dout4 is 0 there.
+  const float* __restrict__ yg = y + (int64_t)g * y_gstride;
+  float* __restrict__ dAg = dA + (int64_t)g * dA_gstride;
+  const int64_t MB = (int64_t)B * HW;
+  float4 dw[4];
+  float db[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int co = 0; co < 4; ++co) dw[co] = make_float4(0, 0, 0, 0);
+  for (int i = pg; i < HW; i += 32) {
+    const int64_t pix = (int64_t)cube * HW + i;
+    const float4 d = *reinterpret_cast<const float4*>(dout4 + ((int64_t)g * MB + pix) * 4);
+    const float4 v = vv_act4(*reinterpret_cast<const float4*>(yg + pix * C + c), a4, b4);
+    const float dd[4] = {d.x, d.y, d.z, d.w};
+    float4 o = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      o.x = fmaf(dd[co], wv[co].x, o.x); o.y = fmaf(dd[co], wv[co].y, o.y);
+      o.z = fmaf(dd[co], wv[co].z, o.z); o.w = fmaf(dd[co], wv[co].w, o.w);
+      dw[co].x = fmaf(dd[co], v.x, dw[co].x); dw[co].y = fmaf(dd[co], v.y, dw[co].y);
+      dw[co].z = fmaf(dd[co], v.z, dw[co].z); dw[co].w = fmaf(dd[co], v.w, dw[co].w);
+      db[co] += dd[co];
+    }
+    *reinterpret_cast<float4*>(dAg + pix * C + c) = o;
+  }
+#pragma unroll
+  for (int co = 0; co < 4; ++co) *reinterpret_cast<float4*>(&sh[pg][sub * 16 + co * 4]) = dw[co];
+  if (sub == 0) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co) sh[pg][128 + co] = db[co];
+  }
+  __syncthreads();
+  float* out = partial + ((int64_t)g * B + cube) * 132;
+  if (tid < 128) {
+    const int co = tid >> 5, cc = tid & 31;
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += sh[k][(cc >> 2) * 16 + co * 4 + (cc & 3)];
+    out[co * 32 + cc] = s;
+  } else if (tid < 132) {
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += sh[k][128 + (tid - 128)];
+    out[tid] = s;
+  }
+}
+
+__global__ void __launch_bounds__(VV_WG)
+outconv_bwd_reduce_kernel(const int C, const int nblk, const float* __restrict__ partial, const int* __restrict__ oc,
+                          float* __restrict__ dW, float* __restrict__ db, const int64_t grad_gstride) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  if (tid >= 132) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[((int64_t)g * nblk + k) * 132 + tid];
+  const int n = oc[g];
+  if (tid < 128) {
+    const int co = tid >> 5, cc = tid & 31;
+    if (co < n) dW[(int64_t)g * grad_gstride + co * C + cc] = (float)s;
+  } else if (tid - 128 < n) {
+    db[(int64_t)g * grad_gstride + (tid - 128)] = (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bias grad
+__global__ void __launch_bounds__(VV_WG)
+bias_grad_stage1(const int64_t M, const int C, const float* __restrict__ dy, const int64_t dy_gstride, const int cstride,
+                 const int coff, float* __restrict__ scratch, const int nblk) {
+  __shared__ float sh[VV_WG];
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int c = threadIdx.x % C, pl = threadIdx.x / C, PL = VV_WG / C;
+  const float* src = dy + (int64_t)g * dy_gstride + coff + c;
+  float s = 0.f;
+  for (int i = pl; i < 1024; i += PL) {
+    const int64_t pix = (int64_t)blk * 1024 + i;
+    if (pix < M) s += src[pix * cstride];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int k = 0; k < PL; ++k) t += sh[k * C + threadIdx.x];
+    scratch[((int64_t)g * nblk + blk) * C + threadIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(VV_WG)
+bias_grad_stage2(const int C, const int nblk, const float* __restrict__ scratch, float* __restrict__ db,
+                 const int64_t grad_gstride) {
+  const int g = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += VV_WG) {
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += (double)scratch[((int64_t)g * nblk + k) * C + c];
+    db[(int64_t)g * grad_gstride + c] = (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void __launch_bounds__(VV_WG)
+adam_kernel(const int64_t n4, float4* __restrict__ p, const float4* __restrict__ gr, float4* __restrict__ m,
+            float4* __restrict__ v, const float step_size, const float beta1, const float beta2, const float eps,
+            const float bc2_sqrt, const float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * VV_WG + threadIdx.x; i < n4; i += (int64_t)gridDim.x * VV_WG) {
+    float4 pv = p[i], gv = gr[i], mv = m[i], vv = v[i];
+    float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gp[k] * gscale;
+      mp[k] = mp[k] + (gk - mp[k]) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1-beta1)
+      vp[k] = fmaf(1.f - beta2, gk * gk, vp[k] * beta2);            // exp_avg_sq.mul_(beta2).addcmul_(g,g,1-beta2)
+      const float denom = __fsqrt_rn(vp[k]) / bc2_sqrt + eps;
+      pp[k] = pp[k] - step_size * (mp[k] / denom);
+    }
+    p[i] = pv; m[i] = mv; v[i] = vv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ adapters
+__global__ void __launch_bounds__(VV_WG)
+cube_gather_kernel(const int B, const int T, const int Tf, const int HW, const int64_t* __restrict__ idx,
+                   const uint8_t* __restrict__ raw, const float* __restrict__ flow, float* __restrict__ x,
+                   float* __restrict__ xof) {
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= (int64_t)B * HW) return;
+  const int b = (int)(e / HW), pix = (int)(e % HW);
+  const int64_t n = idx ? idx[b] : b;
+  if (raw) {
+    const uint8_t* r = raw + (n * T * HW + pix) * 3;
+    float* o = x + e * (3 * T);
+    for (int t = 0; t < T; ++t) {
+      const uint8_t* q = r + (int64_t)t * HW * 3;
+      o[t * 3 + 0] = __fdiv_rn((float)q[0], 255.f);
+      o[t * 3 + 1] = __fdiv_rn((float)q[1], 255.f);
+      o[t * 3 + 2] = __fdiv_rn((float)q[2], 255.f);
+    }
+  }
+  if (flow) {
+    const float* f = flow + (n * Tf * HW + pix) * 2;
+    float* o = xof + e * (2 * Tf);
+    for (int t = 0; t < Tf; ++t) {
+      const float2 q = *reinterpret_cast<const float2*>(f + (int64_t)t * HW * 2);
+      o[t * 2 + 0] = q.x;
+      o[t * 2 + 1] = q.y;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(VV_WG)
+nchw_to_nhwc_kernel(const int B, const int C, const int HW, const float* __restrict__ src, float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= (int64_t)B * HW) return;
+  const int64_t b = e / HW, pix = e % HW;
+  for (int c = 0; c < C; ++c) dst[e * C + c] = src[(b * C + c) * HW + pix];
+}
+__global__ void __launch_bounds__(VV_WG)
+out4_to_nchw_kernel(const int B, const int HW, const int oc, const float* __restrict__ out4, float* __restrict__ dst,
+                    const int Ctot, const int choff) {
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= (int64_t)B * HW) return;
+  const int64_t b = e / HW, pix = e % HW;
+  const float4 v = *reinterpret_cast<const float4*>(out4 + e * 4);
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+  for (int c = 0; c < oc; ++c) dst[(b * Ctot + choff + c) * HW + pix] = vv[c];
+}
+__global__ void __launch_bounds__(VV_WG)
+nchw_to_out4_kernel(const int B, const int HW, const int oc, const float* __restrict__ src, const int Ctot,
+                    const int choff, float* __restrict__ out4) {
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= (int64_t)B * HW) return;
+  const int64_t b = e / HW, pix = e % HW;
+  float vv[4] = {0, 0, 0, 0};
+  for (int c = 0; c < oc; ++c) vv[c] = src[(b * Ctot + choff + c) * HW + pix];
+  *reinterpret_cast<float4*>(out4 + e * 4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
+
+inline int nblocks(int64_t n, int cap = 1 << 20) {
+  int64_t b = (n + VV_WG - 1) / VV_WG;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int vv_pack_weights(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params,
+                               int64_t params_gstride, float* packed, int64_t packed_gstride, int32_t max_elems,
+                               vv_stream stream) {
+  if (!table_dev || !params || !packed || nentries <= 0) return VV_ERR_BAD_ARG;
+  int bx = nblocks(max_elems, 64);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(bx, nentries, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, params,
+                     params_gstride, packed, packed_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t train, float momentum,
+                              float eps, const float* stats, int64_t stats_gstride, const float* gamma,
+                              const float* beta, int64_t param_gstride, float* running_mean, float* running_var,
+                              int64_t buf_gstride, float* a, float* b, float* mean, float* invstd,
+                              int64_t ab_gstride, vv_stream stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !a || !b || !mean || !invstd) return VV_ERR_BAD_ARG;
+  if (train && !stats) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, ntiles,
+                     (double)count, train, momentum, eps, stats, stats_gstride, gamma, beta, param_gstride,
+                     running_mean, running_var, buf_gstride, a, b, mean, invstd, ab_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C) {
+  (void)C;
+  const int64_t M = (int64_t)B * H * W;
+  return (int)((M + 255) / 256);
+}
+
+extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
+  if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial) return VV_ERR_BAD_ARG;
+  if (p->C % 4 || p->C > 256 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
+  const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  if (p->dpool)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_bn_bwd_apply(int32_t G, int64_t M, int32_t C, int32_t nblk, const float* partial, const float* y,
+                               int64_t y_gstride, const float* gamma, int64_t param_gstride, const float* mean,
+                               const float* invstd, int64_t ab_gstride, float* dgamma, float* dbeta,
+                               int64_t grad_gstride, float* dz, int64_t dz_gstride, float* scratch,
+                               vv_stream stream) {
+  if (!partial || !y || !gamma || !mean || !invstd || !dgamma || !dbeta || !dz || !scratch) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, (double)M,
+                     partial, dgamma, dbeta, grad_gstride, scratch);
+  VV_CHECK_LAUNCH();
+  const int64_t n4 = M * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(n4, 8192), G), dim3(VV_WG), 0, (hipStream_t)stream, n4, C, y,
+                     y_gstride, gamma, param_gstride, mean, invstd, ab_gstride, scratch, dz, dz_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream) {
+  if (!p || !p->y || !p->a || !p->b || !p->w || !p->bias || !p->oc || !p->tgt_src || !p->tgt_coff || !p->out4 ||
+      !p->score || !p->tgt0)
+    return VV_ERR_BAD_ARG;
+  if (p->C != 32) return VV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(outconv_fwd_kernel, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_outconv_bwd_nblk(int32_t B, int32_t HW) { (void)HW; return B; }
+
+extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
+                              int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
+                              int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial,
+                              vv_stream stream) {
+  if (!dout4 || !y || !a || !b || !w || !dA || !partial) return VV_ERR_BAD_ARG;
+  if (C != 32) return VV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(outconv_bwd_kernel, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
+                     a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
+                                     float* dW, float* db, int64_t grad_gstride, vv_stream stream) {
+  if (!partial || !oc || !dW || !db) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, partial, oc, dW,
+                     db, grad_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, int64_t dy_gstride, int32_t cstride,
+                            int32_t coff, float* scratch, float* db, int64_t grad_gstride, vv_stream stream) {
+  if (!dy || !scratch || !db) return VV_ERR_BAD_ARG;
+  if (C > VV_WG || VV_WG % C) return VV_ERR_UNSUPPORTED;
+  const int nblk = (int)((M + 1023) / 1024);
+  hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk, G), dim3(VV_WG), 0, (hipStream_t)stream, M, C, dy, dy_gstride, cstride,
+                     coff, scratch, nblk);
+  VV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bias_grad_stage2, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, scratch, db, grad_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_adam(int64_t n, float* param, const float* grad, float* m, float* v, float lr, float beta1,
+                       float beta2, float eps, float bias_corr1, float bias_corr2_sqrt, float grad_scale,
+                       vv_stream stream) {
+  if (!param || !grad || !m || !v || (n & 3)) return VV_ERR_BAD_ARG;
+  const int64_t n4 = n >> 2;
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4, 4096)), dim3(VV_WG), 0, (hipStream_t)stream, n4, (float4*)param,
+                     (const float4*)grad, (float4*)m, (float4*)v, lr / bias_corr1, beta1, beta2, eps, bias_corr2_sqrt,
+                     grad_scale);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_cube_gather(int32_t B, int32_t T, int32_t Tf, int32_t HW, const int64_t* idx, const uint8_t* raw,
+                              const float* flow, float* x, float* xof, vv_stream stream) {
+  if ((!raw && !flow) || (raw && !x) || (flow && !xof)) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cube_gather_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, T, Tf,
+                     HW, idx, raw, flow, x, xof);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_nchw_to_nhwc(int32_t B, int32_t C, int32_t HW, const float* src, float* dst, vv_stream stream) {
+  if (!src || !dst) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, C, HW,
+                     src, dst);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+extern "C" int vv_out4_to_nchw(int32_t B, int32_t HW, int32_t oc, const float* out4, float* dst, int32_t Ctot,
+                               int32_t choff, vv_stream stream) {
+  if (!out4 || !dst || oc > 4) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(out4_to_nchw_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
+                     out4, dst, Ctot, choff);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+extern "C" int vv_nchw_to_out4(int32_t B, int32_t HW, int32_t oc, const float* src, int32_t Ctot, int32_t choff,
+                               float* out4, vv_stream stream) {
+  if (!out4 || !src || oc > 4) return VV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(nchw_to_out4_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
+                     src, Ctot, choff, out4);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" const char* vv_version(void) { return "vecvad_hip 0.1 (gfx950)"; }
+
+extern "C" int vv_device_arch_ok(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  const char* a = prop.gcnArchName;
+  return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

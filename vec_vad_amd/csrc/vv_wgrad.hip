@@ -1,0 +1,199 @@
+// MFMA weight-gradient kernels (gfx950, v_mfma_f32_32x32x2_f32, exact fp32, deterministic split-K).
+//
+//   dW[tap][ci][co] = sum_pixels act[pixel (+tap)][ci] * dy[pixel (*2-1+tap)][co]
+// GEMM view per tap: M = ci (32 per workgroup), N = co (32 per workgroup), K = pixels.  One workgroup owns a
+// (ci-tile, co-tile, k-split) triple, walks its share of the pixel tiles, and each of its 4 waves keeps all 9 taps
+// of the 32x32 tile in accumulators (9 x 16 VGPRs) over a quarter of every pixel tile.  Both operands come from LDS
+// with ds_read_b32: lanes 0-31 read 32 consecutive channels of pixel k, lanes 32-63 of pixel k+1 (conflict-free).
+// The layer input is re-materialised on load from the producer's pre-BN tensor (BatchNorm+ReLU / max-pool / concat /
+// frame erasure), exactly as in the forward kernel, so no post-activation tensor is ever stored.
+// Every wave writes its own slab; vv_wgrad_reduce adds the slabs in a fixed order (bitwise reproducible) and
+// scatters into the PyTorch parameter layout.
+//
+// Replaces the autograd weight gradients of nn.Conv2d / nn.ConvTranspose2d (model/unet.py:10,13,54; cuDNN).
+#include "vv_common.h"
+
+namespace {
+
+template <int TH, int TW, int NI, int KIND>
+__global__ void __launch_bounds__(VV_WG, 2)
+wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+  constexpr bool CT = KIND != VV_CONV3;
+  constexpr int TP = TH * TW * NI;          // pixels (GEMM-K) per tile
+  constexpr int PPW = TP / 4;               // per wave
+  // act tile / dy tile geometry
+  constexpr int AHH = CT ? TH : TH + 2, AHW = CT ? TW : TW + 2;
+  constexpr int BHH = CT ? 2 * TH + 1 : TH, BHW = CT ? 2 * TW + 1 : TW;
+  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * BHH * BHW * 32;
+  __shared__ float lds[ASZ + BSZ];
+  float* lA = lds;
+  float* lB = lds + ASZ;
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int KS = p.ksplit;
+  const int ks = w % KS; w /= KS;
+  const int cot = w % NCO; w /= NCO;
+  const int cit = w % NCI;
+  const int g = w / NCI;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int H = p.H, W = p.W;
+  const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
+
+  const VVSrc sa = vv_make_src(p, g, H, W);
+  VVSrc sb;
+  sb.p0 = p.dy.ptr + (int64_t)g * p.dy.gstride; sb.cs0 = p.dy.cstride; sb.co0 = p.dy.coff;
+  sb.a = sb.b = nullptr; sb.p1 = nullptr; sb.cs1 = sb.co1 = 0; sb.chmap = nullptr; sb.csplit = 0;
+  sb.mode = VV_IN_PLAIN; sb.SH = CT ? 2 * H : H; sb.SW = CT ? 2 * W : W; sb.B = p.B;
+
+  v16f acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  bool first = true;
+  for (int pt = ks; pt < NT; pt += KS) {
+    const int img0 = (pt / tpi) * NI;
+    const int trem = pt % tpi;
+    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+    if (!first) __syncthreads();
+    first = false;
+    vv_stage_tile<NI, AHH, AHW, 32, 32>(lA, sa, img0, CT ? ty0 : ty0 - 1, CT ? tx0 : tx0 - 1, cit * 32, tid, p.CinP);
+    vv_stage_tile<NI, BHH, BHW, 32, 32>(lB, sb, img0, CT ? 2 * ty0 - 1 : ty0, CT ? 2 * tx0 - 1 : tx0, cot * 32, tid);
+    __syncthreads();
+
+#pragma unroll 2
+    for (int kk = 0; kk < PPW / 2; ++kk) {
+      const int pp = wave * PPW + 2 * kk + half;
+      const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+      const float* pa;
+      const float* pb;
+      if constexpr (CT) {
+        pa = lA + pp * 32 + l31;
+        pb = lB + ((im * BHH + 2 * r) * BHW + 2 * c) * 32 + l31;
+      } else {
+        pa = lA + ((im * AHH + r) * AHW + c) * 32 + l31;
+        pb = lB + pp * 32 + l31;
+      }
+      if constexpr (CT) {
+        const float a = pa[0];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[(ky * BHW + kx) * 32], acc[ky * 3 + kx], 0, 0, 0);
+      } else {
+        const float b = pb[0];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(ky * AHW + kx) * 32], b, acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+  }
+
+  // slab = ((cit*NCO + cot)*KS + ks)*4 + wave ; layout [tap][ci(32)][co(32)]
+  float* out = p.partial + (int64_t)g * p.partial_gstride +
+               ((int64_t)(((cit * NCO + cot) * KS + ks) * 4 + wave)) * (9 * 1024);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+      out[t * 1024 + row * 32 + l31] = acc[t][i];
+    }
+}
+
+__global__ void __launch_bounds__(VV_WG)
+wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO, const int nslab,
+                    const float* __restrict__ partial, const int64_t partial_gstride, float* __restrict__ grad,
+                    const int64_t grad_gstride) {
+  const int tap = blockIdx.x % 9;
+  const int tile = blockIdx.x / 9;
+  const int g = blockIdx.y;
+  const int cit = tile / NCO, cot = tile % NCO;
+  const float* src = partial + (int64_t)g * partial_gstride + (int64_t)tile * nslab * (9 * 1024) + tap * 1024;
+  float* dst = grad + (int64_t)g * grad_gstride;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = threadIdx.x + j * VV_WG;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += src[(int64_t)k * (9 * 1024) + e];
+    const int ci = cit * 32 + (e >> 5), co = cot * 32 + (e & 31);
+    if (ci < Cin && co < Cout) {
+      if (kind == VV_CONV3) dst[((int64_t)co * Cin + ci) * 9 + tap] = s;
+      else dst[((int64_t)ci * Cout + co) * 9 + tap] = s;
+    }
+  }
+}
+
+struct WGeo { int TH, TW, NI; };
+inline bool wgeo(int kind, int H, int W, WGeo* t) {
+  if (H != W) return false;
+  if (kind == VV_CONV3) {
+    if (H == 32) { *t = {8, 32, 1}; return true; }
+    if (H == 16) { *t = {16, 16, 1}; return true; }
+    if (H == 8) { *t = {8, 8, 2}; return true; }
+    if (H == 4) { *t = {4, 4, 8}; return true; }
+  } else {
+    if (H == 16) { *t = {8, 16, 1}; return true; }
+    if (H == 8) { *t = {8, 8, 2}; return true; }
+    if (H == 4) { *t = {4, 4, 8}; return true; }
+  }
+  return false;
+}
+
+template <int TH, int TW, int NI, int KIND>
+int launch_w(const vv_wgrad_params* p, hipStream_t st) {
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  const int total = p->G * NCI * NCO * p->ksplit;
+  const int nper = (total + 7) / 8;
+  hipLaunchKernelGGL((wgrad_mfma_kernel<TH, TW, NI, KIND>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total,
+                     nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+}  // namespace
+
+extern "C" int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W) {
+  WGeo t;
+  if (!wgeo(kind, H, W, &t)) return -1;
+  return ((B + t.NI - 1) / t.NI) * (H / t.TH) * (W / t.TW);
+}
+
+extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
+  if (!p || !p->src0.ptr || !p->dy.ptr || !p->partial) return VV_ERR_BAD_ARG;
+  if (p->Cout % 32 || p->ksplit < 1) return VV_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->kind == VV_CONV3) {
+    switch (p->H) {
+      case 32: return launch_w<8, 32, 1, VV_CONV3>(p, st);
+      case 16: return launch_w<16, 16, 1, VV_CONV3>(p, st);
+      case 8: return launch_w<8, 8, 2, VV_CONV3>(p, st);
+      case 4: return launch_w<4, 4, 8, VV_CONV3>(p, st);
+    }
+  } else {
+    switch (p->H) {
+      case 16: return launch_w<8, 16, 1, VV_CONVT_FWD>(p, st);
+      case 8: return launch_w<8, 8, 2, VV_CONVT_FWD>(p, st);
+      case 4: return launch_w<4, 4, 8, VV_CONVT_FWD>(p, st);
+    }
+  }
+  return VV_ERR_UNSUPPORTED;
+}
+
+extern "C" int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t CinP, int32_t Cout,
+                               int32_t nslab_per_tile, const float* partial, int64_t partial_gstride, float* grad,
+                               int64_t grad_gstride, vv_stream stream) {
+  if (!partial || !grad) return VV_ERR_BAD_ARG;
+  const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NCI * NCO * 9, G), dim3(VV_WG), 0, (hipStream_t)stream, kind, Cin, Cout,
+                     NCO, nslab_per_tile, partial, partial_gstride, grad, grad_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
