@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: spatio-temporal cubes/s of one TRAIN step (forward + backward + Adam [+ RCCL gradient
+all-reduce]) of SelfCompleteNet4 (5raw+1of, nf=32) on synthetic 32x32x5 RGB + flow cubes, batch 256 per GPU, fp32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: "UCSDped2 5raw+1of UNet train, batch 256, 1xMI355X, HIP conv kernels".
+Cubes live on the GPU as uint8 / fp32 (the reference's on-disk cube layout); every step gathers a fresh random batch
+(vv_cube_gather), runs the grouped HIP forward, backward and fused Adam.  Multi-GPU: one process per GPU, each rank
+trains on its own 256 cubes per step (weak scaling) and the flat gradient buffer is all-reduced over RCCL.
+
+Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (the MFMA 3x3 convolution used by forward and
+data-gradient), timed with HIP events on the launch stream inside the timed region; `cpu_baseline` times the
+reference's op sequence (oracle, stock PyTorch CPU ops) on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_FLOP_NET4 = 1855520768      # per cube, SURVEY.md section 8(d)
+TRAIN_FLOP_NET4 = 5524094976
+FP32_MFMA_PEAK = 157.3e12       # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
+
+
+def conv_flops(lay, B, G):
+    """algorithmic FLOPs (2/MAC, true Cin, no padding) of every MFMA-conv launch label."""
+    fl = {}
+    for l in lay.convs:
+        f = 2.0 * B * l.H * l.H * 9 * l.cin * l.cout * G
+        fl['conv%d' % l.idx] = f
+        if l.idx > 0:
+            fl['dgrad%d' % l.idx] = f
+    return fl
+
+
+def cpu_baseline(batch=32, steps=3, thread_choices=(8, 16, 32, 64)):
+    """Reference op sequence (torch CPU ops, NCHW fp32, per-op BN/ReLU/pool/cat, Adam eps=1e-7) on the host cores:
+    BASELINE.json configs[0] (Net4, B=32).  This is the oracle restatement ("port"); it is test/bench
+    infrastructure and never part of the product path.  The host of an MI355X box has 256 hardware threads and the
+    B=32 workload scales badly past ~16 of them (oneDNN/OpenMP oversubscription), so a few thread counts are tried
+    (bounded: one warm-up + `steps` timed steps each) and the best one is reported with its thread count."""
+    from oracle import unet_oracle as O
+    ncpu = os.cpu_count() or 1
+    spec = O.bank_spec('net4')
+    raw, flow = O.seeded_cubes(batch, 1, 3)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    best = None
+    tried = []
+    for nt in [t for t in thread_choices if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
+        opt = O.AdamState(O.param_names(sd))
+        O.train_step(sd, spec, x, x_of, opt)          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            O.train_step(sd, spec, x, x_of, opt)
+        dt = (time.perf_counter() - t0) / steps
+        tried.append('%d thr: %.0f cubes/s' % (nt, batch / dt))
+        if best is None or batch / dt > best[0]:
+            best = (batch / dt, nt)
+        if dt * steps > 20:
+            break
+    return {'value': best[0], 'unit': 'cubes/s', 'cores': best[1], 'kind': 'port',
+            'sample': 'SelfCompleteNet4 train step (fwd+bwd+Adam) on stock torch %s CPU ops, batch %d, %d timed steps per '
+                      'thread count; host has %d hardware threads; tried: %s'
+                      % (torch.__version__, batch, steps, ncpu, '; '.join(tried))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='cubes per GPU per step')
+    ap.add_argument('--pool', type=int, default=4096, help='device-resident synthetic cubes per GPU')
+    ap.add_argument('--model', default='net4', choices=['net4', 'full'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from model.unet import SelfCompleteNet4, SelfCompleteNetFull
+    from vec_vad_amd.trainer import FusedTrainer
+    torch.manual_seed(0)
+    tot_of = 1 if args.model == 'net4' else 5
+    cls = SelfCompleteNet4 if args.model == 'net4' else SelfCompleteNetFull
+    net = cls(features_root=32, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=None, useFlow=True,
+              padding=False).to(dev)
+    trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None)
+    bank = trainer.bank
+    B = args.batch
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    raw = torch.randint(0, 256, (args.pool, 5, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
+    flow = (torch.randn((args.pool, tot_of, 32, 32, 2), generator=g) * 2.0).to(dev)
+    perm = torch.stack([torch.randperm(args.pool, generator=g)[:B] for _ in range(args.steps + args.warmup)]).to(dev)
+
+    for it in range(args.warmup):
+        trainer.step_cubes(raw, flow, perm[it])
+    torch.cuda.synchronize()
+    ws = bank.workspace(B)
+    fl = conv_flops(bank.lay, B, bank.Ga)
+    # HIP events around every MFMA 3x3-conv launch (forward conv + data-gradient) of the timed region
+    ev = []
+    trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
+    trainer.event_labels = set(fl.keys()) if not args.breakdown else None
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        trainer.step_cubes(raw, flow, perm[args.warmup + it])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    trainer.event_hook = None
+    l_raw, l_of = bank.losses(ws)
+    loss_now = (float(l_raw), float(l_of) if l_of is not None else 0.0)
+
+    per = {}
+    for label, a, b in ev:
+        per.setdefault(label, []).append(a.elapsed_time(b) * 1e-3)
+    conv_t = sum(sum(v) for k, v in per.items() if k in fl)
+    conv_n = sum(len(v) for k, v in per.items() if k in fl)
+    conv_f = sum(fl[k] * len(v) for k, v in per.items() if k in fl)
+    if args.breakdown and rank == 0:
+        tot = sum(sum(v) for v in per.values())
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            extra = ''
+            if k in fl:
+                extra = '  %.1f TF/s' % (fl[k] / (sum(v) / len(v)) / 1e12)
+            sys.stderr.write('%-22s n=%3d avg %8.1f us  %5.1f%%%s\n' % (k, len(v), 1e6 * sum(v) / len(v), 100 * sum(v) / tot, extra))
+        sys.stderr.write('sum of launches %.3f ms / step ; wall %.3f ms / step\n' % (1e3 * tot / args.steps, 1e3 * dt / args.steps))
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    cubes = B * world * args.steps
+    value = cubes / dt
+    flop_per_cube = TRAIN_FLOP_NET4 if args.model == 'net4' else 9206169600
+    out = {
+        'metric': 'spatio-temporal cubes/sec (train step)', 'value': value, 'unit': 'cubes/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'UCSDped2-shaped 5raw+1of UNet bank (SelfCompleteNet4, nf=32, padding=False) train step: '
+                               'cube gather + forward + backward + Adam(eps=1e-7)' if args.model == 'net4' else
+                               '5raw+5of UNet bank (SelfCompleteNetFull) train step',
+                   'batch_per_gpu': B, 'global_batch': B * world, 'cube': '32x32x5 RGB uint8 + flow fp32',
+                   'parallelism': 'dp%d' % world, 'train_tflops_per_gpu': value / world * flop_per_cube / 1e12,
+                   'frac_of_fp32_mfma_peak_whole_step': value / world * flop_per_cube / FP32_MFMA_PEAK,
+                   'loss_raw': loss_now[0], 'loss_of': loss_now[1]},
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 implicit-GEMM, forward + data-gradient launches)',
+                     'achieved': (conv_f / conv_t / 1e12) if conv_t > 0 else None, 'peak': FP32_MFMA_PEAK / 1e12,
+                     'unit': 'TFLOP/s', 'frac': (conv_f / conv_t / FP32_MFMA_PEAK) if conv_t > 0 else None,
+                     'traffic': None, 'launches_timed': conv_n,
+                     'avg_launch_us': (1e6 * conv_t / conv_n) if conv_n else None,
+                     'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out['cpu_baseline'] = cpu_baseline()
+        except Exception as e:   # the oracle is optional infrastructure for the bench line
+            out['cpu_baseline'] = {'value': None, 'unit': 'cubes/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                   'sample': 'failed: %r' % (e,)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

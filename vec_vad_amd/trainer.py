@@ -1,0 +1,158 @@
+"""Fused training / scoring driver for the UNet bank (the loop bodies of train.py:379-402 and train.py:413-427).
+
+One process per GPU.  Data parallelism replaces the reference's single-process ``nn.DataParallel`` (train.py:375):
+every rank runs the grouped HIP forward/backward on its own shard of the global batch with per-rank BatchNorm
+statistics (what DataParallel does), gradients are summed over RCCL (``torch.distributed`` backend
+"nccl") in two buckets -- the decoder bucket is reduced on a side stream while the encoder half of the backward pass
+is still running -- and scaled by 1/world inside the fused Adam kernel.  No parameter broadcast per step (ranks start
+from identical weights and apply identical updates).
+"""
+import torch
+
+from . import _lib as L
+
+
+def shard_batch(indices, rank, world):
+    """Rank r takes a contiguous chunk of the global batch (DataParallel's scatter; train.py:375).
+    The global batch must split evenly so that the mean of per-rank mean losses equals the global mean."""
+    n = indices.shape[0]
+    if n % world:
+        raise ValueError('global batch %d does not split evenly over %d ranks' % (n, world))
+    per = n // world
+    return indices[rank * per:(rank + 1) * per]
+
+
+class GradBuckets:
+    """Sum-all-reduce of a [G][U] gradient buffer in column buckets.
+
+    Bucket k covers columns [bounds[k], bounds[k+1]) of every row.  ``launch(k)`` stages the strided slab into a
+    contiguous buffer and starts the collective on ``comm_stream`` (after everything already queued on the current
+    stream); ``finish()`` makes the current stream wait and scatters the sums back.  Works with any backend
+    (RCCL on the GPU, gloo on CPU tensors for the tests)."""
+
+    def __init__(self, grads, bounds, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.grads, self.bounds, self.group = grads, list(bounds), group
+        self.cuda = grads.is_cuda
+        self.stage = [torch.empty(grads.shape[0], b - a, device=grads.device, dtype=grads.dtype)
+                      for a, b in zip(self.bounds[:-1], self.bounds[1:])]
+        self.comm_stream = torch.cuda.Stream(device=grads.device) if self.cuda else None
+        self.pending = []
+
+    def launch(self, k):
+        a, b = self.bounds[k], self.bounds[k + 1]
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                self.stage[k].copy_(self.grads[:, a:b])
+                work = self.dist.all_reduce(self.stage[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.stage[k].copy_(self.grads[:, a:b])
+            work = self.dist.all_reduce(self.stage[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((k, work))
+
+    def finish(self):
+        for k, work in self.pending:
+            a, b = self.bounds[k], self.bounds[k + 1]
+            if self.cuda:
+                with torch.cuda.stream(self.comm_stream):
+                    work.wait()
+                    self.grads[:, a:b].copy_(self.stage[k])
+            else:
+                work.wait()
+                self.grads[:, a:b].copy_(self.stage[k])
+        if self.cuda and self.pending:
+            torch.cuda.current_stream(self.grads.device).wait_stream(self.comm_stream)
+        self.pending = []
+
+
+class FusedTrainer:
+    """forward(train) -> backward -> [bucketed RCCL all-reduce] -> Adam, all asynchronous on the current stream."""
+
+    def __init__(self, net, lr=1e-3, eps=1e-7, betas=(0.9, 0.999), lambda_raw=1.0, lambda_of=1.0, process_group=None):
+        net.set_loss_weights(lambda_raw, lambda_of)
+        self.net = net
+        self.bank = net.bank()
+        self.lr, self.eps, self.betas = lr, eps, betas
+        self.group = process_group
+        self.world = 1
+        self.buckets = None
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        if self.world > 1:
+            lay = self.bank.lay
+            split = lay.p['c8.w'][0]          # [0, split): encoder convs, [split, U): decoder convs, convT, 1x1 out
+            self.buckets = GradBuckets(self.bank.grads, [0, split, lay.U], process_group)
+            self.split_label = 'dgradT0'      # last launch of the decoder half of the backward plan
+        self.event_hook = None
+        self.event_labels = None
+
+    # ---- plan execution with optional per-launch HIP events and a mid-plan callback
+    def _run(self, plan, stream, after=None):
+        hook, labels = self.event_hook, self.event_labels
+        for fn, args, label in plan.calls:
+            timed = hook is not None and (labels is None or label in labels)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = fn(*args, stream)
+            if rc:
+                L.check(rc, label)
+            if timed:
+                e1.record()
+                hook(label, e0, e1)
+            if after is not None and label == after[0]:
+                after[1]()
+
+    def _step(self, ws):
+        bank = self.bank
+        stream = bank._stream()
+        self._run(ws.fwd[True], stream)
+        bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+        if ws.bwd is None:
+            ws.bwd = bank._plan_backward(ws, ws.B)
+        if self.buckets is None:
+            self._run(ws.bwd, stream)
+        else:
+            self._run(ws.bwd, stream, after=(self.split_label, lambda: self.buckets.launch(1)))
+            self.buckets.launch(0)
+            self.buckets.finish()
+        if self.event_hook is not None and (self.event_labels is None or 'adam' in self.event_labels):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+            e1.record()
+            self.event_hook('adam', e0, e1)
+        else:
+            bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+        return ws
+
+    def step_cubes(self, raw_u8, flow, idx):
+        """One optimisation step on cubes ``idx`` of a device-resident cube store (uint8 [N,5,32,32,3], fp32 [N,Tf,32,32,2])."""
+        return self._step(self.bank.set_input_cubes(raw_u8, flow, idx))
+
+    def step_nchw(self, x, x_of):
+        """One optimisation step on the reference's DataLoader tensors (train.py:380-383)."""
+        return self._step(self.bank.set_input_nchw(x, x_of))
+
+    def losses(self, ws):
+        return self.bank.losses(ws)
+
+    # ---- eval-mode scoring (train.py:413-427, test.py:319-335)
+    @torch.no_grad()
+    def score_cubes(self, raw_u8, flow, idx=None, batch=None):
+        bank = self.bank
+        ws = bank.set_input_cubes(raw_u8, flow, idx, batch)
+        bank.forward(ws, False)
+        return bank.cube_scores(ws)
+
+    @torch.no_grad()
+    def score_nchw(self, x, x_of):
+        bank = self.bank
+        ws = bank.set_input_nchw(x, x_of)
+        bank.forward(ws, False)
+        return bank.cube_scores(ws)
