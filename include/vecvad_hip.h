@@ -108,7 +108,7 @@ typedef struct vv_wgrad_params {
 
 int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream);
 int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W);
-/* slabs written per (ci-tile, co-tile): ksplit * 4 (one per wave) */
+/* slabs written per (ci-tile, co-tile): ksplit (the 4 waves of a workgroup are summed in LDS first) */
 
 /* Sum the slabs and scatter into PyTorch parameter layout:
  * CONV3 : grad[co][ci][ky][kx]   (nn.Conv2d.weight  [Cout,Cin,3,3])

@@ -355,15 +355,15 @@ class UNetBank:
         for l in lay.convs:
             nci, nco = (l.cinp + 31) // 32, l.cout // 32
             nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
-            ks = max(1, min(nt, 1024 // max(1, Ga * nci * nco)))
-            wplan['c%d' % l.idx] = (ks, nci * nco * ks * 4)
-            wmax = max(wmax, nci * nco * ks * 4)
+            ks = max(1, min(nt, 512 // max(1, Ga * nci * nco)))
+            wplan['c%d' % l.idx] = (ks, nci * nco * ks)
+            wmax = max(wmax, nci * nco * ks)
         for u, (_, H, ci, co) in enumerate(lay.convT):
             nci, nco = ci // 32, co // 32
             nt = lib.vv_wgrad_ntiles(L.CONVT_FWD, B, H, H)
-            ks = max(1, min(nt, 1024 // max(1, Ga * nci * nco)))
-            wplan['t%d' % u] = (ks, nci * nco * ks * 4)
-            wmax = max(wmax, nci * nco * ks * 4)
+            ks = max(1, min(nt, 512 // max(1, Ga * nci * nco)))
+            wplan['t%d' % u] = (ks, nci * nco * ks)
+            wmax = max(wmax, nci * nco * ks)
         ws.wpart = f(Ga, wmax * 9 * 1024)
         wpg = ws.wpart.stride(0)
 
@@ -419,7 +419,7 @@ class UNetBank:
                                L.View(ws.dz.data_ptr(), ws.dz.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i)
-            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * 4, ws.wpart.data_ptr(), wpg,
+            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks, ws.wpart.data_ptr(), wpg,
                                         gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i)
             # data gradient
             if i > 0:
@@ -445,7 +445,7 @@ class UNetBank:
                                ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u)
-            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * 4, ws.wpart.data_ptr(), wpg,
+            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks, ws.wpart.data_ptr(), wpg,
                                         gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u)
             DT = ws.DT[u]
             cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, 0, None,

@@ -112,18 +112,29 @@ __device__ __forceinline__ void vv_stage_tile(float* lds, const VVSrc& s, int im
                                               int cmax = 1 << 30) {
   constexpr int Q = NCH / 4;
   constexpr int NITEMS = NI * HH * HW * Q;
-#pragma unroll 2
-  for (int it = tid; it < NITEMS; it += VV_WG) {
-    const int q = it % Q;
-    const int hp = it / Q;
-    const int hx = hp % HW;
-    const int t = hp / HW;
-    const int hy = t % HH;
-    const int im = t / HH;
-    const int img = img0 + im, y = y0 + hy, x = x0 + hx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (img < s.B && (unsigned)y < (unsigned)s.SH && (unsigned)x < (unsigned)s.SW && c0 + q * 4 < cmax)
-      v = vv_fetch4(s, img, y, x, c0 + q * 4);
-    *reinterpret_cast<float4*>(lds + hp * S + q * 4) = v;
+  constexpr int BATCH = 6;                       // loads in flight per thread before the first LDS write
+  constexpr int NIT = (NITEMS + VV_WG - 1) / VV_WG;
+#pragma unroll 1
+  for (int k0 = 0; k0 < NIT; k0 += BATCH) {
+    float4 v[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int it = tid + (k0 + k) * VV_WG;
+      const int q = it % Q;
+      const int hp = it / Q;
+      const int hx = hp % HW;
+      const int t = hp / HW;
+      const int hy = t % HH;
+      const int im = t / HH;
+      const int img = img0 + im, y = y0 + hy, x = x0 + hx;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < NITEMS && img < s.B && (unsigned)y < (unsigned)s.SH && (unsigned)x < (unsigned)s.SW && c0 + q * 4 < cmax)
+        v[k] = vv_fetch4(s, img, y, x, c0 + q * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int it = tid + (k0 + k) * VV_WG;
+      if (it < NITEMS) *reinterpret_cast<float4*>(lds + (it / Q) * S + (it % Q) * 4) = v[k];
+    }
   }
 }

@@ -386,16 +386,21 @@ outconv_bwd_reduce_kernel(const int C, const int nblk, const float* __restrict__
 __global__ void __launch_bounds__(VV_WG)
 bias_grad_stage1(const int64_t M, const int C, const float* __restrict__ dy, const int64_t dy_gstride, const int cstride,
                  const int coff, float* __restrict__ scratch, const int nblk) {
-  __shared__ float sh[VV_WG];
+  __shared__ float sh[VV_WG * 4];
   const int g = blockIdx.y, blk = blockIdx.x;
-  const int c = threadIdx.x % C, pl = threadIdx.x / C, PL = VV_WG / C;
-  const float* src = dy + (int64_t)g * dy_gstride + coff + c;
-  float s = 0.f;
+  const int Q4 = C >> 2, PL = VV_WG / Q4;
+  const int q = threadIdx.x % Q4, pl = threadIdx.x / Q4;
+  const float* src = dy + (int64_t)g * dy_gstride + coff + q * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
   for (int i = pl; i < 1024; i += PL) {
     const int64_t pix = (int64_t)blk * 1024 + i;
-    if (pix < M) s += src[pix * cstride];
+    if (pix < M) {
+      const float4 v = *reinterpret_cast<const float4*>(src + pix * cstride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  sh[threadIdx.x] = s;
+  *reinterpret_cast<float4*>(sh + (pl * Q4 + q) * 4) = s;
   __syncthreads();
   if (threadIdx.x < C) {
     float t = 0.f;
@@ -594,7 +599,7 @@ extern "C" int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const f
 extern "C" int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, int64_t dy_gstride, int32_t cstride,
                             int32_t coff, float* scratch, float* db, int64_t grad_gstride, vv_stream stream) {
   if (!dy || !scratch || !db) return VV_ERR_BAD_ARG;
-  if (C > VV_WG || VV_WG % C) return VV_ERR_UNSUPPORTED;
+  if (C > VV_WG || C % 4 || VV_WG % (C / 4) || cstride % 4 || coff % 4) return VV_ERR_UNSUPPORTED;
   const int nblk = (int)((M + 1023) / 1024);
   hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk, G), dim3(VV_WG), 0, (hipStream_t)stream, M, C, dy, dy_gstride, cstride,
                      coff, scratch, nblk);

@@ -95,38 +95,56 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     }
   }
 
-  // slab = ((cit*NCO + cot)*KS + ks)*4 + wave ; layout [tap][ci(32)][co(32)]
-  float* out = p.partial + (int64_t)g * p.partial_gstride +
-               ((int64_t)(((cit * NCO + cot) * KS + ks) * 4 + wave)) * (9 * 1024);
+  // cross-wave (K-split) reduction through LDS in fixed wave order, then one slab per workgroup:
+  // slab = (cit*NCO + cot)*KS + ks ; layout [tap][ci(32)][co(32)]
+  static_assert(ASZ + BSZ >= 9 * 1024, "LDS too small for the slab");
+  __syncthreads();
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-      out[t * 1024 + row * 32 + l31] = acc[t][i];
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+          float* q = lds + t * 1024 + row * 32 + l31;
+          *q = wv ? *q + acc[t][i] : acc[t][i];
+        }
     }
+    __syncthreads();
+  }
+  float4* out = reinterpret_cast<float4*>(p.partial + (int64_t)g * p.partial_gstride +
+                                          ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024));
+  const float4* l4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) out[tid + j * VV_WG] = l4[tid + j * VV_WG];
 }
 
 __global__ void __launch_bounds__(VV_WG)
 wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO, const int nslab,
                     const float* __restrict__ partial, const int64_t partial_gstride, float* __restrict__ grad,
                     const int64_t grad_gstride) {
-  const int tap = blockIdx.x % 9;
-  const int tile = blockIdx.x / 9;
+  const int quarter = blockIdx.x & 3;
+  const int tap = (blockIdx.x >> 2) % 9;
+  const int tile = (blockIdx.x >> 2) / 9;
   const int g = blockIdx.y;
   const int cit = tile / NCO, cot = tile % NCO;
-  const float* src = partial + (int64_t)g * partial_gstride + (int64_t)tile * nslab * (9 * 1024) + tap * 1024;
+  const int e = quarter * VV_WG + threadIdx.x;
+  const float* src = partial + (int64_t)g * partial_gstride + (int64_t)tile * nslab * (9 * 1024) + tap * 1024 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= nslab; k += 4) {
+    s0 += src[(int64_t)(k + 0) * (9 * 1024)];
+    s1 += src[(int64_t)(k + 1) * (9 * 1024)];
+    s2 += src[(int64_t)(k + 2) * (9 * 1024)];
+    s3 += src[(int64_t)(k + 3) * (9 * 1024)];
+  }
+  for (; k < nslab; ++k) s0 += src[(int64_t)k * (9 * 1024)];
+  const float s = (s0 + s1) + (s2 + s3);
   float* dst = grad + (int64_t)g * grad_gstride;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = threadIdx.x + j * VV_WG;
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += src[(int64_t)k * (9 * 1024) + e];
-    const int ci = cit * 32 + (e >> 5), co = cot * 32 + (e & 31);
-    if (ci < Cin && co < Cout) {
-      if (kind == VV_CONV3) dst[((int64_t)co * Cin + ci) * 9 + tap] = s;
-      else dst[((int64_t)ci * Cout + co) * 9 + tap] = s;
-    }
+  const int ci = cit * 32 + (e >> 5), co = cot * 32 + (e & 31);
+  if (ci < Cin && co < Cout) {
+    if (kind == VV_CONV3) dst[((int64_t)co * Cin + ci) * 9 + tap] = s;
+    else dst[((int64_t)ci * Cout + co) * 9 + tap] = s;
   }
 }
 
@@ -192,7 +210,7 @@ extern "C" int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t Cin
                                int64_t grad_gstride, vv_stream stream) {
   if (!partial || !grad) return VV_ERR_BAD_ARG;
   const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NCI * NCO * 9, G), dim3(VV_WG), 0, (hipStream_t)stream, kind, Cin, Cout,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NCI * NCO * 9 * 4, G), dim3(VV_WG), 0, (hipStream_t)stream, kind, Cin, Cout,
                      NCO, nslab_per_tile, partial, partial_gstride, grad, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
