@@ -5,6 +5,7 @@
 #include "../../include/vecvad_hip.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define VV_WG 256
 

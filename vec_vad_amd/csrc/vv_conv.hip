@@ -29,9 +29,11 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
   constexpr int S = CK + 4;             // LDS pixel stride (floats): S/4 odd -> conflict-free ds_read_b128
+  constexpr int S4 = S / 4;
   constexpr int MR = 2;                 // 2 x 32 pixels per wave
   constexpr int TN = NR * 32;
-  __shared__ float lds[NI * HH * HW * S];
+  __shared__ float4 lds4[NI * HH * HW * S4];   // float4-typed so that the A reads are ds_read_b128
+  float* lds = reinterpret_cast<float*>(lds4);
 
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
@@ -65,7 +67,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   for (int m = 0; m < MR; ++m) {
     const int pp = wave * 64 + m * 32 + l31;
     const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
-    abase[m] = ((im * HH + r * SP) * HW + c * SP) * S + half * 4;
+    abase[m] = ((im * HH + r * SP) * HW + c * SP) * S4 + half;
   }
 
   v16f acc[MR][NR];
@@ -88,9 +90,13 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     auto mma_tap = [&](const int aoff, const int wt) {
 #pragma unroll
       for (int kg = 0; kg < CK / 8; ++kg) {
-        float4 a[MR], b[NR];
+        v4f a[MR];
+        float4 b[NR];
 #pragma unroll
-        for (int m = 0; m < MR; ++m) a[m] = *reinterpret_cast<const float4*>(lds + abase[m] + aoff + kg * 8);
+        for (int m = 0; m < MR; ++m) {
+          a[m] = reinterpret_cast<const v4f*>(lds4)[abase[m] + aoff + kg * 2];
+          asm volatile("" : "+v"(a[m]));      // keep the 16-byte LDS read whole (ds_read_b128, conflict-free layout)
+        }
         const float* wp = wg + ((int64_t)((wt * KQ + (c0 >> 3) + kg) * 2 + half) * Cout + co0 + l31) * 4;
 #pragma unroll
         for (int n = 0; n < NR; ++n) b[n] = *reinterpret_cast<const float4*>(wp + n * 128);
@@ -111,13 +117,13 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       for (int ty = 0; ty < nty; ++ty)
         for (int tx = 0; tx < ntx; ++tx) {
           const int ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1;
-          mma_tap((ty * HW + tx) * S, ky * 3 + kx);
+          mma_tap((ty * HW + tx) * S4, ky * 3 + kx);
         }
     } else {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) mma_tap((ky * HW + kx) * S, ky * 3 + kx);
+        for (int kx = 0; kx < 3; ++kx) mma_tap((ky * HW + kx) * S4, ky * 3 + kx);
     }
   }
 
