@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""``python test.py`` -- abnormal-event detection stage of VEC_VAD on the MI355X UNet-bank engine.
+
+Drop-in for the reference's test.py:193-399: loads ``<ds>_model_<mode>_SelfComplete.npy`` and the training-score files
+written by train.py (or by the reference: same torch-pickle layout and ``module.``-prefixed keys), scores every test
+cube in eval mode, z-normalises with the training-score mean / population std (test.py:260-266,338-345), paints the
+scores into the bbox rectangles and max-combines them into the per-frame map ``results/<ds>/score_mask/<frame>``
+(test.py:350-358), then evaluates frame-level ROC-AUC (test.py:362-399, utils.py:29-65).
+
+Differences on purpose: the reference runs one tiny batch per frame (1-30 cubes); eval-mode BatchNorm makes scores
+batch independent, so many frames are scored per launch (``[mi355x] score_batch``).  Ground-truth frame labels come from
+``<data_root>/<modality>/<ds>_frame_labels_test.npy`` (bool per frame) because reading the datasets' GT masks needs the
+out-of-scope cv2 frame indexers; without that file the evaluation step is skipped.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from train import read_config, build_network  # noqa: E402
+from utils import save_roc_pr_curve_data  # noqa: E402
+from vad_datasets import frame_size  # noqa: E402
+from vec_vad_amd.trainer import FusedTrainer  # noqa: E402
+
+BIG = 100000
+
+
+def load_model(net, state_dict, device):
+    """test.py:255-257: the saved keys carry DataParallel's 'module.' prefix."""
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+    net.load_state_dict(sd)
+    net.to(device)
+    net.eval()
+    return net
+
+
+def score_cubes_batched(trainer, cube_list, flow_list, score_batch):
+    """cube_list / flow_list: per-frame arrays [n_i,5,32,32,3] uint8 / [n_i,(Tf,)32,32,2] fp32 (n_i may be 0).
+    Returns per-frame (raw_scores [n_i], of_scores [n_i]) with as many frames per launch as fit in score_batch."""
+    dev = trainer.bank.device
+    out = [None] * len(cube_list)
+    i = 0
+    while i < len(cube_list):
+        j, tot = i, 0
+        while j < len(cube_list) and (tot == 0 or tot + len(cube_list[j]) <= score_batch):
+            tot += len(cube_list[j])
+            j += 1
+        if tot == 0:
+            for k in range(i, j):
+                out[k] = (np.zeros(0, np.float32), np.zeros(0, np.float32))
+            i = j
+            continue
+        raw = np.concatenate([np.asarray(cube_list[k]) for k in range(i, j) if len(cube_list[k])])
+        flow = np.concatenate([np.asarray(flow_list[k], dtype=np.float32) for k in range(i, j) if len(cube_list[k])])
+        if raw.ndim == 4:
+            raw = raw[:, None]
+        if flow.ndim == 4:
+            flow = flow[:, None]
+        r, o = trainer.score_cubes(torch.from_numpy(np.ascontiguousarray(raw)).to(dev),
+                                   torch.from_numpy(np.ascontiguousarray(flow)).to(dev), None, raw.shape[0])
+        r = r.cpu().numpy()
+        o = o.cpu().numpy() if o is not None else None
+        p = 0
+        for k in range(i, j):
+            n = len(cube_list[k])
+            out[k] = (r[p:p + n], o[p:p + n] if o is not None else None)
+            p += n
+        i = j
+    return out
+
+
+def paint_frame(scores, bboxes, h, w):
+    """test.py:350-357: each cube's score fills its (ceil'ed) bbox; maps are max-combined; untouched pixels = -1e5."""
+    res = -1.0 * np.ones((h, w)) * BIG
+    for m in range(len(scores)):
+        bb = bboxes[m]
+        x_min, x_max = int(np.ceil(bb[0])), int(np.ceil(bb[2]))
+        y_min, y_max = int(np.ceil(bb[1])), int(np.ceil(bb[3]))
+        region = res[y_min:y_max, x_min:x_max]
+        np.maximum(region, scores[m], out=region)
+    return res
+
+
+def score_frames(net_set, stats_raw, stats_of, foreground_set, foreground_set2, bbox_set, h, w, w_raw, w_of, useFlow,
+                 device, score_batch=512, scene_idx=None, result_dir=None, log=print):
+    """Per-frame anomaly maps / scores.  ``net_set[(s,)hh][ww]`` is a list with 0 or 1 eval-mode networks;
+    ``stats_*[(s,)hh][ww]`` = (mean, std) of the training scores.  Returns the list of frame scores (map maxima)."""
+    n_frames = len(foreground_set)
+    frame_maps = [(-1.0 * np.ones((h, w)) * BIG) for _ in range(n_frames)] if result_dir else None
+    frame_scores = np.full(n_frames, -float(BIG))
+    hb, wb = len(foreground_set[0]), len(foreground_set[0][0])
+    trainers = {}
+    for hh in range(hb):
+        for ww in range(wb):
+            # group frames by the model that scores them (one per scene for ShanghaiTech)
+            keys = sorted(set(scene_idx[f] - 1 for f in range(n_frames))) if scene_idx is not None else [None]
+            for key in keys:
+                frames = [f for f in range(n_frames) if scene_idx is None or scene_idx[f] - 1 == key]
+                models = net_set[key][hh][ww] if key is not None else net_set[hh][ww]
+                cubes = [foreground_set[f][hh][ww] for f in frames]
+                flows = [foreground_set2[f][hh][ww] for f in frames]
+                if len(models) > 0:
+                    net = models[0]
+                    if id(net) not in trainers:
+                        trainers[id(net)] = FusedTrainer(net)
+                    st_r = stats_raw[key][hh][ww] if key is not None else stats_raw[hh][ww]
+                    st_o = (stats_of[key][hh][ww] if key is not None else stats_of[hh][ww]) if useFlow else None
+                    per = score_cubes_batched(trainers[id(net)], cubes, flows, score_batch)
+                for fi, f in enumerate(frames):
+                    n = len(cubes[fi])
+                    if n == 0:
+                        continue
+                    if len(models) > 0:
+                        r, o = per[fi]
+                        r = (r - st_r[0]) / st_r[1]
+                        sc = w_raw * r
+                        if useFlow:
+                            sc = sc + w_of * ((o - st_o[0]) / st_o[1])
+                    else:
+                        sc = np.ones(n) * BIG        # anomaly: no object in the training set in this block (test.py:346-348)
+                    m = paint_frame(sc, bbox_set[f][hh][ww], h, w)
+                    if frame_maps is not None:
+                        np.maximum(frame_maps[f], m, out=frame_maps[f])
+                    frame_scores[f] = max(frame_scores[f], m.max())
+    if result_dir:
+        os.makedirs(result_dir, exist_ok=True)
+        for f in range(n_frames):
+            torch.save(frame_maps[f], os.path.join(result_dir, '{}'.format(f)))
+    return frame_scores
+
+
+def main(config_path='config.cfg'):
+    c = read_config(config_path)
+    cp, ds, fg, root, mod, method = c['cp'], c['dataset_name'], c['mode_fg'], c['data_root_dir'], c['modality'], c['method']
+    if not cp.getboolean(ds, 'test_foreground_saved'):
+        raise NotImplementedError('test_foreground_saved = False needs the cv2 / mmdet extraction stages of the reference '
+                                  '(test.py:44-180), outside the hot path built here; extract once with the reference.')
+    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(device)
+    base = os.path.join(root, mod, ds + '_')
+    h, w, _, _ = frame_size[ds]
+    results_dir = 'results'
+    shanghai = ds == 'ShanghaiTech'
+    frame_scores_path = os.path.join(results_dir, ds, 'frame_scores_{}_{}.npy'.format(fg, method))
+    if not cp.getboolean(ds, 'scores_saved'):
+        fset = np.load(base + 'foreground_test_{}-raw.npy'.format(fg), allow_pickle=True)
+        fset2 = np.load(base + 'foreground_test_{}-flow.npy'.format(fg), allow_pickle=True)
+        bset = np.load(base + 'foreground_bbox_test_{}.npy'.format(fg), allow_pickle=True)
+        scene_idx = np.load(base + 'scene_idx.npy') if shanghai else None
+        weights = torch.load(base + 'model_{}_{}.npy'.format(fg, method), map_location='cpu', weights_only=False)
+        raw_tr = torch.load(base + 'raw_training_scores_{}_{}.npy'.format(fg, method), weights_only=False)
+        of_tr = torch.load(base + 'of_training_scores_{}_{}.npy'.format(fg, method), weights_only=False)
+
+        def build(wl):
+            return [load_model(build_network(c), wl[0], device)] if len(wl) > 0 else []
+
+        def stat(a):
+            a = np.asarray(a)
+            return (np.mean(a), np.std(a)) if a.size else (0.0, 1.0)      # population std, test.py:264-266
+
+        if shanghai:
+            net_set = [[[build(weights[s][hh][ww]) for ww in range(len(weights[s][hh]))] for hh in range(len(weights[s]))]
+                       for s in range(len(weights))]
+            st_r = [[[stat(raw_tr[s][hh][ww]) for ww in range(c['w_block'])] for hh in range(c['h_block'])] for s in range(len(weights))]
+            st_o = [[[stat(of_tr[s][hh][ww]) for ww in range(c['w_block'])] for hh in range(c['h_block'])] for s in range(len(weights))]
+        else:
+            net_set = [[build(weights[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+            st_r = [[stat(raw_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+            st_o = [[stat(of_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+        mask_dir = os.path.join(results_dir, ds, 'score_mask') if c['save_score_masks'] else None
+        fs = score_frames(net_set, st_r, st_o, fset, fset2, bset, h, w, c['w_raw'], c['w_of'], c['useFlow'], device,
+                          c['score_batch'], scene_idx, mask_dir)
+        os.makedirs(os.path.join(results_dir, ds), exist_ok=True)
+        np.save(frame_scores_path, fs)
+    else:
+        fs = np.load(frame_scores_path)
+
+    # ---- evaluation (test.py:362-399), criterion = 'frame'
+    lab_path = base + 'frame_labels_test.npy'
+    if not os.path.exists(lab_path):
+        print('no {} -> frame-level evaluation skipped (ground-truth masks need the dataset frame indexers)'.format(lab_path))
+        return None
+    labels = np.load(lab_path).astype(bool)
+    print('Evaluating {} by frame-criterion:'.format(ds))
+    if shanghai:
+        scene_idx = np.load(base + 'scene_idx.npy')
+        aucs = []
+        for si in sorted(set(scene_idx)):
+            sel = scene_idx == si
+            aucs.append(save_roc_pr_curve_data(fs[sel], labels[sel], os.path.join(
+                results_dir, ds, '{}_{}_{}_frame_results_scene_{}.npz'.format(mod, fg, method, si))))
+        auc = float(np.mean(aucs))
+        print('Average frame-level AUC is {}'.format(auc))
+    else:
+        path = os.path.join(results_dir, ds, '{}_{}_{}_frame_results.npz'.format(mod, fg, method))
+        print('Results written to {}:'.format(path))
+        auc = save_roc_pr_curve_data(fs, labels, path)
+    return auc
+
+
+if __name__ == '__main__':
+    main()

@@ -72,10 +72,14 @@ class GradBuckets:
 class FusedTrainer:
     """forward(train) -> backward -> [bucketed RCCL all-reduce] -> Adam, all asynchronous on the current stream."""
 
-    def __init__(self, net, lr=1e-3, eps=1e-7, betas=(0.9, 0.999), lambda_raw=1.0, lambda_of=1.0, process_group=None):
+    def __init__(self, net, lr=1e-3, eps=1e-7, betas=(0.9, 0.999), lambda_raw=1.0, lambda_of=1.0, process_group=None,
+                 reset_optimizer=True):
         net.set_loss_weights(lambda_raw, lambda_of)
         self.net = net
         self.bank = net.bank()
+        if reset_optimizer:      # the reference builds a fresh Adam for every block (train.py:376)
+            self.bank.adam_m = self.bank.adam_v = None
+            self.bank.adam_t = 0
         self.lr, self.eps, self.betas = lr, eps, betas
         self.group = process_group
         self.world = 1
