@@ -231,6 +231,9 @@ int vv_channelnorm_fwd(const float* in, float* out, int32_t B, int32_t C, int32_
 
 /* library self-description */
 const char* vv_version(void);
+/* text of the HIP error behind the last VV_ERR_LAUNCH returned on this thread ("" if none); never printed by the library */
+const char* vv_last_hip_error(void);
+void vv_set_last_hip_error(int code);
 int vv_device_arch_ok(void); /* 1 when the current device is gfx950 */
 
 #ifdef __cplusplus

@@ -7,6 +7,9 @@ raises.  The reference's equivalent seam is the cffi glue of the FlowNet2 ops
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST be imported before the .so: both link libamdhip64; loading PyTorch's copy first makes
+#                       the dynamic linker bind our kernels to the same HIP runtime (one device context, shared streams)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libvecvad_hip.so')
 
@@ -90,6 +93,8 @@ _SIGS = {
     'vv_resample2d_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_channelnorm_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_version': (C.c_char_p, []),
+    'vv_last_hip_error': (C.c_char_p, []),
+    'vv_set_last_hip_error': (None, [c_i32]),
     'vv_device_arch_ok': (c_i32, []),
 }
 
@@ -122,7 +127,10 @@ _STATUS = {1: 'VV_ERR_BAD_ARG', 2: 'VV_ERR_LAUNCH', 3: 'VV_ERR_UNSUPPORTED'}
 
 def check(status, what=''):
     if status != 0:
-        raise VecVadHipError('%s failed: %s' % (what or 'libvecvad_hip call', _STATUS.get(status, status)))
+        detail = ''
+        if status == 2 and _lib is not None:
+            detail = ' (%s)' % _lib.vv_last_hip_error().decode()
+        raise VecVadHipError('%s failed: %s%s' % (what or 'libvecvad_hip call', _STATUS.get(status, status), detail))
 
 
 def view(t, cstride, coff=0, gstride=0):

@@ -9,10 +9,22 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define VV_WG 256
 
+// hipGetLastError() is sticky per thread: clear anything an earlier, unrelated runtime call left behind so that
+// VV_CHECK_LAUNCH reports only this launch.
+#define VV_LAUNCH(...)                  \
+  do {                                  \
+    (void)hipGetLastError();            \
+    hipLaunchKernelGGL(__VA_ARGS__);    \
+  } while (0)
+
+extern "C" void vv_set_last_hip_error(int code);   // thread-local record for vv_last_hip_error()
 #define VV_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \
-    if (e__ != hipSuccess) return VV_ERR_LAUNCH;            \
+    if (e__ != hipSuccess) {                                \
+      vv_set_last_hip_error((int)e__);                      \
+      return VV_ERR_LAUNCH;                                 \
+    }                                                       \
   } while (0)
 
 // XCD-aware work-item remap: the dispatcher places block b on XCD b%8 (observed, MI355X_MICROARCH.md);

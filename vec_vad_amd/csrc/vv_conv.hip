@@ -202,7 +202,7 @@ int launch(const vv_conv_params* p, hipStream_t st) {
   const int NPH = KIND == VV_CONVT_FWD ? 4 : 1;
   const int total = p->G * NPH * NN * NT;
   const int nper = (total + 7) / 8;
-  hipLaunchKernelGGL((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
+  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
                      total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;

@@ -509,7 +509,7 @@ extern "C" int vv_pack_weights(const vv_pack_entry* table_dev, int32_t nentries,
                                vv_stream stream) {
   if (!table_dev || !params || !packed || nentries <= 0) return VV_ERR_BAD_ARG;
   int bx = nblocks(max_elems, 64);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(bx, nentries, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, params,
+  VV_LAUNCH(pack_weights_kernel, dim3(bx, nentries, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, params,
                      params_gstride, packed, packed_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -522,7 +522,7 @@ extern "C" int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t coun
                               int64_t ab_gstride, vv_stream stream) {
   if (!gamma || !beta || !running_mean || !running_var || !a || !b || !mean || !invstd) return VV_ERR_BAD_ARG;
   if (train && !stats) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, ntiles,
+  VV_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, ntiles,
                      (double)count, train, momentum, eps, stats, stats_gstride, gamma, beta, param_gstride,
                      running_mean, running_var, buf_gstride, a, b, mean, invstd, ab_gstride);
   VV_CHECK_LAUNCH();
@@ -540,9 +540,9 @@ extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
   if (p->C % 4 || p->C > 256 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
   const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   if (p->dpool)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
+    VV_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
+    VV_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -553,11 +553,11 @@ extern "C" int vv_bn_bwd_apply(int32_t G, int64_t M, int32_t C, int32_t nblk, co
                                int64_t grad_gstride, float* dz, int64_t dz_gstride, float* scratch,
                                vv_stream stream) {
   if (!partial || !y || !gamma || !mean || !invstd || !dgamma || !dbeta || !dz || !scratch) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, (double)M,
+  VV_LAUNCH(bn_bwd_sum_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, (double)M,
                      partial, dgamma, dbeta, grad_gstride, scratch);
   VV_CHECK_LAUNCH();
   const int64_t n4 = M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(n4, 8192), G), dim3(VV_WG), 0, (hipStream_t)stream, n4, C, y,
+  VV_LAUNCH(bn_bwd_apply_kernel, dim3(nblocks(n4, 8192), G), dim3(VV_WG), 0, (hipStream_t)stream, n4, C, y,
                      y_gstride, gamma, param_gstride, mean, invstd, ab_gstride, scratch, dz, dz_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -568,7 +568,7 @@ extern "C" int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream) {
       !p->score || !p->tgt0)
     return VV_ERR_BAD_ARG;
   if (p->C != 32) return VV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(outconv_fwd_kernel, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
+  VV_LAUNCH(outconv_fwd_kernel, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -581,7 +581,7 @@ extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const
                               vv_stream stream) {
   if (!dout4 || !y || !a || !b || !w || !dA || !partial) return VV_ERR_BAD_ARG;
   if (C != 32) return VV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(outconv_bwd_kernel, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
+  VV_LAUNCH(outconv_bwd_kernel, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
                      a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -590,7 +590,7 @@ extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const
 extern "C" int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
                                      float* dW, float* db, int64_t grad_gstride, vv_stream stream) {
   if (!partial || !oc || !dW || !db) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, partial, oc, dW,
+  VV_LAUNCH(outconv_bwd_reduce_kernel, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, partial, oc, dW,
                      db, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -601,10 +601,10 @@ extern "C" int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, in
   if (!dy || !scratch || !db) return VV_ERR_BAD_ARG;
   if (C > VV_WG || C % 4 || VV_WG % (C / 4) || cstride % 4 || coff % 4) return VV_ERR_UNSUPPORTED;
   const int nblk = (int)((M + 1023) / 1024);
-  hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk, G), dim3(VV_WG), 0, (hipStream_t)stream, M, C, dy, dy_gstride, cstride,
+  VV_LAUNCH(bias_grad_stage1, dim3(nblk, G), dim3(VV_WG), 0, (hipStream_t)stream, M, C, dy, dy_gstride, cstride,
                      coff, scratch, nblk);
   VV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bias_grad_stage2, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, scratch, db, grad_gstride);
+  VV_LAUNCH(bias_grad_stage2, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, scratch, db, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -614,7 +614,7 @@ extern "C" int vv_adam(int64_t n, float* param, const float* grad, float* m, flo
                        vv_stream stream) {
   if (!param || !grad || !m || !v || (n & 3)) return VV_ERR_BAD_ARG;
   const int64_t n4 = n >> 2;
-  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4, 4096)), dim3(VV_WG), 0, (hipStream_t)stream, n4, (float4*)param,
+  VV_LAUNCH(adam_kernel, dim3(nblocks(n4, 4096)), dim3(VV_WG), 0, (hipStream_t)stream, n4, (float4*)param,
                      (const float4*)grad, (float4*)m, (float4*)v, lr / bias_corr1, beta1, beta2, eps, bias_corr2_sqrt,
                      grad_scale);
   VV_CHECK_LAUNCH();
@@ -624,7 +624,7 @@ extern "C" int vv_adam(int64_t n, float* param, const float* grad, float* m, flo
 extern "C" int vv_cube_gather(int32_t B, int32_t T, int32_t Tf, int32_t HW, const int64_t* idx, const uint8_t* raw,
                               const float* flow, float* x, float* xof, vv_stream stream) {
   if ((!raw && !flow) || (raw && !x) || (flow && !xof)) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(cube_gather_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, T, Tf,
+  VV_LAUNCH(cube_gather_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, T, Tf,
                      HW, idx, raw, flow, x, xof);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -632,7 +632,7 @@ extern "C" int vv_cube_gather(int32_t B, int32_t T, int32_t Tf, int32_t HW, cons
 
 extern "C" int vv_nchw_to_nhwc(int32_t B, int32_t C, int32_t HW, const float* src, float* dst, vv_stream stream) {
   if (!src || !dst) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, C, HW,
+  VV_LAUNCH(nchw_to_nhwc_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, C, HW,
                      src, dst);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -640,7 +640,7 @@ extern "C" int vv_nchw_to_nhwc(int32_t B, int32_t C, int32_t HW, const float* sr
 extern "C" int vv_out4_to_nchw(int32_t B, int32_t HW, int32_t oc, const float* out4, float* dst, int32_t Ctot,
                                int32_t choff, vv_stream stream) {
   if (!out4 || !dst || oc > 4) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(out4_to_nchw_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
+  VV_LAUNCH(out4_to_nchw_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
                      out4, dst, Ctot, choff);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -648,13 +648,19 @@ extern "C" int vv_out4_to_nchw(int32_t B, int32_t HW, int32_t oc, const float* o
 extern "C" int vv_nchw_to_out4(int32_t B, int32_t HW, int32_t oc, const float* src, int32_t Ctot, int32_t choff,
                                float* out4, vv_stream stream) {
   if (!out4 || !src || oc > 4) return VV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(nchw_to_out4_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
+  VV_LAUNCH(nchw_to_out4_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
                      src, Ctot, choff, out4);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
 
 extern "C" const char* vv_version(void) { return "vecvad_hip 0.1 (gfx950)"; }
+
+static thread_local int g_last_hip_error = 0;
+extern "C" void vv_set_last_hip_error(int code) { g_last_hip_error = code; }
+extern "C" const char* vv_last_hip_error(void) {
+  return g_last_hip_error ? hipGetErrorString((hipError_t)g_last_hip_error) : "";
+}
 
 extern "C" int vv_device_arch_ok(void) {
   int dev = 0;

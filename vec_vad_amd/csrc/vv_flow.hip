@@ -165,7 +165,7 @@ extern "C" int vv_correlation_fwd(const float* in1, const float* in2, float* out
   const int xtiles = (oW + CORR_XT - 1) / CORR_XT;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)correlation_k1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(correlation_k1_kernel, dim3(xtiles * oH, B), dim3(VV_WG), lds, (hipStream_t)stream, in1, in2, out, C,
+  VV_LAUNCH(correlation_k1_kernel, dim3(xtiles * oH, B), dim3(VV_WG), lds, (hipStream_t)stream, in1, in2, out, C,
                      H, W, oC, oH, oW, pad_size, max_displacement, stride1, stride2, dr, xtiles);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -177,7 +177,7 @@ extern "C" int vv_resample2d_fwd(const float* img, const float* flow, float* out
   if (kernel_size != 1) return VV_ERR_UNSUPPORTED;                 // resample2d.py:8 default, flownet2.py:37-52
   if (fH > H || fW > W) return VV_ERR_BAD_ARG;
   const int64_t npix = (int64_t)B * fH * fW;
-  hipLaunchKernelGGL(resample2d_kernel, dim3((unsigned)((npix + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream,
+  VV_LAUNCH(resample2d_kernel, dim3((unsigned)((npix + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream,
                      npix, img, flow, out, C, H, W, fH, fW);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -188,7 +188,7 @@ extern "C" int vv_channelnorm_fwd(const float* in, float* out, int32_t B, int32_
   if (!in || !out) return VV_ERR_BAD_ARG;
   if (norm_deg != 2) return VV_ERR_UNSUPPORTED;                    // the kernel ignores norm_deg and always does L2
   const int64_t npix = (int64_t)B * H * W;
-  hipLaunchKernelGGL(channelnorm_kernel, dim3((unsigned)((npix + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream,
+  VV_LAUNCH(channelnorm_kernel, dim3((unsigned)((npix + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream,
                      npix, in, out, C, (int64_t)H * W);
   VV_CHECK_LAUNCH();
   return VV_OK;

@@ -170,7 +170,7 @@ int launch_w(const vv_wgrad_params* p, hipStream_t st) {
   const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
   const int total = p->G * NCI * NCO * p->ksplit;
   const int nper = (total + 7) / 8;
-  hipLaunchKernelGGL((wgrad_mfma_kernel<TH, TW, NI, KIND>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total,
+  VV_LAUNCH((wgrad_mfma_kernel<TH, TW, NI, KIND>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total,
                      nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -210,7 +210,7 @@ extern "C" int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t Cin
                                int64_t grad_gstride, vv_stream stream) {
   if (!partial || !grad) return VV_ERR_BAD_ARG;
   const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(NCI * NCO * 9 * 4, G), dim3(VV_WG), 0, (hipStream_t)stream, kind, Cin, Cout,
+  VV_LAUNCH(wgrad_reduce_kernel, dim3(NCI * NCO * 9 * 4, G), dim3(VV_WG), 0, (hipStream_t)stream, kind, Cin, Cout,
                      NCO, nslab_per_tile, partial, partial_gstride, grad, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
