@@ -29,6 +29,20 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+def _pick_ksplit(groups, ntiles, ncu=256, epilogue=1.5, max_wg=1024):
+    """Pixel-tile split factor of the weight-gradient kernel (one workgroup per CU): minimise
+    rounds * (tiles per workgroup + epilogue) where rounds = ceil(groups * ks / #CU)."""
+    best, best_cost = 1, None
+    for ks in range(1, ntiles + 1):
+        if groups * ks > max_wg and ks > 1:
+            break
+        rounds = -(-groups * ks // ncu)
+        cost = rounds * (-(-ntiles // ks) + epilogue)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = ks, cost
+    return best
+
+
 class UnitSpec:
     """One UNet of the bank: which frame it erases from the input and what it predicts."""
 
@@ -355,13 +369,13 @@ class UNetBank:
         for l in lay.convs:
             nci, nco = (l.cinp + 31) // 32, l.cout // 32
             nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
-            ks = max(1, min(nt, 512 // max(1, Ga * nci * nco)))
+            ks = _pick_ksplit(Ga * nci * nco, nt)
             wplan['c%d' % l.idx] = (ks, nci * nco * ks)
             wmax = max(wmax, nci * nco * ks)
         for u, (_, H, ci, co) in enumerate(lay.convT):
             nci, nco = ci // 32, co // 32
             nt = lib.vv_wgrad_ntiles(L.CONVT_FWD, B, H, H)
-            ks = max(1, min(nt, 512 // max(1, Ga * nci * nco)))
+            ks = _pick_ksplit(Ga * nci * nco, nt)
             wplan['t%d' % u] = (ks, nci * nco * ks)
             wmax = max(wmax, nci * nco * ks)
         ws.wpart = f(Ga, wmax * 9 * 1024)

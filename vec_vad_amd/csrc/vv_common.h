@@ -151,3 +151,151 @@ __device__ __forceinline__ void vv_stage_tile(float* lds, const VVSrc& s, int im
     }
   }
 }
+
+// Register-staged, software-pipelined tile loader: prefetch() issues every global load of the tile into registers
+// (they stay in flight under the caller's MFMA phase), commit() applies the deferred BatchNorm+ReLU and writes LDS.
+// A thread always handles the same channel quad (VV_WG % Q == 0), so its scale/shift are loaded once per chunk.
+template <int NI, int HH, int HW, int S, int NCH>
+struct VVStager {
+  static constexpr int Q = NCH / 4;
+  static constexpr int NITEMS = NI * HH * HW * Q;
+  static constexpr int NIT = (NITEMS + VV_WG - 1) / VV_WG;
+  static_assert(VV_WG % Q == 0 && NIT <= 32, "stager geometry");
+  float4 r[NIT];
+  float4 sa, sb;
+  unsigned valid;
+  bool act;
+
+  __device__ __forceinline__ void prefetch(const VVSrc& s, int img0, int y0, int x0, int c0, int tid, int cmax = 1 << 30) {
+    const int q = tid % Q;
+    const int c = c0 + q * 4;
+    valid = 0;
+    act = (s.mode == VV_IN_ACT) || (s.mode == VV_IN_CAT && c < s.csplit);
+    if (act && c < cmax) {
+      sa = *reinterpret_cast<const float4*>(s.a + c);
+      sb = *reinterpret_cast<const float4*>(s.b + c);
+    }
+    const bool immediate = (s.mode == VV_IN_POOL) || (s.mode == VV_IN_CUBE);
+    const bool second = (s.mode == VV_IN_CAT) && c >= s.csplit;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * VV_WG;
+      const int hp = it / Q;
+      const int hx = hp % HW;
+      const int t = hp / HW;
+      const int hy = t % HH;
+      const int im = t / HH;
+      const int img = img0 + im, y = y0 + hy, x = x0 + hx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((NITEMS % VV_WG == 0 || it < NITEMS) && img < s.B && (unsigned)y < (unsigned)s.SH && (unsigned)x < (unsigned)s.SW && c < cmax) {
+        valid |= 1u << k;
+        if (immediate) v = vv_fetch4(s, img, y, x, c);
+        else if (second) v = *reinterpret_cast<const float4*>(s.p1 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs1 + s.co1 + (c - s.csplit));
+        else v = *reinterpret_cast<const float4*>(s.p0 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs0 + s.co0 + c);
+      }
+      r[k] = v;
+    }
+  }
+
+  __device__ __forceinline__ void commit(float* lds, int tid) const {
+    const int q = tid % Q;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * VV_WG;
+      if (NITEMS % VV_WG == 0 || it < NITEMS) {
+        float4 v = r[k];
+        if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
+        *reinterpret_cast<float4*>(lds + (it / Q) * S + q * 4) = v;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// VVStagerB: the same register pipeline with (a) per-item pixel offsets / halo rows computed ONCE per workgroup and
+// (b) raw buffer loads: 32-bit voffset + SGPR descriptor, and out-of-image items get an offset beyond num_records so
+// the hardware bounds check returns 0.0f (the convolution's zero padding) without a branch.  Per item and tile the
+// address math is ~5 VALU instructions instead of ~30 (the staging code was issue-bound, not latency-bound).
+// VV_IN_POOL / VV_IN_CUBE items (4-tap max-pool, channel gather) keep the generic immediate path.
+template <int NI, int HH, int HW, int S, int NCH>
+struct VVStagerB {
+  static constexpr int Q = NCH / 4;
+  static constexpr int NITEMS = NI * HH * HW * Q;
+  static constexpr int NIT = (NITEMS + VV_WG - 1) / VV_WG;
+  static_assert(VV_WG % Q == 0 && NIT <= 32, "stager geometry");
+  static constexpr unsigned OOB = 0x80000000u;
+  float4 r[NIT];
+  int pix[NIT];        // (im*SH + hy)*SW + hx relative to the tile origin, or INT_MIN/2 when the column is never valid
+  short hy[NIT], im[NIT];
+  float4 sa, sb;
+  unsigned valid;
+  bool act;
+
+  __device__ __forceinline__ void init(const VVSrc& s, int x0, int tid) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * VV_WG;
+      const int hp = it / Q;
+      const int hx = hp % HW;
+      const int t = hp / HW;
+      hy[k] = (short)(t % HH);
+      im[k] = (short)(t / HH);
+      const int x = x0 + hx;
+      const bool ok = (NITEMS % VV_WG == 0 || it < NITEMS) && (unsigned)x < (unsigned)s.SW;
+      pix[k] = ok ? (im[k] * s.SH + hy[k]) * s.SW + hx : -(1 << 30);
+    }
+  }
+
+  // x0 must be the value given to init() (all tiles of a workgroup share their column origin)
+  __device__ __forceinline__ void prefetch(const VVSrc& s, int img0, int y0, int x0, int c0, int tid, int cmax = 1 << 30) {
+    const int q = tid % Q;
+    const int c = c0 + q * 4;
+    valid = 0;
+    act = (s.mode == VV_IN_ACT) || (s.mode == VV_IN_CAT && c < s.csplit);
+    if (act && c < cmax) {
+      sa = *reinterpret_cast<const float4*>(s.a + c);
+      sb = *reinterpret_cast<const float4*>(s.b + c);
+    }
+    if (s.mode == VV_IN_POOL || s.mode == VV_IN_CUBE) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int img = img0 + im[k], y = y0 + hy[k], x = x0 + ((tid + k * VV_WG) / Q) % HW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pix[k] >= 0 && img < s.B && (unsigned)y < (unsigned)s.SH && c < cmax) v = vv_fetch4(s, img, y, x, c);
+        r[k] = v;
+      }
+      return;
+    }
+    // All threads of a workgroup read the same source in one call (chunks / ci-tiles never straddle the concat split);
+    // make that provable (readfirstlane) so the buffer descriptor lives in SGPRs -- a lane-varying descriptor would be
+    // executed as a serialising waterfall loop per load.
+    const bool second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit)) != 0;
+    const float* base = second ? s.p1 + s.co1 - s.csplit : s.p0 + s.co0;
+    const int cs = second ? s.cs1 : s.cs0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    const int tile = (img0 * s.SH + y0) * s.SW + x0;      // may be negative (top halo row of image 0)
+    const bool cok = c < cmax;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int y = y0 + hy[k];
+      const bool ok = cok && (unsigned)y < (unsigned)s.SH && (img0 + im[k]) < s.B && pix[k] >= 0;
+      const unsigned off = ok ? (unsigned)((tile + pix[k]) * cs + c) * 4u : OOB;
+      valid |= ok ? (1u << k) : 0u;
+      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      r[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  }
+
+  __device__ __forceinline__ void commit(float* lds, int tid) const {
+    const int q = tid % Q;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * VV_WG;
+      if (NITEMS % VV_WG == 0 || it < NITEMS) {
+        float4 v = r[k];
+        if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
+        *reinterpret_cast<float4*>(lds + (it / Q) * S + q * 4) = v;
+      }
+    }
+  }
+};

@@ -120,10 +120,42 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
           mma_tap((ty * HW + tx) * S4, ky * 3 + kx);
         }
     } else {
+      // 9 taps x CK/8 channel groups, fully unrolled, with the weight panel of step it+PF already in flight while
+      // step it runs on the matrix cores (register ring, pinned with sched_barrier so the loads are not sunk back
+      // next to their use).
+      constexpr int KGC = CK / 8, NIT = 9 * KGC, PF = 2;
+      float4 bq[PF + 1][NR];
+      auto bload = [&](const int it, float4 (&dst)[NR]) {
+        const int tap = it / KGC, kg = it % KGC;
+        const float* wp = wg + ((int64_t)((tap * KQ + (c0 >> 3) + kg) * 2 + half) * Cout + co0 + l31) * 4;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+        for (int n = 0; n < NR; ++n) dst[n] = *reinterpret_cast<const float4*>(wp + n * 128);
+      };
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) mma_tap((ky * HW + kx) * S4, ky * 3 + kx);
+      for (int it = 0; it < PF; ++it) bload(it, bq[it]);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (it + PF < NIT) bload(it + PF, bq[(it + PF) % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tap = it / KGC, kg = it % KGC;
+        const int aoff = ((tap / 3) * HW + (tap % 3)) * S4;
+        v4f a[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          a[m] = reinterpret_cast<const v4f*>(lds4)[abase[m] + aoff + kg * 2];
+          asm volatile("" : "+v"(a[m]));
+        }
+        const float4 (&b)[NR] = bq[it % (PF + 1)];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
     }
   }
 

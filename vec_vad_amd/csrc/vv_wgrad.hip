@@ -7,8 +7,9 @@
 // with ds_read_b32: lanes 0-31 read 32 consecutive channels of pixel k, lanes 32-63 of pixel k+1 (conflict-free).
 // The layer input is re-materialised on load from the producer's pre-BN tensor (BatchNorm+ReLU / max-pool / concat /
 // frame erasure), exactly as in the forward kernel, so no post-activation tensor is ever stored.
-// Every wave writes its own slab; vv_wgrad_reduce adds the slabs in a fixed order (bitwise reproducible) and
-// scatters into the PyTorch parameter layout.
+// Tiles are software-pipelined through registers (loads of tile t+1 fly under tile t's MFMAs).  The 4 waves are
+// summed through LDS in fixed order, each workgroup writes one slab; vv_wgrad_reduce adds the slabs in a fixed order
+// (bitwise reproducible) and scatters into the PyTorch parameter layout.
 //
 // Replaces the autograd weight gradients of nn.Conv2d / nn.ConvTranspose2d (model/unet.py:10,13,54; cuDNN).
 #include "vv_common.h"
@@ -16,7 +17,7 @@
 namespace {
 
 template <int TH, int TW, int NI, int KIND>
-__global__ void __launch_bounds__(VV_WG, 2)
+__global__ void __launch_bounds__(VV_WG, 1)
 wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
   constexpr bool CT = KIND != VV_CONV3;
   constexpr int TP = TH * TW * NI;          // pixels (GEMM-K) per tile
@@ -53,23 +54,38 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  bool first = true;
-  for (int pt = ks; pt < NT; pt += KS) {
+  // software pipeline over this workgroup's pixel tiles: the global loads of tile t+1 are in flight (in registers)
+  // while tile t runs on the matrix cores; one workgroup per CU (up to 512 VGPRs per lane), so nothing else hides them.
+  VVStagerB<NI, AHH, AHW, 32, 32> stA;
+  VVStagerB<NI, BHH, BHW, 32, 32> stB;
+  static_assert(TW >= 4, "tiles span whole rows");
+  auto issue = [&](const int pt) {
     const int img0 = (pt / tpi) * NI;
     const int trem = pt % tpi;
     const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
-    if (!first) __syncthreads();
-    first = false;
-    vv_stage_tile<NI, AHH, AHW, 32, 32>(lA, sa, img0, CT ? ty0 : ty0 - 1, CT ? tx0 : tx0 - 1, cit * 32, tid, p.CinP);
-    vv_stage_tile<NI, BHH, BHW, 32, 32>(lB, sb, img0, CT ? 2 * ty0 - 1 : ty0, CT ? 2 * tx0 - 1 : tx0, cot * 32, tid);
-    __syncthreads();
+    stA.prefetch(sa, img0, CT ? ty0 : ty0 - 1, CT ? tx0 : tx0 - 1, cit * 32, tid, p.CinP);
+    stB.prefetch(sb, img0, CT ? 2 * ty0 - 1 : ty0, CT ? 2 * tx0 - 1 : tx0, cot * 32, tid);
+  };
+  // every tile of this kernel spans full image rows (TW == W), so the column origin is tile independent
+  stA.init(sa, CT ? 0 : -1, tid);
+  stB.init(sb, CT ? -1 : 0, tid);
+  const int dbg = p.pad0;                   // bring-up switch (0 in production): 1 = skip staging (timing experiments)
+  if (!(dbg & 1)) issue(ks);
+  for (int pt = ks; pt < NT; pt += KS) {
+    if (!(dbg & 1)) {
+      if (pt != ks) __syncthreads();          // every wave is done reading the previous tile
+      stA.commit(lA, tid);
+      stB.commit(lB, tid);
+      __syncthreads();
+      if (pt + KS < NT) issue(pt + KS);
+    }
 
-#pragma unroll 2
-    for (int kk = 0; kk < PPW / 2; ++kk) {
+    // k-loop over pixel pairs.  The LDS operands of step k+1 are read into a second register set while step k runs:
+    // each MFMA is followed by exactly one ds_read of the next step (pinned with sched_barrier), so the matrix pipe
+    // never waits behind a block of LDS issue slots and no ds_read is waited on right after it was issued.
+    auto addr = [&](const int kk, const float*& pa, const float*& pb) {
       const int pp = wave * PPW + 2 * kk + half;
       const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
-      const float* pa;
-      const float* pb;
       if constexpr (CT) {
         pa = lA + pp * 32 + l31;
         pb = lB + ((im * BHH + 2 * r) * BHW + 2 * c) * 32 + l31;
@@ -77,20 +93,46 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
         pa = lA + ((im * AHH + r) * AHW + c) * 32 + l31;
         pb = lB + pp * 32 + l31;
       }
-      if constexpr (CT) {
-        const float a = pa[0];
+    };
+    auto rd = [&](const float* pa, const float* pb, const int t) -> float {      // the tap-shifted operand of tap t
+      if constexpr (CT) return pb[((t / 3) * BHW + (t % 3)) * 32];
+      else return pa[((t / 3) * AHW + (t % 3)) * 32];
+    };
+    auto rd1 = [&](const float* pa, const float* pb) -> float {                   // the un-shifted operand
+      if constexpr (CT) return pa[0];
+      else return pb[0];
+    };
+    auto mfma1 = [&](const int t, const float sh, const float un) {
+      if constexpr (CT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(un, sh, acc[t], 0, 0, 0);   // A = act, B = dy(tap)
+      else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sh, un, acc[t], 0, 0, 0);                // A = act(tap), B = dy
+    };
+    constexpr int NK = PPW / 2;
+    static_assert(NK % 2 == 0, "k-loop is unrolled by two");
+    float a0[9], a1[9], b0, b1;
+    const float *pa, *pb;
+    addr(0, pa, pb);
+    b0 = rd1(pa, pb);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+    for (int t = 0; t < 9; ++t) a0[t] = rd(pa, pb, t);
+#pragma unroll 1
+    for (int kk = 0; kk < NK; kk += 2) {
+      addr(kk + 1, pa, pb);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[(ky * BHW + kx) * 32], acc[ky * 3 + kx], 0, 0, 0);
-      } else {
-        const float b = pb[0];
+      for (int t = 0; t < 9; ++t) {
+        mfma1(t, a0[t], b0);
+        if (t == 0) b1 = rd1(pa, pb);
+        a1[t] = rd(pa, pb, t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      addr(kk + 2 < NK ? kk + 2 : 0, pa, pb);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(ky * AHW + kx) * 32], b, acc[ky * 3 + kx], 0, 0, 0);
+      for (int t = 0; t < 9; ++t) {
+        mfma1(t, a1[t], b1);
+        if (t == 0) b0 = rd1(pa, pb);
+        a0[t] = rd(pa, pb, t);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
