@@ -229,6 +229,31 @@ int vv_resample2d_fwd(const float* img, const float* flow, float* out, int32_t B
 int vv_channelnorm_fwd(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t norm_deg,
                        vv_stream stream);
 
+/* ---- FlowNet2 conv stack (forward only; FlowNet2_src/models/components/misc.py:8-44, FlowNet{C,S,SD,Fusion}.py) ----
+ * Generic NHWC MFMA convolution: kind 0 = nn.Conv2d(k=R in {1,3,5,7}, stride in {1,2}, padding=(R-1)/2),
+ * kind 1 = nn.ConvTranspose2d(k4, s2, p1); optional bias; y = v > 0 ? v : slope*v  (slope 0.1 = LeakyReLU, 1.0 = none).
+ * src: NHWC with cstride % 4 == 0 and coff % 4 == 0 (pad channels must hold finite values); out: any channel slice of
+ * the consumer's concat buffer.  Weights packed by vv_pack_conv2d: [taps][CinP/8][2][CoutP][4], zero padded. */
+typedef struct vv_conv2d_params {
+  int32_t kind, R, stride;
+  int32_t B, H, W;          /* input size */
+  int32_t Cin, CinP, Cout, CoutP;
+  vv_view src;
+  const float* w;
+  const float* bias;
+  float slope;
+  int32_t pad0;
+  vv_view out;
+} vv_conv2d_params;
+int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream);
+/* w: Conv2d [N][K][R][R] (transposed = 0) or ConvTranspose2d [K][N][4][4] (transposed = 1); taps = R*R */
+int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32_t KP, int32_t N, int32_t NP,
+                   int32_t transposed, vv_stream stream);
+/* nn.Upsample(scale_factor=4, mode='bilinear' (align_corners=False) | 'nearest') on NCHW planes, times `scale`
+ * (flownet2.py:28,34,43-44,76,90,105,122) */
+int vv_upsample4(const float* src, float* dst, int32_t BC, int32_t H, int32_t W, int32_t bilinear, float scale,
+                 vv_stream stream);
+
 /* library self-description */
 const char* vv_version(void);
 /* text of the HIP error behind the last VV_ERR_LAUNCH returned on this thread ("" if none); never printed by the library */

@@ -62,7 +62,16 @@ class OutconvParams(C.Structure):
                 ('dout4', c_vp)]
 
 
+class Conv2dParams(C.Structure):
+    _fields_ = [('kind', c_i32), ('R', c_i32), ('stride', c_i32), ('B', c_i32), ('H', c_i32), ('W', c_i32),
+                ('Cin', c_i32), ('CinP', c_i32), ('Cout', c_i32), ('CoutP', c_i32), ('src', View), ('w', c_vp),
+                ('bias', c_vp), ('slope', c_f32), ('pad0', c_i32), ('out', View)]
+
+
 _SIGS = {
+    'vv_conv2d_mfma': (c_i32, [C.POINTER(Conv2dParams), c_vp]),
+    'vv_pack_conv2d': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_upsample4': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     'vv_conv_mfma': (c_i32, [C.POINTER(ConvParams), c_vp]),
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),

@@ -1,0 +1,257 @@
+// Generic NHWC MFMA convolution for the FlowNet2 forward pass (gfx950, v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   conv   : nn.Conv2d(k in {1,3,5,7}, stride in {1,2}, padding=(k-1)//2) [+ LeakyReLU(0.1)]   components/misc.py:8-28,42-44
+//   deconv : nn.ConvTranspose2d(k4, s2, p1) [+ LeakyReLU(0.1)]                                  components/misc.py:31-39
+//            (also the 2->2 channel "upsampled_flow" layers, FlowNetC.py:53-60)
+// FlowNet2 is built with_bn=False (flownet2.py:13), so there is no normalisation on this path.
+//
+// Same structure as the UNet kernel (vv_conv.hip): one workgroup = 8x32 output pixels x 32/64 output channels,
+// input halo tile [(TH-1)*s+R][(TW-1)*s+R][CK+4] in LDS (zero padding by predicate, ragged image edges masked),
+// packed weight panels [tap][Cin/8][2][CoutP][4] read from global/L2, 4 MFMAs per (A,B) float4 pair.
+// The transposed conv runs as 4 output-parity phases with 2x2 taps each.  Channel counts are arbitrary: K is padded
+// with zero weights, N is masked in the epilogue; producers write straight into channel slices of the consumer's
+// concat buffer (vv_view), so torch.cat never runs.
+#include "vv_common.h"
+
+namespace {
+
+template <int R, int STRIDE, int DECONV, int NR, int CK>
+__global__ void __launch_bounds__(VV_WG, 2)
+conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY, const int NN, const int total,
+                   const int nper) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HH = DECONV ? TH + 2 : (TH - 1) * STRIDE + R;
+  constexpr int HW = DECONV ? TW + 2 : (TW - 1) * STRIDE + R;
+  constexpr int SP = DECONV ? 1 : STRIDE;
+  constexpr int S = CK + 4, S4 = S / 4;
+  constexpr int MR = 2, TN = NR * 32;
+  constexpr int NTAP = DECONV ? 4 : R * R;
+  __shared__ float4 lds4[HH * HW * S4];
+  float* lds = reinterpret_cast<float*>(lds4);
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int tx = w % tilesX; w /= tilesX;
+  const int ty = w % tilesY; w /= tilesY;
+  const int nn = w % NN; w /= NN;
+  constexpr int NPH = DECONV ? 4 : 1;
+  const int ph = w % NPH;
+  const int img = w / NPH;
+  const int py = ph >> 1, px = ph & 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int H = p.H, W = p.W;
+  // tile coordinate space: conv = output pixels, deconv = input pixels (each yields one output per phase)
+  const int ty0 = ty * TH, tx0 = tx * TW;
+  const int pad = (R - 1) / 2;
+  const int oy0 = DECONV ? ty0 - 1 : ty0 * STRIDE - pad;
+  const int ox0 = DECONV ? tx0 - 1 : tx0 * STRIDE - pad;
+
+  VVSrc s;
+  s.p0 = p.src.ptr; s.cs0 = p.src.cstride; s.co0 = p.src.coff; s.a = s.b = nullptr; s.p1 = nullptr; s.cs1 = s.co1 = 0;
+  s.chmap = nullptr; s.csplit = 0; s.mode = VV_IN_PLAIN; s.SH = H; s.SW = W; s.B = p.B;
+
+  const int CoutP = p.CoutP, CinP = p.CinP, KQ = CinP >> 3;
+  const int co0 = nn * TN;
+  const float* __restrict__ wg = p.w;
+
+  int abase[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int pp = wave * 64 + m * 32 + l31;
+    const int r = pp / TW, c = pp % TW;
+    abase[m] = ((r * SP) * HW + c * SP) * S4 + half;
+  }
+  v16f acc[MR][NR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  for (int c0 = 0; c0 < CinP; c0 += CK) {
+    if (c0) __syncthreads();
+    vv_stage_tile<1, HH, HW, S, CK>(lds, s, img, oy0, ox0, c0, tid, p.src.cstride);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < NTAP; ++t) {
+      int aoff, wt;
+      if constexpr (DECONV) {
+        // oy = 2*iy - 1 + ky: even rows use ky=1 (iy=r) and ky=3 (iy=r-1); odd rows ky=2 (iy=r) and ky=0 (iy=r+1)
+        const int ty_ = t >> 1, tx_ = t & 1;
+        const int dy = py ? (ty_ ? 1 : 0) : (ty_ ? -1 : 0), ky = py ? (ty_ ? 0 : 2) : (ty_ ? 3 : 1);
+        const int dx = px ? (tx_ ? 1 : 0) : (tx_ ? -1 : 0), kx = px ? (tx_ ? 0 : 2) : (tx_ ? 3 : 1);
+        aoff = ((1 + dy) * HW + (1 + dx)) * S4;
+        wt = ky * 4 + kx;
+      } else {
+        aoff = ((t / R) * HW + (t % R)) * S4;
+        wt = t;
+      }
+#pragma unroll
+      for (int kg = 0; kg < CK / 8; ++kg) {
+        v4f a[MR];
+        float4 b[NR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          a[m] = reinterpret_cast<const v4f*>(lds4)[abase[m] + aoff + kg * 2];
+          asm volatile("" : "+v"(a[m]));
+        }
+        const float* wp = wg + ((int64_t)((wt * KQ + (c0 >> 3) + kg) * 2 + half) * CoutP + co0 + l31) * 4;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) b[n] = *reinterpret_cast<const float4*>(wp + n * 128);
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, LeakyReLU, masked NHWC store into the (possibly shared concat) output buffer
+  const int OH = DECONV ? 2 * H : (H + 2 * pad - R) / STRIDE + 1;
+  const int OW = DECONV ? 2 * W : (W + 2 * pad - R) / STRIDE + 1;
+  const int LH = DECONV ? H : OH, LW = DECONV ? W : OW;      // extent of the tile coordinate space
+  float* __restrict__ outg = p.out.ptr + p.out.coff;
+  const int ocs = p.out.cstride;
+  const float slope = p.slope;
+  float bias[NR];
+  bool cok[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    const int co = co0 + n * 32 + l31;
+    cok[n] = co < p.Cout;
+    bias[n] = (p.bias && cok[n]) ? p.bias[co] : 0.f;
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+      const int pp = wave * 64 + m * 32 + row;
+      const int r = ty0 + pp / TW, c = tx0 + pp % TW;
+      if (r < LH && c < LW) {
+        const int oy = DECONV ? 2 * r + py : r, ox = DECONV ? 2 * c + px : c;
+        float* o = outg + ((int64_t)(img * OH + oy) * OW + ox) * ocs + co0 + l31;
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+          if (cok[n]) {
+            float v = acc[m][n][i] + bias[n];
+            v = v > 0.f ? v : v * slope;
+            o[n * 32] = v;
+          }
+      }
+    }
+}
+
+__global__ void __launch_bounds__(VV_WG)
+pack_conv2d_kernel(const float* __restrict__ w, float* __restrict__ packed, const int taps, const int K, const int KP,
+                   const int N, const int NP, const int transposed) {
+  const int64_t total = (int64_t)taps * KP * NP;
+  const int KQ = KP >> 3;
+  for (int64_t d = (int64_t)blockIdx.x * VV_WG + threadIdx.x; d < total; d += (int64_t)gridDim.x * VV_WG) {
+    const int j = (int)(d & 3);
+    int64_t t = d >> 2;
+    const int n = (int)(t % NP); t /= NP;
+    const int half = (int)(t & 1); t >>= 1;
+    const int kq = (int)(t % KQ);
+    const int tap = (int)(t / KQ);
+    const int k = kq * 8 + half * 4 + j;
+    float v = 0.f;
+    if (k < K && n < N)
+      v = transposed ? w[((int64_t)k * N + n) * taps + tap]       // ConvTranspose2d weight [Cin=k][Cout=n][ky][kx]
+                     : w[((int64_t)n * K + k) * taps + tap];      // Conv2d weight [Cout=n][Cin=k][ky][kx]
+    packed[d] = v;
+  }
+}
+
+__global__ void __launch_bounds__(VV_WG)
+upsample4_kernel(const int64_t n, const float* __restrict__ src, float* __restrict__ dst, const int C, const int H,
+                 const int W, const int bilinear, const float scale) {
+  // NCHW, x4: nn.Upsample(scale_factor=4, mode='bilinear' (align_corners=False) | 'nearest'), flownet2.py:28,34,43-44
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= n) return;
+  const int OW = 4 * W, OH = 4 * H;
+  const int ox = (int)(e % OW);
+  const int oy = (int)((e / OW) % OH);
+  const int64_t bc = e / ((int64_t)OW * OH);
+  const float* p = src + bc * H * W;
+  float v;
+  if (bilinear) {
+    const float sy = fmaxf((oy + 0.5f) * 0.25f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.25f - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    v = hy * (hx * p[y0 * W + x0] + lx * p[y0 * W + x1]) + ly * (hx * p[y1 * W + x0] + lx * p[y1 * W + x1]);
+  } else {
+    v = p[min(oy >> 2, H - 1) * W + min(ox >> 2, W - 1)];
+  }
+  dst[e] = v * scale;
+}
+
+template <int R, int STRIDE, int DECONV, int CK>
+int launch2d(const vv_conv2d_params* p, hipStream_t st) {
+  const int pad = (R - 1) / 2;
+  const int LH = DECONV ? p->H : (p->H + 2 * pad - R) / STRIDE + 1;
+  const int LW = DECONV ? p->W : (p->W + 2 * pad - R) / STRIDE + 1;
+  const int tilesY = (LH + 7) / 8, tilesX = (LW + 31) / 32;
+  const bool wide = p->CoutP % 64 == 0 && p->Cout > 32;
+  const int NN = p->CoutP / (wide ? 64 : 32);
+  const int total = p->B * (DECONV ? 4 : 1) * NN * tilesY * tilesX;
+  const int nper = (total + 7) / 8;
+  if (wide)
+    VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 2, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
+              total, nper);
+  else
+    VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 1, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
+              total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+}  // namespace
+
+extern "C" int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream) {
+  if (!p || !p->src.ptr || !p->w || !p->out.ptr) return VV_ERR_BAD_ARG;
+  if (p->CinP % 16 || p->CoutP % 32 || p->src.cstride % 4 || p->src.coff % 4) return VV_ERR_BAD_ARG;
+  if ((int64_t)p->B * p->H * p->W * p->src.cstride >= (1ll << 31)) return VV_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->kind == 1) return launch2d<4, 2, 1, 16>(p, st);
+  if (p->kind != 0) return VV_ERR_BAD_ARG;
+  switch (p->R * 10 + p->stride) {
+    case 11: return launch2d<1, 1, 0, 16>(p, st);
+    case 31: return launch2d<3, 1, 0, 16>(p, st);
+    case 32: return launch2d<3, 2, 0, 8>(p, st);
+    case 52: return launch2d<5, 2, 0, 8>(p, st);
+    case 72: return launch2d<7, 2, 0, 8>(p, st);
+  }
+  return VV_ERR_UNSUPPORTED;
+}
+
+extern "C" int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32_t KP, int32_t N, int32_t NP,
+                              int32_t transposed, vv_stream stream) {
+  if (!w || !packed || KP % 8 || NP % 32) return VV_ERR_BAD_ARG;
+  const int64_t total = (int64_t)taps * KP * NP;
+  int64_t nb = (total + VV_WG - 1) / VV_WG;
+  if (nb > 16384) nb = 16384;
+  VV_LAUNCH(pack_conv2d_kernel, dim3((unsigned)nb), dim3(VV_WG), 0, (hipStream_t)stream, w, packed, taps, K, KP, N, NP,
+            transposed);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_upsample4(const float* src, float* dst, int32_t BC, int32_t H, int32_t W, int32_t bilinear, float scale,
+                            vv_stream stream) {
+  if (!src || !dst) return VV_ERR_BAD_ARG;
+  const int64_t n = (int64_t)BC * 16 * H * W;
+  VV_LAUNCH(upsample4_kernel, dim3((unsigned)((n + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream, n, src, dst, BC,
+            H, W, bilinear, scale);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}

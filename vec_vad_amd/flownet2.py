@@ -1,0 +1,465 @@
+"""FlowNet2 forward pass (inference only, as VEC_VAD uses it: calc_optical_flow.py:15-22,56-57) on gfx950 kernels.
+
+Module tree / constructor signatures / ``state_dict`` keys follow the reference (FlowNet2_src/models/flownet2.py:10-149,
+components/FlowNetC.py:10-132, FlowNetS.py:11-96, FlowNetSD.py:9-103, FlowNetFusion.py:9-64, misc.py:8-44) so that
+``FlowNet2_checkpoint.pth.tar['state_dict']`` loads unchanged.  What runs: every conv / deconv / predict_flow layer is
+the hand-written MFMA kernel ``vv_conv2d_mfma`` on NHWC buffers (producers write straight into the channel slices of
+the consumer's concat buffer), the three native ops are ``vv_correlation_fwd / vv_resample2d_fwd / vv_channelnorm_fwd``
+and the x4 flow up-sampling is ``vv_upsample4``.  Only tensor plumbing (mean subtraction of the input, NCHW<->NHWC
+views, packing 12/11-channel network inputs) uses torch tensor ops.  No torch.nn op, no fallback.
+
+``with_bn`` must be False and ``fp16`` False (what VEC_VAD instantiates, flownet2.py:12-17).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .flow_ops import Correlation, Resample2d, ChannelNorm, correlation, resample2d, channelnorm
+
+
+def _c4(c):
+    return (c + 3) // 4 * 4
+
+
+def _c16(c):
+    return (c + 15) // 16 * 16
+
+
+def _c32(c):
+    return (c + 31) // 32 * 32
+
+
+def conv(in_channels, out_channels, kernel_size=3, stride=1, bias=True, with_bn=False, with_relu=True):
+    """reference components/misc.py:8-28 (with_bn=False only)."""
+    if with_bn:
+        raise NotImplementedError('FlowNet2 is built with_bn=False in VEC_VAD (flownet2.py:13)')
+    layers = [nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True)]
+    if with_relu:
+        layers.append(nn.LeakyReLU(0.1, inplace=True))
+    return nn.Sequential(*layers)
+
+
+def deconv(in_channels, out_channels):
+    """reference components/misc.py:31-39."""
+    return nn.Sequential(nn.ConvTranspose2d(in_channels, out_channels, kernel_size=4, stride=2, padding=1, bias=True),
+                         nn.LeakyReLU(0.1, inplace=True))
+
+
+def predict_flow(in_channels):
+    """reference components/misc.py:42-44."""
+    return nn.Conv2d(in_channels, 2, kernel_size=3, stride=1, padding=1, bias=True)
+
+
+def _xavier_init(module):
+    # flownet2.py:50-59 / FlowNetC.py:64-73: uniform(bias), xavier_uniform(weight)
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            if m.bias is not None:
+                nn.init.uniform_(m.bias)
+            nn.init.xavier_uniform_(m.weight)
+
+
+class _Buf:
+    """NHWC activation buffer [B,H,W,ceil4(C)] (zero initialised so pad channels are finite)."""
+
+    def __init__(self, B, H, W, C, device):
+        self.B, self.H, self.W, self.C, self.cs = B, H, W, C, _c4(C)
+        self.t = torch.zeros(B, H, W, self.cs, device=device, dtype=torch.float32)
+
+    def view(self, coff=0):
+        return L.View(self.t.data_ptr(), 0, self.cs, coff)
+
+    def nchw(self, c0=0, c1=None):
+        return self.t[..., c0:(self.C if c1 is None else c1)].permute(0, 3, 1, 2).contiguous()
+
+
+class _Runner:
+    """Launches one conv / deconv layer; packed weight panels are cached per module and refreshed when the parameter
+    tensor changes (load_state_dict bumps ``_version``)."""
+
+    def __init__(self):
+        self.lib = L.lib()
+        self.cache = {}
+
+    def _packed(self, m):
+        key = id(m)
+        ver = (m.weight.data_ptr(), m.weight._version)
+        ent = self.cache.get(key)
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        w = m.weight.detach().contiguous().float()
+        transposed = isinstance(m, nn.ConvTranspose2d)
+        K, N = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        taps = w.shape[2] * w.shape[3]
+        KP, NP = _c16(K), _c32(N)
+        packed = torch.empty(taps * KP * NP, device=w.device, dtype=torch.float32)
+        L.check(self.lib.vv_pack_conv2d(w.data_ptr(), packed.data_ptr(), taps, K, KP, N, NP, 1 if transposed else 0,
+                                        torch.cuda.current_stream(w.device).cuda_stream), 'pack_conv2d')
+        self.cache[key] = (ver, packed, K, KP, N, NP)
+        return packed
+
+    def __call__(self, layer, src, dst, dst_coff=0):
+        """layer: nn.Sequential(Conv2d|ConvTranspose2d[, LeakyReLU]) or a bare Conv2d / ConvTranspose2d."""
+        if isinstance(layer, nn.Sequential):
+            m = layer[0]
+            slope = 0.1 if len(layer) > 1 else 1.0
+        else:
+            m, slope = layer, 1.0
+        packed = self._packed(m)
+        _, _, K, KP, N, NP = self.cache[id(m)]
+        assert K == src.C, (K, src.C)
+        de = isinstance(m, nn.ConvTranspose2d)
+        if de:
+            assert m.kernel_size == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
+            OH, OW = 2 * src.H, 2 * src.W
+            R, stride = 4, 2
+        else:
+            R, stride = m.kernel_size[0], m.stride[0]
+            pad = (R - 1) // 2
+            assert m.padding == (pad, pad)
+            OH, OW = (src.H + 2 * pad - R) // stride + 1, (src.W + 2 * pad - R) // stride + 1
+        assert (dst.H, dst.W) == (OH, OW), ((dst.H, dst.W), (OH, OW))
+        assert dst_coff + N <= dst.cs
+        p = L.Conv2dParams(1 if de else 0, R, stride, src.B, src.H, src.W, K, KP, N, NP, src.view(0), packed.data_ptr(),
+                           m.bias.data_ptr() if m.bias is not None else None, slope, 0, dst.view(dst_coff))
+        L.check(self.lib.vv_conv2d_mfma(C.byref(p), torch.cuda.current_stream(src.t.device).cuda_stream),
+                'conv2d %dx%d s%d %d->%d' % (R, R, stride, K, N))
+        return dst
+
+
+def _upsample4(x_nchw, bilinear, scale):
+    x = x_nchw.contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, Cc, 4 * H, 4 * W, device=x.device, dtype=torch.float32)
+    L.check(L.lib().vv_upsample4(x.data_ptr(), out.data_ptr(), B * Cc, H, W, 1 if bilinear else 0, float(scale),
+                                 torch.cuda.current_stream(x.device).cuda_stream), 'upsample4')
+    return out
+
+
+def _to_buf(x_nchw, device=None):
+    B, Cc, H, W = x_nchw.shape
+    b = _Buf(B, H, W, Cc, x_nchw.device)
+    b.t[..., :Cc] = x_nchw.permute(0, 2, 3, 1)
+    return b
+
+
+class _Decoder:
+    """The refinement ladder shared by FlowNetC / FlowNetS (predict_flow on the concat buffers, FlowNetC.py:104-127)."""
+
+    @staticmethod
+    def run(net, run, out_conv6, cat5, cat4, cat3, cat2, inter=False):
+        dev = out_conv6.t.device
+        B = out_conv6.B
+
+        def flow_of(pred, src):
+            f = _Buf(B, src.H, src.W, 2, dev)
+            run(pred, src, f)
+            return f
+
+        flow6 = flow_of(net.predict_flow6, out_conv6)
+        run(net.upsampled_flow6_to_5, flow6, cat5, cat5.C - 2)
+        run(net.deconv5, out_conv6, cat5, cat5.C - 2 - net.deconv5[0].out_channels)
+        cats = [(cat5, 5, cat4), (cat4, 4, cat3), (cat3, 3, cat2)]
+        for cat, lvl, nxt in cats:
+            src = cat
+            if inter:
+                ic = getattr(net, 'inter_conv%d' % lvl)
+                src = _Buf(B, cat.H, cat.W, ic[0].out_channels, dev)
+                run(ic, cat, src)
+            flow = flow_of(getattr(net, 'predict_flow%d' % lvl), src)
+            run(getattr(net, 'upsampled_flow%d_to_%d' % (lvl, lvl - 1)), flow, nxt, nxt.C - 2)
+            d = getattr(net, 'deconv%d' % (lvl - 1))
+            run(d, cat, nxt, nxt.C - 2 - d[0].out_channels)
+        src = cat2
+        if inter:
+            src = _Buf(B, cat2.H, cat2.W, net.inter_conv2[0].out_channels, dev)
+            run(net.inter_conv2, cat2, src)
+        return flow_of(net.predict_flow2, src)
+
+
+class FlowNetC(nn.Module):
+    def __init__(self, with_bn=False, fp16=False):
+        super().__init__()
+        assert not with_bn and not fp16
+        self.with_bn, self.fp16 = with_bn, fp16
+        self.conv1 = conv(3, 64, kernel_size=7, stride=2)
+        self.conv2 = conv(64, 128, kernel_size=5, stride=2)
+        self.conv3 = conv(128, 256, kernel_size=5, stride=2)
+        self.conv_redir = conv(256, 32, kernel_size=1, stride=1)
+        self.corr = Correlation(pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2, corr_multiply=1)
+        self.corr_activation = nn.LeakyReLU(0.1, inplace=True)
+        self.conv3_1 = conv(473, 256)
+        self.conv4 = conv(256, 512, stride=2)
+        self.conv4_1 = conv(512, 512)
+        self.conv5 = conv(512, 512, stride=2)
+        self.conv5_1 = conv(512, 512)
+        self.conv6 = conv(512, 1024, stride=2)
+        self.conv6_1 = conv(1024, 1024)
+        self.deconv5 = deconv(1024, 512)
+        self.deconv4 = deconv(1026, 256)
+        self.deconv3 = deconv(770, 128)
+        self.deconv2 = deconv(386, 64)
+        self.predict_flow6 = predict_flow(1024)
+        self.predict_flow5 = predict_flow(1026)
+        self.predict_flow4 = predict_flow(770)
+        self.predict_flow3 = predict_flow(386)
+        self.predict_flow2 = predict_flow(194)
+        for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
+            setattr(self, 'upsampled_flow%d_to_%d' % (a, b), nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+        self.upsample1 = nn.Upsample(scale_factor=4, mode='bilinear')
+        _xavier_init(self)
+
+    def run(self, run, img0, img1):
+        """img0 / img1: _Buf [B,H,W,3].  Returns flow2 _Buf [B,H/4,W/4,2] (FlowNetC.py:75-132)."""
+        dev, B, H, W = img0.t.device, img0.B, img0.H, img0.W
+        nb = lambda h, w, c: _Buf(B, h, w, c, dev)
+        cat2 = nb(H // 4, W // 4, 194)
+        c1a, c1b = nb(H // 2, W // 2, 64), nb(H // 2, W // 2, 64)
+        run(self.conv1, img0, c1a); run(self.conv1, img1, c1b)
+        c2b = nb(H // 4, W // 4, 128)
+        c2a_view = _SliceView(cat2, 0, 128)
+        run(self.conv2, c1a, cat2, 0); run(self.conv2, c1b, c2b)
+        c3a, c3b = nb(H // 8, W // 8, 256), nb(H // 8, W // 8, 256)
+        run(self.conv3, c2a_view, c3a); run(self.conv3, c2b, c3b)
+        in31 = nb(H // 8, W // 8, 473)
+        corr = correlation(c3a.nchw(), c3b.nchw(), 20, 1, 20, 1, 2, 1)
+        in31.t[..., 32:473] = torch.where(corr > 0, corr, corr * 0.1).permute(0, 2, 3, 1)      # corr_activation
+        run(self.conv_redir, c3a, in31, 0)
+        cat3 = nb(H // 8, W // 8, 386)
+        run(self.conv3_1, in31, cat3, 0)
+        cat4 = nb(H // 16, W // 16, 770)
+        t4 = nb(H // 16, W // 16, 512)
+        run(self.conv4, _SliceView(cat3, 0, 256), t4); run(self.conv4_1, t4, cat4, 0)
+        cat5 = nb(H // 32, W // 32, 1026)
+        t5 = nb(H // 32, W // 32, 512)
+        run(self.conv5, _SliceView(cat4, 0, 512), t5); run(self.conv5_1, t5, cat5, 0)
+        t6, c6 = nb(H // 64, W // 64, 1024), nb(H // 64, W // 64, 1024)
+        run(self.conv6, _SliceView(cat5, 0, 512), t6); run(self.conv6_1, t6, c6)
+        return _Decoder.run(self, run, c6, cat5, cat4, cat3, cat2)
+
+
+class _SliceView:
+    """The first C channels of a concat buffer seen as a conv input (coff 0)."""
+
+    def __init__(self, buf, c0, c):
+        assert c0 == 0
+        self.B, self.H, self.W, self.C, self.cs, self.t = buf.B, buf.H, buf.W, c, buf.cs, buf.t
+
+    def view(self, coff=0):
+        return L.View(self.t.data_ptr(), 0, self.cs, coff)
+
+
+class FlowNetS(nn.Module):
+    def __init__(self, input_channels=12, with_bn=False):
+        super().__init__()
+        assert not with_bn
+        self.with_bn = with_bn
+        self.conv1 = conv(input_channels, 64, kernel_size=7, stride=2)
+        self.conv2 = conv(64, 128, kernel_size=5, stride=2)
+        self.conv3 = conv(128, 256, kernel_size=5, stride=2)
+        self.conv3_1 = conv(256, 256)
+        self.conv4 = conv(256, 512, stride=2)
+        self.conv4_1 = conv(512, 512)
+        self.conv5 = conv(512, 512, stride=2)
+        self.conv5_1 = conv(512, 512)
+        self.conv6 = conv(512, 1024, stride=2)
+        self.conv6_1 = conv(1024, 1024)
+        self.deconv5 = deconv(1024, 512)
+        self.deconv4 = deconv(1026, 256)
+        self.deconv3 = deconv(770, 128)
+        self.deconv2 = deconv(386, 64)
+        self.predict_flow6 = predict_flow(1024)
+        self.predict_flow5 = predict_flow(1026)
+        self.predict_flow4 = predict_flow(770)
+        self.predict_flow3 = predict_flow(386)
+        self.predict_flow2 = predict_flow(194)
+        for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
+            setattr(self, 'upsampled_flow%d_to_%d' % (a, b), nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=False))
+        self.upsample1 = nn.Upsample(scale_factor=4, mode='bilinear')
+        _xavier_init(self)
+
+    def run(self, run, x):
+        """x: _Buf [B,H,W,12] (FlowNetS.py:63-96)."""
+        dev, B, H, W = x.t.device, x.B, x.H, x.W
+        nb = lambda h, w, c: _Buf(B, h, w, c, dev)
+        c1 = nb(H // 2, W // 2, 64)
+        run(self.conv1, x, c1)
+        cat2 = nb(H // 4, W // 4, 194)
+        run(self.conv2, c1, cat2, 0)
+        t3, cat3 = nb(H // 8, W // 8, 256), nb(H // 8, W // 8, 386)
+        run(self.conv3, _SliceView(cat2, 0, 128), t3); run(self.conv3_1, t3, cat3, 0)
+        t4, cat4 = nb(H // 16, W // 16, 512), nb(H // 16, W // 16, 770)
+        run(self.conv4, _SliceView(cat3, 0, 256), t4); run(self.conv4_1, t4, cat4, 0)
+        t5, cat5 = nb(H // 32, W // 32, 512), nb(H // 32, W // 32, 1026)
+        run(self.conv5, _SliceView(cat4, 0, 512), t5); run(self.conv5_1, t5, cat5, 0)
+        t6, c6 = nb(H // 64, W // 64, 1024), nb(H // 64, W // 64, 1024)
+        run(self.conv6, _SliceView(cat5, 0, 512), t6); run(self.conv6_1, t6, c6)
+        return _Decoder.run(self, run, c6, cat5, cat4, cat3, cat2)
+
+
+class FlowNetSD(nn.Module):
+    def __init__(self, with_bn=False):
+        super().__init__()
+        assert not with_bn
+        self.with_bn = with_bn
+        self.conv0 = conv(6, 64)
+        self.conv1 = conv(64, 64, stride=2)
+        self.conv1_1 = conv(64, 128)
+        self.conv2 = conv(128, 128, stride=2)
+        self.conv2_1 = conv(128, 128)
+        self.conv3 = conv(128, 256, stride=2)
+        self.conv3_1 = conv(256, 256)
+        self.conv4 = conv(256, 512, stride=2)
+        self.conv4_1 = conv(512, 512)
+        self.conv5 = conv(512, 512, stride=2)
+        self.conv5_1 = conv(512, 512)
+        self.conv6 = conv(512, 1024, stride=2)
+        self.conv6_1 = conv(1024, 1024)
+        self.deconv5 = deconv(1024, 512)
+        self.deconv4 = deconv(1026, 256)
+        self.deconv3 = deconv(770, 128)
+        self.deconv2 = deconv(386, 64)
+        self.inter_conv5 = conv(1026, 512, with_relu=False)
+        self.inter_conv4 = conv(770, 256, with_relu=False)
+        self.inter_conv3 = conv(386, 128, with_relu=False)
+        self.inter_conv2 = conv(194, 64, with_relu=False)
+        self.predict_flow6 = predict_flow(1024)
+        self.predict_flow5 = predict_flow(512)
+        self.predict_flow4 = predict_flow(256)
+        self.predict_flow3 = predict_flow(128)
+        self.predict_flow2 = predict_flow(64)
+        for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
+            setattr(self, 'upsampled_flow%d_to_%d' % (a, b), nn.ConvTranspose2d(2, 2, 4, 2, 1))
+        self.upsample1 = nn.Upsample(scale_factor=4, mode='bilinear')
+        _xavier_init(self)
+
+    def run(self, run, x):
+        """x: _Buf [B,H,W,6] (FlowNetSD.py:60-103)."""
+        dev, B, H, W = x.t.device, x.B, x.H, x.W
+        nb = lambda h, w, c: _Buf(B, h, w, c, dev)
+        c0 = nb(H, W, 64)
+        run(self.conv0, x, c0)
+        t1, c1 = nb(H // 2, W // 2, 64), nb(H // 2, W // 2, 128)
+        run(self.conv1, c0, t1); run(self.conv1_1, t1, c1)
+        t2, cat2 = nb(H // 4, W // 4, 128), nb(H // 4, W // 4, 194)
+        run(self.conv2, c1, t2); run(self.conv2_1, t2, cat2, 0)
+        t3, cat3 = nb(H // 8, W // 8, 256), nb(H // 8, W // 8, 386)
+        run(self.conv3, _SliceView(cat2, 0, 128), t3); run(self.conv3_1, t3, cat3, 0)
+        t4, cat4 = nb(H // 16, W // 16, 512), nb(H // 16, W // 16, 770)
+        run(self.conv4, _SliceView(cat3, 0, 256), t4); run(self.conv4_1, t4, cat4, 0)
+        t5, cat5 = nb(H // 32, W // 32, 512), nb(H // 32, W // 32, 1026)
+        run(self.conv5, _SliceView(cat4, 0, 512), t5); run(self.conv5_1, t5, cat5, 0)
+        t6, c6 = nb(H // 64, W // 64, 1024), nb(H // 64, W // 64, 1024)
+        run(self.conv6, _SliceView(cat5, 0, 512), t6); run(self.conv6_1, t6, c6)
+        return _Decoder.run(self, run, c6, cat5, cat4, cat3, cat2, inter=True)
+
+
+class FlowNetFusion(nn.Module):
+    def __init__(self, with_bn=False):
+        super().__init__()
+        assert not with_bn
+        self.with_bn = with_bn
+        self.conv0 = conv(11, 64)
+        self.conv1 = conv(64, 64, stride=2)
+        self.conv1_1 = conv(64, 128)
+        self.conv2 = conv(128, 128, stride=2)
+        self.conv2_1 = conv(128, 128)
+        self.deconv1 = deconv(128, 32)
+        self.deconv0 = deconv(162, 16)
+        self.inter_conv1 = conv(162, 32, with_relu=False)
+        self.inter_conv0 = conv(82, 16, with_relu=False)
+        self.predict_flow2 = predict_flow(128)
+        self.predict_flow1 = predict_flow(32)
+        self.predict_flow0 = predict_flow(16)
+        self.upsampled_flow2_to_1 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow1_to_0 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        _xavier_init(self)
+
+    def run(self, run, x):
+        """x: _Buf [B,H,W,11] -> full-resolution flow _Buf [B,H,W,2] (FlowNetFusion.py:43-64)."""
+        dev, B, H, W = x.t.device, x.B, x.H, x.W
+        nb = lambda h, w, c: _Buf(B, h, w, c, dev)
+        cat0 = nb(H, W, 82)
+        run(self.conv0, x, cat0, 0)
+        t1, cat1 = nb(H // 2, W // 2, 64), nb(H // 2, W // 2, 162)
+        run(self.conv1, _SliceView(cat0, 0, 64), t1); run(self.conv1_1, t1, cat1, 0)
+        t2, c2 = nb(H // 4, W // 4, 128), nb(H // 4, W // 4, 128)
+        run(self.conv2, _SliceView(cat1, 0, 128), t2); run(self.conv2_1, t2, c2)
+        f2 = nb(H // 4, W // 4, 2)
+        run(self.predict_flow2, c2, f2)
+        run(self.upsampled_flow2_to_1, f2, cat1, 160)
+        run(self.deconv1, c2, cat1, 128)
+        i1, f1 = nb(H // 2, W // 2, 32), nb(H // 2, W // 2, 2)
+        run(self.inter_conv1, cat1, i1); run(self.predict_flow1, i1, f1)
+        run(self.upsampled_flow1_to_0, f1, cat0, 80)
+        run(self.deconv0, cat1, cat0, 64)
+        i0, f0 = nb(H, W, 16), nb(H, W, 2)
+        run(self.inter_conv0, cat0, i0); run(self.predict_flow0, i0, f0)
+        return f0
+
+
+class FlowNet2(nn.Module):
+    """FlowNetC -> warp -> FlowNetS -> warp -> FlowNetS, || FlowNetSD, -> FlowNetFusion (flownet2.py:65-149)."""
+
+    def __init__(self, with_bn=False, fp16=False, rgb_max=255., div_flow=20., grads=None):
+        super().__init__()
+        if with_bn or fp16:
+            raise NotImplementedError('VEC_VAD instantiates FlowNet2() with_bn=False, fp16=False (calc_optical_flow.py:15)')
+        self.with_bn, self.div_flow, self.rgb_max = with_bn, div_flow, rgb_max
+        self.grads = {} if grads is None else grads
+        self.channelnorm = ChannelNorm()
+        self.flownetc = FlowNetC(with_bn=with_bn, fp16=fp16)
+        self.upsample1 = nn.Upsample(scale_factor=4, mode='bilinear')
+        self.resample1 = Resample2d()
+        self.flownets_1 = FlowNetS(with_bn=with_bn)
+        self.upsample2 = nn.Upsample(scale_factor=4, mode='bilinear')
+        self.resample2 = Resample2d()
+        self.flownets_2 = FlowNetS(with_bn=with_bn)
+        self.flownets_d = FlowNetSD(with_bn=with_bn)
+        self.upsample3 = nn.Upsample(scale_factor=4, mode='nearest')
+        self.upsample4 = nn.Upsample(scale_factor=4, mode='nearest')
+        self.resample3 = Resample2d()
+        self.resample4 = Resample2d()
+        self.flownetfusion = FlowNetFusion(with_bn=with_bn)
+        _xavier_init(self)
+        self._runner = None
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        """inputs [B,3,2,H,W] fp32 in 0..rgb_max (H, W multiples of 64) -> flow [B,2,H,W]."""
+        if not inputs.is_cuda:
+            raise L.VecVadHipError('FlowNet2 runs on the GPU only (no CPU fallback)')
+        if inputs.shape[3] % 64 or inputs.shape[4] % 64:
+            raise ValueError('H and W must be multiples of 64 (the reference fails with a cat size mismatch otherwise)')
+        if self._runner is None:
+            self._runner = _Runner()
+        run = self._runner
+        inputs = inputs.float()
+        rgb_mean = inputs.contiguous().view(inputs.size()[:2] + (-1,)).mean(dim=-1).view(inputs.size()[:2] + (1, 1, 1))
+        x = (inputs - rgb_mean) / self.rgb_max
+        x1, x2 = x[:, :, 0].contiguous(), x[:, :, 1].contiguous()
+        xcat = torch.cat((x1, x2), dim=1)
+        img0, img1, x6 = _to_buf(x1), _to_buf(x2), _to_buf(xcat)
+
+        def warp_pack(flow):
+            """[x, resample(img1, flow), flow/div_flow, |img0 - warped|] as a 12-channel NHWC buffer (flownet2.py:78-86)."""
+            warped = resample2d(x2, flow)
+            norm = channelnorm(x1 - warped)
+            return _to_buf(torch.cat([xcat, warped, flow / self.div_flow, norm], dim=1))
+
+        c_flow2 = self.flownetc.run(run, img0, img1).nchw(0, 2)
+        c_flow = _upsample4(c_flow2, True, self.div_flow)
+        s1_flow2 = self.flownets_1.run(run, warp_pack(c_flow)).nchw(0, 2)
+        s1_flow = _upsample4(s1_flow2, True, self.div_flow)
+        s2_flow2 = self.flownets_2.run(run, warp_pack(s1_flow)).nchw(0, 2)
+        s2_flow = _upsample4(s2_flow2, False, self.div_flow)
+        norm_s2 = channelnorm(s2_flow)
+        diff_s2 = channelnorm(x1 - resample2d(x2, s2_flow))
+        sd_flow2 = self.flownets_d.run(run, x6).nchw(0, 2)
+        sd_flow = _upsample4(sd_flow2, False, 1.0 / self.div_flow)
+        norm_sd = channelnorm(sd_flow)
+        diff_sd = channelnorm(x1 - resample2d(x2, sd_flow))
+        concat3 = torch.cat((x1, sd_flow, s2_flow, norm_sd, norm_s2, diff_sd, diff_s2), dim=1)
+        return self.flownetfusion.run(run, _to_buf(concat3)).nchw(0, 2)
