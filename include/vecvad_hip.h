@@ -242,10 +242,13 @@ typedef struct vv_conv2d_params {
   const float* w;
   const float* bias;
   float slope;
-  int32_t pad0;
+  int32_t pad0;       /* ksplit: > 1 splits the input-channel loop over that many workgroups; `out` must then be a
+                         workspace [ksplit][B*OH*OW][CoutP] (cstride = CoutP, coff = 0) finished by vv_conv2d_splitk_finish */
   vv_view out;
 } vv_conv2d_params;
 int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream);
+int vv_conv2d_splitk_finish(const float* ws, int32_t ksplit, int64_t M, int32_t Cout, int32_t CoutP, const float* bias,
+                            float slope, float* out, int32_t out_cstride, int32_t out_coff, vv_stream stream);
 /* w: Conv2d [N][K][R][R] (transposed = 0) or ConvTranspose2d [K][N][4][4] (transposed = 1); taps = R*R */
 int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32_t KP, int32_t N, int32_t NP,
                    int32_t transposed, vv_stream stream);

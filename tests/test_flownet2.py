@@ -62,6 +62,7 @@ def test_conv2d_hip_vs_torch_cpu(kind, R, stride, Cin, Cout, H, W, relu):
         ref = F.conv_transpose2d(x, m.weight, m.bias, stride=2, padding=1)
     if relu:
         ref = F.leaky_relu(ref, 0.1)
+    ref = ref.detach()
     layer = nn.Sequential(m, nn.LeakyReLU(0.1)) if relu else m
     layer = layer.cuda()
     src = _to_buf(x.cuda())
@@ -99,5 +100,9 @@ def test_flownet2_hip_vs_oracle_and_golden():
     err = float((out - ref).abs().max())
     assert err <= 1e-3 * scale, (err, scale)
     np.testing.assert_allclose(out.numpy()[0, :, ::16, ::16], g['out_samples'], rtol=5e-3, atol=1e-3 * scale)
+    out_g = net.forward_graphed(inp.cuda()).cpu()          # hipGraph replay gives the same bits
+    assert torch.equal(out_g, out)
+    out_g2 = net.forward_graphed(inp.cuda()).cpu()
+    assert torch.equal(out_g2, out)
     with pytest.raises(Exception):
         net(inp)            # CPU tensor: no fallback

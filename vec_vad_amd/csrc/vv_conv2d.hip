@@ -31,6 +31,8 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
 
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
+  const int KS = p.pad0 > 1 ? p.pad0 : 1;        // split-K over input-channel chunks (tiny-M, huge-K layers)
+  const int ks = w % KS; w /= KS;
   const int tx = w % tilesX; w /= tilesX;
   const int ty = w % tilesY; w /= tilesY;
   const int nn = w % NN; w /= NN;
@@ -70,8 +72,10 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  for (int c0 = 0; c0 < CinP; c0 += CK) {
-    if (c0) __syncthreads();
+  const int nchunk = CinP / CK;
+  const int cbeg = (nchunk * ks / KS) * CK, cend = (nchunk * (ks + 1) / KS) * CK;
+  for (int c0 = cbeg; c0 < cend; c0 += CK) {
+    if (c0 != cbeg) __syncthreads();
     vv_stage_tile<1, HH, HW, S, CK>(lds, s, img, oy0, ox0, c0, tid, p.src.cstride);
     __syncthreads();
 #pragma unroll 1
@@ -117,6 +121,25 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
   const int OH = DECONV ? 2 * H : (H + 2 * pad - R) / STRIDE + 1;
   const int OW = DECONV ? 2 * W : (W + 2 * pad - R) / STRIDE + 1;
   const int LH = DECONV ? H : OH, LW = DECONV ? W : OW;      // extent of the tile coordinate space
+  if (KS > 1) {
+    // raw partial sums -> workspace [ks][B*OH*OW][CoutP]; vv_conv2d_splitk_finish adds them up (+ bias, activation)
+    float* ws = p.out.ptr + (int64_t)ks * p.B * OH * OW * CoutP;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+        const int pp = wave * 64 + m * 32 + row;
+        const int r = ty0 + pp / TW, c = tx0 + pp % TW;
+        if (r < LH && c < LW) {
+          const int oy = DECONV ? 2 * r + py : r, ox = DECONV ? 2 * c + px : c;
+          float* o = ws + ((int64_t)(img * OH + oy) * OW + ox) * CoutP + co0 + l31;
+#pragma unroll
+          for (int n = 0; n < NR; ++n) o[n * 32] = acc[m][n][i];
+        }
+      }
+    return;
+  }
   float* __restrict__ outg = p.out.ptr + p.out.coff;
   const int ocs = p.out.cstride;
   const float slope = p.slope;
@@ -147,6 +170,19 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
           }
       }
     }
+}
+
+__global__ void __launch_bounds__(VV_WG)
+splitk_finish_kernel(const float* __restrict__ ws, const int KS, const int64_t M, const int Cout, const int CoutP,
+                     const float* __restrict__ bias, const float slope, float* __restrict__ out, const int ocs) {
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= M * Cout) return;
+  const int co = (int)(e % Cout);
+  const int64_t pix = e / Cout;
+  float v = bias ? bias[co] : 0.f;
+  for (int k = 0; k < KS; ++k) v += ws[((int64_t)k * M + pix) * CoutP + co];      // fixed order: deterministic
+  v = v > 0.f ? v : v * slope;
+  out[pix * ocs + co] = v;
 }
 
 __global__ void __launch_bounds__(VV_WG)
@@ -203,7 +239,7 @@ int launch2d(const vv_conv2d_params* p, hipStream_t st) {
   const int tilesY = (LH + 7) / 8, tilesX = (LW + 31) / 32;
   const bool wide = p->CoutP % 64 == 0 && p->Cout > 32;
   const int NN = p->CoutP / (wide ? 64 : 32);
-  const int total = p->B * (DECONV ? 4 : 1) * NN * tilesY * tilesX;
+  const int total = p->B * (DECONV ? 4 : 1) * NN * tilesY * tilesX * (p->pad0 > 1 ? p->pad0 : 1);
   const int nper = (total + 7) / 8;
   if (wide)
     VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 2, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
@@ -232,6 +268,17 @@ extern "C" int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream) {
     case 72: return launch2d<7, 2, 0, 8>(p, st);
   }
   return VV_ERR_UNSUPPORTED;
+}
+
+extern "C" int vv_conv2d_splitk_finish(const float* ws, int32_t ksplit, int64_t M, int32_t Cout, int32_t CoutP,
+                                       const float* bias, float slope, float* out, int32_t out_cstride, int32_t out_coff,
+                                       vv_stream stream) {
+  if (!ws || !out || ksplit < 1) return VV_ERR_BAD_ARG;
+  const int64_t n = M * Cout;
+  VV_LAUNCH(splitk_finish_kernel, dim3((unsigned)((n + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream, ws, ksplit, M,
+            Cout, CoutP, bias, slope, out + out_coff, out_cstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
 }
 
 extern "C" int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32_t KP, int32_t N, int32_t NP,
