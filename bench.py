@@ -43,6 +43,16 @@ def conv_flops(lay, B, G):
     return fl
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+    separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed."""
+    p = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        return json.load(open(p))['conv_mfma_family']['hbm_bytes_per_launch_corrected']
+    except Exception:
+        return None
+
+
 def cpu_baseline(batch=32, steps=3, thread_choices=(8, 16, 32, 64)):
     """Reference op sequence (torch CPU ops, NCHW fp32, per-op BN/ReLU/pool/cat, Adam eps=1e-7) on the host cores:
     BASELINE.json configs[0] (Net4, B=32).  This is the oracle restatement ("port"); it is test/bench
@@ -180,7 +190,7 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 implicit-GEMM, forward + data-gradient launches)',
                      'achieved': (conv_f / conv_t / 1e12) if conv_t > 0 else None, 'peak': FP32_MFMA_PEAK / 1e12,
                      'unit': 'TFLOP/s', 'frac': (conv_f / conv_t / FP32_MFMA_PEAK) if conv_t > 0 else None,
-                     'traffic': None, 'launches_timed': conv_n,
+                     'traffic': pmc_traffic(), 'launches_timed': conv_n,
                      'avg_launch_us': (1e6 * conv_t / conv_n) if conv_n else None,
                      'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None},
     }

@@ -32,8 +32,15 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr int S4 = S / 4;
   constexpr int MR = 2;                 // 2 x 32 pixels per wave
   constexpr int TN = NR * 32;
-  __shared__ float4 lds4[NI * HH * HW * S4];   // float4-typed so that the A reads are ds_read_b128
+  constexpr int KGC = CK / 8;           // 8-channel groups per chunk
+  constexpr int A4 = NI * HH * HW * S4; // float4 slots of the activation halo tile
+  constexpr int BROWS = 9 * KGC * 2;    // weight panel rows of one chunk: [tap][kg][half]
+  constexpr int B4 = BROWS * TN;
+  constexpr int NBT = (B4 + VV_WG - 1) / VV_WG;
+  __shared__ float4 lds4[A4 + B4];
   float* lds = reinterpret_cast<float*>(lds4);
+  const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
+  const v4f* ldsB = reinterpret_cast<const v4f*>(lds4) + A4;
 
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
@@ -78,82 +85,118 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
+  // ---- software pipeline over the K chunks: activation tile (BatchNorm+ReLU deferred to commit) and weight panel of
+  // chunk c+1 are in flight in registers while chunk c runs on the matrix cores; nothing but LDS is read in the MFMA loop.
+  VVStagerB<NI, HH, HW, S, CK> stA;
+  stA.init(s, ox0, tid);            // every tile spans full rows (TW == W): the column origin is tile independent
+  unsigned boff[NBT];
+  float4 rb[NBT];
+#pragma unroll
+  for (int k = 0; k < NBT; ++k) {
+    const int it = tid + k * VV_WG;
+    const int col = it % TN, row = it / TN;            // row = (tap*KGC + kg)*2 + half
+    const int hf = row & 1, tk = row >> 1;
+    const int kg = tk % KGC, tap = tk / KGC;
+    boff[k] = (B4 % VV_WG == 0 || it < B4) ? (unsigned)(((tap * KQ + kg) * 2 + hf) * Cout + co0 + col) * 16u : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
+  auto issue = [&](const int c0) {
+    stA.prefetch(s, img0, oy0, ox0, c0, tid);
+    const int so = (c0 >> 3) * 2 * Cout * 16;
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) {
+      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rsW, boff[k], so, 0);
+      rb[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  auto commit = [&]() {
+    stA.commit(lds, tid);
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) {
+      const int it = tid + k * VV_WG;
+      if (B4 % VV_WG == 0 || it < B4) lds4[A4 + it] = rb[k];
+    }
+  };
+
   // tap ranges
   const int nty = KIND == VV_CONVT_FWD ? (py ? 2 : 1) : 3;
   const int ntx = KIND == VV_CONVT_FWD ? (px ? 2 : 1) : 3;
 
+  issue(0);
   for (int c0 = 0; c0 < CinP; c0 += CK) {
-    if (c0) __syncthreads();
-    vv_stage_tile<NI, HH, HW, S, CK>(lds, s, img0, oy0, ox0, c0, tid);
+    if (c0) __syncthreads();            // every wave finished reading the previous chunk
+    commit();
     __syncthreads();
-
-    auto mma_tap = [&](const int aoff, const int wt) {
-#pragma unroll
-      for (int kg = 0; kg < CK / 8; ++kg) {
-        v4f a[MR];
-        float4 b[NR];
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          a[m] = reinterpret_cast<const v4f*>(lds4)[abase[m] + aoff + kg * 2];
-          asm volatile("" : "+v"(a[m]));      // keep the 16-byte LDS read whole (ds_read_b128, conflict-free layout)
-        }
-        const float* wp = wg + ((int64_t)((wt * KQ + (c0 >> 3) + kg) * 2 + half) * Cout + co0 + l31) * 4;
-#pragma unroll
-        for (int n = 0; n < NR; ++n) b[n] = *reinterpret_cast<const float4*>(wp + n * 128);
-#pragma unroll
-        for (int m = 0; m < MR; ++m)
-#pragma unroll
-          for (int n = 0; n < NR; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
-          }
-      }
-    };
+    if (c0 + CK < CinP) issue(c0 + CK);
 
     if constexpr (KIND == VV_CONVT_FWD) {
       // output parity phase (py,px): oy = 2*iy - 1 + ky  ->  py=0: ky=1 (iy=r) ; py=1: ky=2 (iy=r), ky=0 (iy=r+1)
       for (int ty = 0; ty < nty; ++ty)
         for (int tx = 0; tx < ntx; ++tx) {
           const int ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1;
-          mma_tap((ty * HW + tx) * S4, ky * 3 + kx);
+          const int aoff = (ty * HW + tx) * S4, wt = ky * 3 + kx;
+#pragma unroll
+          for (int kg = 0; kg < KGC; ++kg) {
+            v4f a[MR], b[NR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) { a[m] = ldsA[abase[m] + aoff + kg * 2]; asm volatile("" : "+v"(a[m])); }
+#pragma unroll
+            for (int n = 0; n < NR; ++n) { b[n] = ldsB[((wt * KGC + kg) * 2 + half) * TN + n * 32 + l31]; asm volatile("" : "+v"(b[n])); }
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+              for (int n = 0; n < NR; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+              }
+          }
         }
     } else {
-      // 9 taps x CK/8 channel groups, fully unrolled, with the weight panel of step it+PF already in flight while
-      // step it runs on the matrix cores (register ring, pinned with sched_barrier so the loads are not sunk back
-      // next to their use).
-      constexpr int KGC = CK / 8, NIT = 9 * KGC, PF = 2;
-      float4 bq[PF + 1][NR];
-      auto bload = [&](const int it, float4 (&dst)[NR]) {
+      // 9 taps x CK/8 channel groups, fully unrolled.  The A / B fragments of step it+1 are read from LDS while step it
+      // runs: one ds_read_b128 after each group of 4 MFMAs (pinned with sched_barrier), never a block of LDS issue
+      // slots in front of the matrix pipe and never a read that is waited on right after it was issued.
+      constexpr int NIT = 9 * KGC;
+      v4f fa[2][MR], fb[2][NR];
+      auto rdA = [&](const int it, const int m) -> v4f {
         const int tap = it / KGC, kg = it % KGC;
-        const float* wp = wg + ((int64_t)((tap * KQ + (c0 >> 3) + kg) * 2 + half) * Cout + co0 + l31) * 4;
-#pragma unroll
-        for (int n = 0; n < NR; ++n) dst[n] = *reinterpret_cast<const float4*>(wp + n * 128);
+        v4f v = ldsA[abase[m] + ((tap / 3) * HW + (tap % 3)) * S4 + kg * 2];
+        asm volatile("" : "+v"(v));
+        return v;
+      };
+      auto rdB = [&](const int it, const int n) -> v4f {
+        const int tap = it / KGC, kg = it % KGC;
+        v4f v = ldsB[((tap * KGC + kg) * 2 + half) * TN + n * 32 + l31];
+        asm volatile("" : "+v"(v));
+        return v;
       };
 #pragma unroll
-      for (int it = 0; it < PF; ++it) bload(it, bq[it]);
+      for (int m = 0; m < MR; ++m) fa[0][m] = rdA(0, m);
+#pragma unroll
+      for (int n = 0; n < NR; ++n) fb[0][n] = rdB(0, n);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        if (it + PF < NIT) bload(it + PF, bq[(it + PF) % (PF + 1)]);
-        __builtin_amdgcn_sched_barrier(0);
-        const int tap = it / KGC, kg = it % KGC;
-        const int aoff = ((tap / 3) * HW + (tap % 3)) * S4;
-        v4f a[MR];
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          a[m] = reinterpret_cast<const v4f*>(lds4)[abase[m] + aoff + kg * 2];
-          asm volatile("" : "+v"(a[m]));
-        }
-        const float4 (&b)[NR] = bq[it % (PF + 1)];
+        const int cur = it & 1, nxt = cur ^ 1;
+        int piece = 0;                       // pieces of the next step's fragments: A[0..MR), then B[0..NR)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][n], 0, 0, 0);
+            if (it + 1 < NIT) {
+              const int last = (m == MR - 1 && n == NR - 1);
+              // spread MR+NR reads over MR*NR MFMA groups (the last group takes whatever is left)
+              do {
+                if (piece < MR) fa[nxt][piece] = rdA(it + 1, piece);
+                else if (piece < MR + NR) fb[nxt][piece - MR] = rdB(it + 1, piece - MR);
+                ++piece;
+              } while (last && piece < MR + NR);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
       }
     }
@@ -249,7 +292,7 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
     case 32: return wide ? launch<8, 32, 1, 2, KIND, CK>(p, st) : launch<8, 32, 1, 1, KIND, CK>(p, st);
     case 16: return wide ? launch<16, 16, 1, 2, KIND, CK>(p, st) : launch<16, 16, 1, 1, KIND, CK>(p, st);
     case 8: return wide ? launch<8, 8, 4, 2, KIND, CK>(p, st) : launch<8, 8, 4, 1, KIND, CK>(p, st);
-    case 4: return wide ? launch<4, 4, 16, 2, KIND, CK>(p, st) : launch<4, 4, 16, 1, KIND, CK>(p, st);
+    case 4: return wide ? launch<4, 4, 16, 2, KIND, 8>(p, st) : launch<4, 4, 16, 1, KIND, 8>(p, st);   // 16 images x 6x6 halo: small chunks
   }
   return VV_ERR_UNSUPPORTED;
 }
