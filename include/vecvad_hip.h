@@ -204,6 +204,16 @@ int vv_adam(int64_t n, float* param, const float* grad, float* m, float* v, floa
 int vv_cube_gather(int32_t B, int32_t T, int32_t Tf, int32_t HW, const int64_t* idx, const uint8_t* raw,
                    const float* flow, float* x, float* xof, vv_stream stream);
 
+/* Small materialised inputs that keep the MFMA kernels on their fast (plain, pipelined) load path:
+ *  vv_pool_act  : out[g][b,y,x,c] = max_{2x2} relu(a*y+b)    nn.MaxPool2d(2) of the activated tensor (model/unet.py:38);
+ *                 1/4 of the source tensor, written once in the forward and reused by the weight-gradient.
+ *  vv_cube_erase: out[g][pixel][k] = cube[pixel][chmap[g][k]] (or 0): the frame-erased input of UNet g, Cin padded to CP
+ *                 (model/unet.py:178-183). */
+int vv_pool_act(int32_t G, int32_t B, int32_t H2, int32_t W2, int32_t C, const float* y, int64_t y_gstride, const float* a,
+                const float* b, int64_t ab_gstride, float* out, int64_t out_gstride, vv_stream stream);
+int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, const float* cube, const int32_t* chmap, float* out,
+                  int64_t out_gstride, vv_stream stream);
+
 /* NCHW <-> NHWC for the module surface (forward(x, x_of) takes NCHW like the reference) */
 int vv_nchw_to_nhwc(int32_t B, int32_t C, int32_t HW, const float* src, float* dst, vv_stream stream);
 /* gathers channels [0,oc) of out4[g] into NCHW dst[b][choff + ...] ; dst has Ctot channels */

@@ -93,6 +93,8 @@ _SIGS = {
     'vv_bias_grad': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'vv_adam': (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     'vv_cube_gather': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vv_pool_act': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'vv_cube_erase': (c_i32, [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'vv_nchw_to_nhwc': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'vv_out4_to_nchw': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     'vv_nchw_to_out4': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),

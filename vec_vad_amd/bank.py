@@ -255,6 +255,8 @@ class UNetBank:
         ws.flow = f(B, HWp, OF_C * self.tot_of)
         ws.y = [f(Ga, B * l.H * l.H, l.cout) for l in lay.convs]
         ws.t = [f(Ga, B * (2 * H) * (2 * H), co) for (_, H, ci, co) in lay.convT]
+        ws.pooled = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.mode == L.IN_POOL}
+        ws.erased = f(Ga, B * HWp, lay.convs[0].cinp)
         nt = [lib.vv_conv_ntiles(B, l.H, l.H) for l in lay.convs]
         ws.stats = f(Ga, max(n * 2 * l.cout for n, l in zip(nt, lay.convs)))
         ws.ab = torch.zeros(4, len(lay.convs), Ga, lay.cmax, device=d)
@@ -277,19 +279,21 @@ class UNetBank:
         return ws
 
     def _src_for(self, ws, l):
-        """(src0 view, a, b, src1 view, csplit, chmap) of conv layer l's input."""
+        """(load mode, src0 view, a, b, src1 view, csplit, chmap) of conv layer l's input."""
         lay, Ga = self.lay, self.Ga
         abg = lay.cmax
-        if l.mode == L.IN_CUBE:
-            return (L.view(ws.cube, ws.cube.shape[2], 0, 0), None, None, L.NULL_VIEW, 0,
-                    self._p(self.chmap, self.g0 * l.cinp))
-        if l.mode in (L.IN_ACT, L.IN_POOL):
+        if l.mode == L.IN_CUBE:       # frame-erased input, materialised once per step by vv_cube_erase
+            return (L.IN_PLAIN, L.view(ws.erased, l.cinp, 0, ws.erased.stride(0)), None, None, L.NULL_VIEW, 0, None)
+        if l.mode == L.IN_POOL:       # 2x2 max-pooled activation, materialised by vv_pool_act right after its BatchNorm
+            pb = ws.pooled[l.idx]
+            return (L.IN_PLAIN, L.view(pb, l.cin, 0, pb.stride(0)), None, None, L.NULL_VIEW, 0, None)
+        if l.mode == L.IN_ACT:
             s = lay.convs[l.src]
             y = ws.y[s.idx]
-            return (L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]), L.NULL_VIEW, 0, None)
+            return (L.IN_ACT, L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]), L.NULL_VIEW, 0, None)
         s = lay.convs[l.skip]
         y, t = ws.y[s.idx], ws.t[l.up]
-        return (L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]),
+        return (L.IN_CAT, L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]),
                 L.view(t, t.shape[2], 0, t.stride(0)), s.cout, None)
 
     def _plan_forward(self, ws, B, train):
@@ -301,9 +305,9 @@ class UNetBank:
         abg = lay.cmax
 
         def conv(l):
-            s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
+            mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             y = ws.y[l.idx]
-            cp = L.ConvParams(L.CONV3, l.mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, 0, chmap,
+            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, 0, chmap,
                               kbase + 4 * lay.pk['c%d.f' % l.idx][0], UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
@@ -326,9 +330,16 @@ class UNetBank:
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'convT%d' % u)
 
+        P.add(lib.vv_cube_erase, (Ga, B * HW0 * HW0, ws.cube.shape[2], lay.convs[0].cinp, ws.cube.data_ptr(),
+                                  self._p(self.chmap, g0 * lay.convs[0].cinp), ws.erased.data_ptr(), ws.erased.stride(0)), 'cube_erase')
         for l in lay.convs:
             if l.mode == L.IN_CAT:
                 convT(l.up)
+            if l.mode == L.IN_POOL:
+                s = lay.convs[l.src]
+                ys, pb = ws.y[s.idx], ws.pooled[l.idx]
+                P.add(lib.vv_pool_act, (Ga, B, l.H, l.H, s.cout, ys.data_ptr(), ys.stride(0), self._p(ws.ab[0, s.idx]),
+                                        self._p(ws.ab[1, s.idx]), abg, pb.data_ptr(), pb.stride(0)), 'pool%d' % l.idx)
             conv(l)
         last = lay.convs[-1]
         y = ws.y[last.idx]
@@ -427,9 +438,9 @@ class UNetBank:
                                         gbase + 4 * lay.p['c%d.g' % i][0], gbase + 4 * lay.p['c%d.beta' % i][0], U,
                                         ws.dz.data_ptr(), ws.dz.stride(0), ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i)
             # weight gradient
-            s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
+            mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             ks, nslab = wplan['c%d' % i]
-            wp = L.WgradParams(L.CONV3, l.mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit, 0, chmap,
+            wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit, 0, chmap,
                                L.View(ws.dz.data_ptr(), ws.dz.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i)

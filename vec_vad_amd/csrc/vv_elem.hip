@@ -497,6 +497,52 @@ nchw_to_out4_kernel(const int B, const int HW, const int oc, const float* __rest
   *reinterpret_cast<float4*>(out4 + e * 4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
 }
 
+// pooled activation: out[g][b, y, x, c] = max over the 2x2 window of relu(a*y+b)   (MaxPool2d(2) o ReLU o BatchNorm)
+__global__ void __launch_bounds__(VV_WG)
+pool_act_kernel(const int64_t n4, const int C, const int H2, const int W2, const float* __restrict__ y, const int64_t y_gstride,
+                const float* __restrict__ a, const float* __restrict__ b, const int64_t ab_gstride, float* __restrict__ out,
+                const int64_t out_gstride) {
+  const int g = blockIdx.y;
+  const int Q4 = C >> 2;
+  const float* yg = y + (int64_t)g * y_gstride;
+  float* og = out + (int64_t)g * out_gstride;
+  for (int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x; e < n4; e += (int64_t)gridDim.x * VV_WG) {
+    const int c = (int)(e % Q4) * 4;
+    const int64_t pix = e / Q4;                        // pooled pixel index (b, y2, x2)
+    const int x2 = (int)(pix % W2);
+    const int64_t t = pix / W2;
+    const int y2 = (int)(t % H2);
+    const int64_t img = t / H2;
+    const int W = 2 * W2;
+    const float* q = yg + (((img * 2 * H2 + 2 * y2) * W + 2 * x2) * (int64_t)C + c);
+    const float4 a4 = *reinterpret_cast<const float4*>(a + (int64_t)g * ab_gstride + c);
+    const float4 b4 = *reinterpret_cast<const float4*>(b + (int64_t)g * ab_gstride + c);
+    const float4 v00 = vv_act4(*reinterpret_cast<const float4*>(q), a4, b4);
+    const float4 v01 = vv_act4(*reinterpret_cast<const float4*>(q + C), a4, b4);
+    const float4 v10 = vv_act4(*reinterpret_cast<const float4*>(q + (int64_t)W * C), a4, b4);
+    const float4 v11 = vv_act4(*reinterpret_cast<const float4*>(q + (int64_t)(W + 1) * C), a4, b4);
+    *reinterpret_cast<float4*>(og + e * 4) = vv_max4(vv_max4(v00, v01), vv_max4(v10, v11));
+  }
+}
+
+// frame erasure: out[g][pixel][k] = chmap[g][k] >= 0 ? cube[pixel][chmap[g][k]] : 0   (model/unet.py:178-183)
+__global__ void __launch_bounds__(VV_WG)
+cube_erase_kernel(const int64_t npix, const int Cc, const int CP, const float* __restrict__ cube, const int* __restrict__ chmap,
+                  float* __restrict__ out, const int64_t out_gstride) {
+  const int g = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= npix) return;
+  const float* q = cube + e * Cc;
+  float* o = out + (int64_t)g * out_gstride + e * CP;
+  const int* m = chmap + (int64_t)g * CP;
+  for (int k = 0; k < CP; k += 4) {
+    float4 v;
+    const int m0 = m[k], m1 = m[k + 1], m2 = m[k + 2], m3 = m[k + 3];
+    v.x = m0 >= 0 ? q[m0] : 0.f; v.y = m1 >= 0 ? q[m1] : 0.f; v.z = m2 >= 0 ? q[m2] : 0.f; v.w = m3 >= 0 ? q[m3] : 0.f;
+    *reinterpret_cast<float4*>(o + k) = v;
+  }
+}
+
 inline int nblocks(int64_t n, int cap = 1 << 20) {
   int64_t b = (n + VV_WG - 1) / VV_WG;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -650,6 +696,26 @@ extern "C" int vv_nchw_to_out4(int32_t B, int32_t HW, int32_t oc, const float* s
   if (!out4 || !src || oc > 4) return VV_ERR_BAD_ARG;
   VV_LAUNCH(nchw_to_out4_kernel, dim3(nblocks((int64_t)B * HW)), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, oc,
                      src, Ctot, choff, out4);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_pool_act(int32_t G, int32_t B, int32_t H2, int32_t W2, int32_t C, const float* y, int64_t y_gstride,
+                           const float* a, const float* b, int64_t ab_gstride, float* out, int64_t out_gstride,
+                           vv_stream stream) {
+  if (!y || !a || !b || !out || C % 4) return VV_ERR_BAD_ARG;
+  const int64_t n4 = (int64_t)B * H2 * W2 * C / 4;
+  VV_LAUNCH(pool_act_kernel, dim3(nblocks(n4, 4096), G), dim3(VV_WG), 0, (hipStream_t)stream, n4, C, H2, W2, y, y_gstride, a,
+            b, ab_gstride, out, out_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, const float* cube, const int32_t* chmap,
+                             float* out, int64_t out_gstride, vv_stream stream) {
+  if (!cube || !chmap || !out || CP % 4) return VV_ERR_BAD_ARG;
+  VV_LAUNCH(cube_erase_kernel, dim3(nblocks(npix), G), dim3(VV_WG), 0, (hipStream_t)stream, npix, Cc, CP, cube, chmap, out,
+            out_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
