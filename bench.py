@@ -103,13 +103,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if os.environ.get('VV_SINGLE_DEVICE'):          # bring-up: all ranks share GPU 0 (gloo backend only)
+        local_rank_dev = 0
+    else:
+        local_rank_dev = local_rank
+    torch.cuda.set_device(local_rank_dev)
+    dev = torch.device('cuda', local_rank_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('VV_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' only for single-GPU bring-up tests
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from model.unet import SelfCompleteNet4, SelfCompleteNetFull
     from vec_vad_amd.trainer import FusedTrainer
