@@ -287,11 +287,16 @@ template <int KIND, int CK>
 int dispatch(const vv_conv_params* p, hipStream_t st) {
   TileGeo t;
   if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
-  const bool wide = (p->Cout % 64) == 0;
+  // 64-wide N tiles halve the activation re-staging but also halve the workgroup count; with 2 workgroups per CU
+  // (512 slots) a launch needs >= 2 full rounds of them, otherwise 32-wide tiles fill the machine better.
+  const int nt = ((p->B + t.NI - 1) / t.NI) * (p->H / t.TH) * (p->W / t.TW);
+  const int nph = KIND == VV_CONVT_FWD ? 4 : 1;
+  const bool wide = (p->Cout % 64) == 0 && (int64_t)p->G * nph * nt * (p->Cout / 64) >= 1024;
+  constexpr int CKD = KIND == VV_CONVT_DGRAD ? 8 : 16;
   switch (p->H) {
-    case 32: return wide ? launch<8, 32, 1, 2, KIND, CK>(p, st) : launch<8, 32, 1, 1, KIND, CK>(p, st);
-    case 16: return wide ? launch<16, 16, 1, 2, KIND, CK>(p, st) : launch<16, 16, 1, 1, KIND, CK>(p, st);
-    case 8: return wide ? launch<8, 8, 4, 2, KIND, CK>(p, st) : launch<8, 8, 4, 1, KIND, CK>(p, st);
+    case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD>(p, st) : launch<8, 32, 1, 1, KIND, CKD>(p, st);
+    case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD>(p, st) : launch<16, 16, 1, 1, KIND, CKD>(p, st);
+    case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD>(p, st) : launch<8, 8, 4, 1, KIND, CKD>(p, st);
     case 4: return wide ? launch<4, 4, 16, 2, KIND, 8>(p, st) : launch<4, 4, 16, 1, KIND, 8>(p, st);   // 16 images x 6x6 halo: small chunks
   }
   return VV_ERR_UNSUPPORTED;
