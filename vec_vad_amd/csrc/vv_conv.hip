@@ -24,7 +24,7 @@ struct Geo {
 };
 
 template <int TH, int TW, int NI, int NR, int KIND, int CK>
-__global__ void __launch_bounds__(VV_WG, 2)
+__global__ void __launch_bounds__(VV_WG, (NR == 1 ? 3 : 2))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
