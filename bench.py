@@ -96,6 +96,8 @@ def main():
     ap.add_argument('--model', default='net4', choices=['net4', 'full'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
+    ap.add_argument('--overlap', action='store_true', help='run the weight-gradient kernels on a side stream (about +4 %% cubes/s; '
+                    'per-kernel timings then include the contention, so the default keeps one stream)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -126,7 +128,8 @@ def main():
     cls = SelfCompleteNet4 if args.model == 'net4' else SelfCompleteNetFull
     net = cls(features_root=32, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=None, useFlow=True,
               padding=False).to(dev)
-    trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None)
+    trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
+                           overlap=args.overlap)
     bank = trainer.bank
     B = args.batch
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
@@ -159,6 +162,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     trainer.event_hook = None
+    # a few extra (untimed) steps with the side stream disabled: the same launches without a concurrent weight-grad kernel
+    iso = []
+    if args.overlap:
+        trainer.event_hook = lambda label, a, b: iso.append((label, a, b))
+        trainer.event_labels = set(fl.keys())
+        trainer.overlap = False
+        for it in range(3):
+            trainer.step_cubes(raw, flow, perm[it])
+        torch.cuda.synchronize()
+        trainer.overlap = True
+        trainer.event_hook = None
+    iso_t = sum(a.elapsed_time(b) * 1e-3 for _, a, b in iso)
+    iso_f = sum(fl[label] for label, _, _ in iso)
     l_raw, l_of = bank.losses(ws)
     loss_now = (float(l_raw), float(l_of) if l_of is not None else 0.0)
 
@@ -200,7 +216,9 @@ def main():
                      'unit': 'TFLOP/s', 'frac': (conv_f / conv_t / FP32_MFMA_PEAK) if conv_t > 0 else None,
                      'traffic': pmc_traffic(), 'launches_timed': conv_n,
                      'avg_launch_us': (1e6 * conv_t / conv_n) if conv_n else None,
-                     'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None},
+                     'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None,
+                     'side_stream_weight_grad': bool(args.overlap),
+                     'isolated_frac': (iso_f / iso_t / FP32_MFMA_PEAK) if iso_t > 0 else None},
     }
     if not args.no_cpu_baseline and world == 1:
         try:

@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
     net.load_state_dict(O.seeded_state_dict('net4', nf=32, padding=False, seed=0))
     net = net.cuda().train()
     raw, flow = O.seeded_cubes(8, 1, 21)
-    tr = FusedTrainer(net, process_group=dist.group.WORLD)
+    tr = FusedTrainer(net, process_group=dist.group.WORLD, overlap=True)      # exercises the side stream + bucket ordering
     idx = shard_batch(torch.arange(8, device='cuda'), rank, world)
     for _ in range(2):
         tr.step_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), idx)

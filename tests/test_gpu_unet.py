@@ -168,6 +168,23 @@ def test_batch_independence_and_determinism_large():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_side_stream_weight_grad_is_bitwise_identical():
+    """overlap=True (weight gradients on a side stream, double-buffered dy) must not change a single bit."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    raw, flow = O.seeded_cubes(40, 1, 9)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    outs = []
+    for overlap in (False, True):
+        net, _, _ = _build('net4', False)
+        net.train()
+        tr = FusedTrainer(net, overlap=overlap)
+        for s in range(3):
+            tr.step_cubes(rawd, flowd, torch.arange(40, device='cuda'))
+        outs.append(tr.bank.params.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_odd_batch_sizes_train():
     """ragged batches (last partial batch is kept, train.py:373 drop_last=False): B = 1, 2, 7, 17."""
     from oracle import unet_oracle as O

@@ -78,7 +78,8 @@ def read_config(path='config.cfg'):
              w_raw=cp.getfloat(method, 'w_raw'), w_of=cp.getfloat(method, 'w_of'), nf=cp.getint(method, 'nf'),
              shuffle_seed=cp.getint('mi355x', 'shuffle_seed', fallback=0),
              score_batch=cp.getint('mi355x', 'score_batch', fallback=512),
-             save_score_masks=cp.getboolean('mi355x', 'save_score_masks', fallback=True))
+             save_score_masks=cp.getboolean('mi355x', 'save_score_masks', fallback=True),
+             overlap_wgrad=cp.getboolean('mi355x', 'overlap_wgrad', fallback=False))
     assert c['modality'] == 'raw2flow'
     return c
 
@@ -110,7 +111,7 @@ def _dist():
 
 
 def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0, shuffle_seed=0, device='cuda',
-                log=print, tag='(0, 0)', dist=None):
+                log=print, tag='(0, 0)', dist=None, overlap=False):
     """The loop of train.py:375-427 for one (h, w) block.
 
     ``segments``: list of callables returning (raw uint8 [N,5,32,32,3], flow fp32 [N,(Tf,)32,32,2]) -- one entry for
@@ -120,7 +121,7 @@ def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0
     net = net.to(device)
     net.train()
     trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, lambda_raw=lambda_raw, lambda_of=lambda_of,
-                           process_group=dist.group.WORLD if dist is not None else None)
+                           process_group=dist.group.WORLD if dist is not None else None, overlap=overlap)
     raw_losses, of_losses = AverageMeter(device), AverageMeter(device)
     rng = np.random.default_rng(shuffle_seed) if shuffle_seed is not None and shuffle_seed >= 0 else None
     stores = [None] * len(segments)
@@ -248,7 +249,7 @@ def main(config_path='config.cfg'):
             data2 = np.asarray(fset2[h][w])
             segments = [lambda data=data, data2=data2: (data, data2)]
         sd, r, o = train_block(net, segments, c['epochs'], c['batch_size'], c['lambda_raw'], c['lambda_of'],
-                               c['shuffle_seed'], device, tag='({}, {})'.format(h, w), dist=dist)
+                               c['shuffle_seed'], device, tag='({}, {})'.format(h, w), dist=dist, overlap=c['overlap_wgrad'])
         tgt = (model_set[s][h][w], raw_scores_set[s][h], of_scores_set[s][h]) if shanghai else \
               (model_set[h][w], raw_scores_set[h], of_scores_set[h])
         tgt[0].append({k: v.cpu() for k, v in sd.items()})

@@ -136,11 +136,13 @@ def conv_key_to_state_name(stems, key):
 
 class _Plan:
     def __init__(self):
-        self.calls = []     # (fn, args tuple without stream, label)
+        self.calls = []     # (fn, args tuple without stream, label) in a valid single-stream order
+        self.meta = []      # per call: (stream id 0|1, events to wait for, event to record) for the two-stream executor
         self.keep = []      # ctypes objects that must stay alive
 
-    def add(self, fn, args, label):
+    def add(self, fn, args, label, stream=0, wait=(), record=None):
         self.calls.append((fn, args, label))
+        self.meta.append((stream, tuple(wait), record))
 
     def run(self, stream):
         for fn, args, label in self.calls:
@@ -368,7 +370,8 @@ class UNetBank:
         ws.gA_last = f(Ga, B * HWp, nf)
         ws.D = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.idx > 0}
         ws.DT = [f(Ga, B * H * H, ci) for (_, H, ci, co) in lay.convT]
-        ws.dz = f(Ga, B * HWp * nf)
+        ws.dz2 = [f(Ga, B * HWp * nf), f(Ga, B * HWp * nf)]   # dy of consecutive layers alternate (weight-grad runs on a side stream)
+        ws.dz = ws.dz2[0]
         nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
         ws.bnpart = f(Ga, max(n * 2 * l.cout for n, l in zip(nblk, lay.convs)))
         ws.bnscr = f(Ga, 2 * lay.cmax)
@@ -423,37 +426,44 @@ class UNetBank:
             dn = ws.D[m.idx]
             return L.view(dn, m.cin, 0, dn.stride(0)), None, 0
 
+        order = [l.idx for l in reversed(lay.convs)]            # backward visiting order: 13, 12, ..., 0
+
         def conv_bwd(l):
             i = l.idx
             y = ws.y[i]
+            pos = order.index(i)
+            dzb = ws.dz2[pos % 2]
+            # the layer visited two steps earlier used the same dy buffer: its weight-grad (side stream) must be done
+            reuse_wait = ('wdone%d' % order[pos - 2],) if pos >= 2 else ()
             dA, dpool, dpg = dA_for(l)
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout, y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
-                               self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, ws.dz.data_ptr(), ws.dz.stride(0),
+                               self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
-            P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i)
+            P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i, wait=reuse_wait)
             nb = lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout)
             P.add(lib.vv_bn_bwd_apply, (Ga, B * l.H * l.H, l.cout, nb, ws.bnpart.data_ptr(), y.data_ptr(), y.stride(0),
                                         pbase + 4 * lay.p['c%d.g' % i][0], U, self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg,
                                         gbase + 4 * lay.p['c%d.g' % i][0], gbase + 4 * lay.p['c%d.beta' % i][0], U,
-                                        ws.dz.data_ptr(), ws.dz.stride(0), ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i)
-            # weight gradient
+                                        dzb.data_ptr(), dzb.stride(0), ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
+                  record='dy%d' % i)
+            # weight gradient (side stream: only depends on dy_i and forward products)
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             ks, nslab = wplan['c%d' % i]
             wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit, 0, chmap,
-                               L.View(ws.dz.data_ptr(), ws.dz.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
+                               L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
-            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i)
+            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,), record='wdone%d' % i)
             P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks, ws.wpart.data_ptr(), wpg,
-                                        gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i)
+                                        gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i, stream=1)
             # data gradient
             if i > 0:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
-                                  L.View(ws.dz.data_ptr(), ws.dz.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, 0, None,
+                                  L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, 0, None,
                                   kbase + 4 * lay.pk['c%d.d' % i][0], UP, None, 0, L.view(Dl, l.cin, 0, Dl.stride(0)), None)
                 P.keep.append(cp)
-                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i)
+                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i)
 
         def convT_bwd(u, m):
             """m: the CAT conv layer that consumed convT u; its data gradient holds d(convT out) in channels [skipC, cin)."""
@@ -462,16 +472,17 @@ class UNetBank:
             skipc = lay.convs[m.skip].cout
             dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
             P.add(lib.vv_bias_grad, (Ga, B * (2 * H) * (2 * H), co, dcat.data_ptr(), dcat.stride(0), m.cin, skipc,
-                                     ws.bscr.data_ptr(), gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u)
+                                     ws.bscr.data_ptr(), gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u, stream=1,
+                  wait=('D%d' % m.idx,))
             y = ws.y[sidx]
             ks, nslab = wplan['t%d' % u]
             wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
                                self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, 0, None, dy,
                                ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
-            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u)
+            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1)
             P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks, ws.wpart.data_ptr(), wpg,
-                                        gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u)
+                                        gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
             DT = ws.DT[u]
             cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, 0, None,
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)

@@ -73,7 +73,7 @@ class FusedTrainer:
     """forward(train) -> backward -> [bucketed RCCL all-reduce] -> Adam, all asynchronous on the current stream."""
 
     def __init__(self, net, lr=1e-3, eps=1e-7, betas=(0.9, 0.999), lambda_raw=1.0, lambda_of=1.0, process_group=None,
-                 reset_optimizer=True):
+                 reset_optimizer=True, overlap=False):
         net.set_loss_weights(lambda_raw, lambda_of)
         self.net = net
         self.bank = net.bank()
@@ -94,6 +94,11 @@ class FusedTrainer:
             self.split_label = 'dgradT0'      # last launch of the decoder half of the backward plan
         self.event_hook = None
         self.event_labels = None
+        # overlap=True: weight gradients (MFMA-bound, one workgroup per CU) run on a side stream under the BatchNorm-backward
+        # passes (HBM-bound) and the data gradients of the following layers; measured +4 % cubes/s at B=256.  Off by default
+        # so that per-kernel timings (bench roofline, rocprof) are not contended.
+        self.overlap = overlap
+        self.side = torch.cuda.Stream(device=self.bank.device) if overlap else None
 
     # ---- plan execution with optional per-launch HIP events and a mid-plan callback
     def _run(self, plan, stream, after=None):
@@ -112,6 +117,36 @@ class FusedTrainer:
             if after is not None and label == after[0]:
                 after[1]()
 
+    def _run_dual(self, plan, after=None):
+        """Two-stream executor of a plan: meta = (stream id, events to wait for, event to record)."""
+        dev = self.bank.device
+        main = torch.cuda.current_stream(dev)
+        streams = (main, self.side)
+        self.side.wait_stream(main)
+        events = {}
+        hook, labels = self.event_hook, self.event_labels
+        for (fn, args, label), (sid, waits, rec) in zip(plan.calls, plan.meta):
+            st = streams[sid]
+            for w in waits:
+                st.wait_event(events[w])
+            timed = hook is not None and (labels is None or label in labels)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+            rc = fn(*args, st.cuda_stream)
+            if rc:
+                L.check(rc, label)
+            if timed:
+                e1.record(st)
+                hook(label, e0, e1)
+            if rec is not None:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events[rec] = ev
+            if after is not None and label == after[0]:
+                after[1](events)
+        main.wait_stream(self.side)
+
     def _step(self, ws):
         bank = self.bank
         stream = bank._stream()
@@ -119,7 +154,17 @@ class FusedTrainer:
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
         if ws.bwd is None:
             ws.bwd = bank._plan_backward(ws, ws.B)
-        if self.buckets is None:
+        if self.overlap:
+            if self.buckets is None:
+                self._run_dual(ws.bwd)
+            else:
+                def dec(events):     # decoder bucket: needs the side stream's decoder weight-grads too
+                    torch.cuda.current_stream(bank.device).wait_event(events['sideT0'])
+                    self.buckets.launch(1)
+                self._run_dual(ws.bwd, after=('wgradT_reduce0', dec))
+                self.buckets.launch(0)
+                self.buckets.finish()
+        elif self.buckets is None:
             self._run(ws.bwd, stream)
         else:
             self._run(ws.bwd, stream, after=(self.split_label, lambda: self.buckets.launch(1)))
