@@ -142,7 +142,7 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
                    float* a, float* b, float* mean, float* invstd, int64_t ab_gstride, vv_stream stream);
 
 /* BatchNorm + ReLU (+ MaxPool, + skip fan-in) backward, phase 1:
- * dz = (dA0 [+ route(dPool)]) * [a*y+b > 0]; writes dz and per-block partial sums of dz and dz*xhat. */
+ * dz = (dA0 [+ route(dPool)]) * [a*y+b > 0]; writes per-block partial sums of dz and dz*xhat (not dz). */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
   const float* y; int64_t y_gstride;             /* pre-BN conv output [B,H,W,C] */
@@ -154,13 +154,10 @@ typedef struct vv_bnbwd_params {
 } vv_bnbwd_params;
 int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream);
 int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C);
-/* phase 2: sums the partials (fixed order), writes dgamma/dbeta, then dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
- * in place over dz. */
-int vv_bn_bwd_apply(int32_t G, int64_t M, int32_t C, int32_t nblk, const float* partial,
-                    const float* y, int64_t y_gstride, const float* gamma, int64_t param_gstride,
-                    const float* mean, const float* invstd, int64_t ab_gstride,
-                    float* dgamma, float* dbeta, int64_t grad_gstride,
-                    float* dz, int64_t dz_gstride, float* scratch /* [G][2][C] */, vv_stream stream);
+/* phase 2: sums the partials (fixed order, fp64), writes dgamma/dbeta, then re-reads dA and y and writes
+ * dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) into p->dz (dz itself is never materialised). */
+int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int64_t param_gstride, float* dgamma, float* dbeta,
+                    int64_t grad_gstride, float* scratch /* [G][2][C] */, vv_stream stream);
 
 /* ---- output 1x1 conv + squared error (model/unet.py:63-70 ; train.py:385-392,421-426 ; test.py:330-335) ----
  * out[p][co] = bias[co] + sum_c relu(a*y+b)[p][c] * W[co][c];  score[g][cube] = sum (out - target)^2;

@@ -156,8 +156,9 @@ def main():
             l = int(label[len('bn_bwd_apply'):])
             L_ = lay.convs[l]
             M = B * L_.H * L_.H
+            pos = len(lay.convs) - 1 - l          # backward visiting order 13, 12, ...; dy buffers alternate
             for g in range(bank.G):
-                dz = ws.dz[g][:M * L_.cout].view(M, L_.cout)
+                dz = ws.dz2[pos % 2][g][:M * L_.cout].view(M, L_.cout)
                 d, r = err(dz, nhwc(cpu_inter[g][0][l].grad))
                 if r > 2e-4:
                     print('  BWD g%d dy%d abs %.3e rel %.3e' % (g, l, d, r))

@@ -83,8 +83,7 @@ _SIGS = {
                                c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'vv_bn_bwd_reduce': (c_i32, [C.POINTER(BnBwdParams), c_vp]),
     'vv_bn_bwd_nblk': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
-    'vv_bn_bwd_apply': (c_i32, [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64,
-                                c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'vv_bn_bwd_apply': (c_i32, [C.POINTER(BnBwdParams), c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'vv_outconv_fwd': (c_i32, [C.POINTER(OutconvParams), c_vp]),
     'vv_outconv_bwd': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
                                c_vp, c_i64, c_vp, c_vp]),

@@ -441,11 +441,8 @@ class UNetBank:
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
             P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i, wait=reuse_wait)
-            nb = lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout)
-            P.add(lib.vv_bn_bwd_apply, (Ga, B * l.H * l.H, l.cout, nb, ws.bnpart.data_ptr(), y.data_ptr(), y.stride(0),
-                                        pbase + 4 * lay.p['c%d.g' % i][0], U, self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg,
-                                        gbase + 4 * lay.p['c%d.g' % i][0], gbase + 4 * lay.p['c%d.beta' % i][0], U,
-                                        dzb.data_ptr(), dzb.stride(0), ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
+            P.add(lib.vv_bn_bwd_apply, (C.byref(bp), pbase + 4 * lay.p['c%d.g' % i][0], U, gbase + 4 * lay.p['c%d.g' % i][0],
+                                        gbase + 4 * lay.p['c%d.beta' % i][0], U, ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
                   record='dy%d' % i)
             # weight gradient (side stream: only depends on dy_i and forward products)
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)

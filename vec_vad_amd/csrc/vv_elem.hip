@@ -93,10 +93,15 @@ bn_finalize_kernel(const int C, const int ntiles, const double count, const int 
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
-// phase 1: dz = (dA [+ maxpool-routed dPool]) * [z > 0], partial sums of dz and dz * xhat per block of 256 pixels.
-template <bool POOL>
+// dz = (dA [+ maxpool-routed dPool]) * [z > 0]; pass 0 = partial sums of dz and dz*xhat per block of 256 pixels,
+// pass 1 = dy.
+// PASS 0: only the per-block partial sums of dz and dz*xhat (dz is NOT written);
+// PASS 1: recompute dz the same way and write dy = gamma*invstd*(dz - c1 - xhat*c2) -- one HBM pass less than
+//         materialising dz first and rewriting it.
+template <bool POOL, int PASS>
 __global__ void __launch_bounds__(VV_WG)
-bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk) {
+bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __restrict__ gamma, const int64_t param_gstride,
+                     const float* __restrict__ scratch) {
   __shared__ float sh[2][VV_WG * 4];
   const int g = blockIdx.y, blk = blockIdx.x;
   const int C = p.C, Q4 = C >> 2, PL = VV_WG / Q4;
@@ -111,16 +116,28 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk) {
   const float4 a4 = *reinterpret_cast<const float4*>(p.a + abo), b4 = *reinterpret_cast<const float4*>(p.b + abo);
   const float4 m4 = *reinterpret_cast<const float4*>(p.mean + abo), i4 = *reinterpret_cast<const float4*>(p.invstd + abo);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  float4 gk = make_float4(0, 0, 0, 0), c1 = gk, c2 = gk;
+  if constexpr (PASS == 1) {
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + (int64_t)g * param_gstride + c);
+    gk = make_float4(gm.x * i4.x, gm.y * i4.y, gm.z * i4.z, gm.w * i4.w);
+    c1 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + c);
+    c2 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + C + c);
+  }
 
   auto one = [&](const int64_t pix, float4 d) {
     const float4 yv = *reinterpret_cast<const float4*>(y + pix * C + c);
     float4 z;
     z.x = fmaf(a4.x, yv.x, b4.x); z.y = fmaf(a4.y, yv.y, b4.y); z.z = fmaf(a4.z, yv.z, b4.z); z.w = fmaf(a4.w, yv.w, b4.w);
     d.x = z.x > 0.f ? d.x : 0.f; d.y = z.y > 0.f ? d.y : 0.f; d.z = z.z > 0.f ? d.z : 0.f; d.w = z.w > 0.f ? d.w : 0.f;
-    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
-    s2.x = fmaf(d.x, (yv.x - m4.x) * i4.x, s2.x); s2.y = fmaf(d.y, (yv.y - m4.y) * i4.y, s2.y);
-    s2.z = fmaf(d.z, (yv.z - m4.z) * i4.z, s2.z); s2.w = fmaf(d.w, (yv.w - m4.w) * i4.w, s2.w);
-    *reinterpret_cast<float4*>(dz + pix * C + c) = d;
+    const float4 xh = make_float4((yv.x - m4.x) * i4.x, (yv.y - m4.y) * i4.y, (yv.z - m4.z) * i4.z, (yv.w - m4.w) * i4.w);
+    if constexpr (PASS == 0) {
+      s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+      s2.x = fmaf(d.x, xh.x, s2.x); s2.y = fmaf(d.y, xh.y, s2.y); s2.z = fmaf(d.z, xh.z, s2.z); s2.w = fmaf(d.w, xh.w, s2.w);
+    } else {
+      d.x = gk.x * (d.x - c1.x - xh.x * c2.x); d.y = gk.y * (d.y - c1.y - xh.y * c2.y);
+      d.z = gk.z * (d.z - c1.z - xh.z * c2.z); d.w = gk.w * (d.w - c1.w - xh.w * c2.w);
+      *reinterpret_cast<float4*>(dz + pix * C + c) = d;
+    }
   };
 
   if constexpr (!POOL) {
@@ -167,6 +184,7 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk) {
       }
     }
   }
+  if constexpr (PASS == 1) return;
   // block reduction over the PL pixel lanes in fixed order
   float* r1 = sh[0];
   float* r2 = sh[1];
@@ -210,33 +228,6 @@ bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __re
   dgamma[(int64_t)g * grad_gstride + c] = (float)s2;
   scratch[(int64_t)g * 2 * C + c] = (float)(s1 / M);
   scratch[(int64_t)g * 2 * C + C + c] = (float)(s2 / M);
-}
-
-// phase 2b: dy = gamma*invstd*(dz - c1 - xhat*c2), in place
-__global__ void __launch_bounds__(VV_WG)
-bn_bwd_apply_kernel(const int64_t n4, const int C, const float* __restrict__ y, const int64_t y_gstride,
-                    const float* __restrict__ gamma, const int64_t param_gstride, const float* __restrict__ mean,
-                    const float* __restrict__ invstd, const int64_t ab_gstride, const float* __restrict__ scratch,
-                    float* __restrict__ dz, const int64_t dz_gstride) {
-  const int g = blockIdx.y;
-  const int Q4 = C >> 2;
-  const float* yg = y + (int64_t)g * y_gstride;
-  float* dg = dz + (int64_t)g * dz_gstride;
-  for (int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x; e < n4; e += (int64_t)gridDim.x * VV_WG) {
-    const int c = (int)(e % Q4) * 4;
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + (int64_t)g * param_gstride + c);
-    const float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)g * ab_gstride + c);
-    const float4 is = *reinterpret_cast<const float4*>(invstd + (int64_t)g * ab_gstride + c);
-    const float4 c1 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + c);
-    const float4 c2 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + C + c);
-    const float4 yv = *reinterpret_cast<const float4*>(yg + e * 4);
-    float4 d = *reinterpret_cast<const float4*>(dg + e * 4);
-    d.x = gm.x * is.x * (d.x - c1.x - (yv.x - mu.x) * is.x * c2.x);
-    d.y = gm.y * is.y * (d.y - c1.y - (yv.y - mu.y) * is.y * c2.y);
-    d.z = gm.z * is.z * (d.z - c1.z - (yv.z - mu.z) * is.z * c2.z);
-    d.w = gm.w * is.w * (d.w - c1.w - (yv.w - mu.w) * is.w * c2.w);
-    *reinterpret_cast<float4*>(dg + e * 4) = d;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ output conv
@@ -586,25 +577,25 @@ extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
   if (p->C % 4 || p->C > 256 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
   const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   if (p->dpool)
-    VV_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
   else
-    VV_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk);
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
 
-extern "C" int vv_bn_bwd_apply(int32_t G, int64_t M, int32_t C, int32_t nblk, const float* partial, const float* y,
-                               int64_t y_gstride, const float* gamma, int64_t param_gstride, const float* mean,
-                               const float* invstd, int64_t ab_gstride, float* dgamma, float* dbeta,
-                               int64_t grad_gstride, float* dz, int64_t dz_gstride, float* scratch,
-                               vv_stream stream) {
-  if (!partial || !y || !gamma || !mean || !invstd || !dgamma || !dbeta || !dz || !scratch) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(bn_bwd_sum_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, (double)M,
-                     partial, dgamma, dbeta, grad_gstride, scratch);
+extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int64_t param_gstride, float* dgamma,
+                               float* dbeta, int64_t grad_gstride, float* scratch, vv_stream stream) {
+  if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial || !gamma || !dgamma || !dbeta || !scratch) return VV_ERR_BAD_ARG;
+  const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  const int64_t M = (int64_t)p->B * p->H * p->W;
+  VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(VV_WG), 0, (hipStream_t)stream, p->C, nblk, (double)M,
+            p->partial, dgamma, dbeta, grad_gstride, scratch);
   VV_CHECK_LAUNCH();
-  const int64_t n4 = M * C / 4;
-  VV_LAUNCH(bn_bwd_apply_kernel, dim3(nblocks(n4, 8192), G), dim3(VV_WG), 0, (hipStream_t)stream, n4, C, y,
-                     y_gstride, gamma, param_gstride, mean, invstd, ab_gstride, scratch, dz, dz_gstride);
+  if (p->dpool)
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, gamma, param_gstride, scratch);
+  else
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, gamma, param_gstride, scratch);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
