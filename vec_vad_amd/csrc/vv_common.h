@@ -152,68 +152,10 @@ __device__ __forceinline__ void vv_stage_tile(float* lds, const VVSrc& s, int im
   }
 }
 
-// Register-staged, software-pipelined tile loader: prefetch() issues every global load of the tile into registers
-// (they stay in flight under the caller's MFMA phase), commit() applies the deferred BatchNorm+ReLU and writes LDS.
-// A thread always handles the same channel quad (VV_WG % Q == 0), so its scale/shift are loaded once per chunk.
-template <int NI, int HH, int HW, int S, int NCH>
-struct VVStager {
-  static constexpr int Q = NCH / 4;
-  static constexpr int NITEMS = NI * HH * HW * Q;
-  static constexpr int NIT = (NITEMS + VV_WG - 1) / VV_WG;
-  static_assert(VV_WG % Q == 0 && NIT <= 32, "stager geometry");
-  float4 r[NIT];
-  float4 sa, sb;
-  unsigned valid;
-  bool act;
-
-  __device__ __forceinline__ void prefetch(const VVSrc& s, int img0, int y0, int x0, int c0, int tid, int cmax = 1 << 30) {
-    const int q = tid % Q;
-    const int c = c0 + q * 4;
-    valid = 0;
-    act = (s.mode == VV_IN_ACT) || (s.mode == VV_IN_CAT && c < s.csplit);
-    if (act && c < cmax) {
-      sa = *reinterpret_cast<const float4*>(s.a + c);
-      sb = *reinterpret_cast<const float4*>(s.b + c);
-    }
-    const bool immediate = (s.mode == VV_IN_POOL) || (s.mode == VV_IN_CUBE);
-    const bool second = (s.mode == VV_IN_CAT) && c >= s.csplit;
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int it = tid + k * VV_WG;
-      const int hp = it / Q;
-      const int hx = hp % HW;
-      const int t = hp / HW;
-      const int hy = t % HH;
-      const int im = t / HH;
-      const int img = img0 + im, y = y0 + hy, x = x0 + hx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((NITEMS % VV_WG == 0 || it < NITEMS) && img < s.B && (unsigned)y < (unsigned)s.SH && (unsigned)x < (unsigned)s.SW && c < cmax) {
-        valid |= 1u << k;
-        if (immediate) v = vv_fetch4(s, img, y, x, c);
-        else if (second) v = *reinterpret_cast<const float4*>(s.p1 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs1 + s.co1 + (c - s.csplit));
-        else v = *reinterpret_cast<const float4*>(s.p0 + ((int64_t)(img * s.SH + y) * s.SW + x) * s.cs0 + s.co0 + c);
-      }
-      r[k] = v;
-    }
-  }
-
-  __device__ __forceinline__ void commit(float* lds, int tid) const {
-    const int q = tid % Q;
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int it = tid + k * VV_WG;
-      if (NITEMS % VV_WG == 0 || it < NITEMS) {
-        float4 v = r[k];
-        if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
-        *reinterpret_cast<float4*>(lds + (it / Q) * S + q * 4) = v;
-      }
-    }
-  }
-};
-
 // ---------------------------------------------------------------------------------------------------------------
-// VVStagerB: the same register pipeline with (a) per-item pixel offsets / halo rows computed ONCE per workgroup and
-// (b) raw buffer loads: 32-bit voffset + SGPR descriptor, and out-of-image items get an offset beyond num_records so
+// VVStagerB: register-staged, software-pipelined tile loader.  prefetch() issues every load of a tile into registers
+// (they stay in flight under the caller's MFMA phase), commit() applies the deferred BatchNorm+ReLU and writes LDS.
+// (a) per-item pixel offsets / halo rows are computed ONCE per workgroup and (b) loads are raw buffer loads: 32-bit voffset + SGPR descriptor, and out-of-image items get an offset beyond num_records so
 // the hardware bounds check returns 0.0f (the convolution's zero padding) without a branch.  Per item and tile the
 // address math is ~5 VALU instructions instead of ~30 (the staging code was issue-bound, not latency-bound).
 // VV_IN_POOL / VV_IN_CUBE items (4-tap max-pool, channel gather) keep the generic immediate path.
