@@ -144,3 +144,22 @@ def test_grad_buckets_gloo_world2():
     expect = torch.arange(60, dtype=torch.float32).view(6, 10) * 3
     assert np.array_equal(res[0][1], expect.numpy()) and np.array_equal(res[1][1], expect.numpy())
     assert res[0][2].tolist() == [0, 1, 2, 3] and res[1][2].tolist() == [4, 5, 6, 7]
+
+
+def test_context_range_matches_reference_golden():
+    """vad_datasets.context_range vs the real reference method on 459 synthetic video layouts (incl. the 30 layouts on
+    which the reference raises NotImplementedError); fixture made by tests/golden/make_context_range_golden.py."""
+    import json
+    import vad_datasets
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'context_range.json')))
+    assert len(cases) > 400
+    n_err = 0
+    for lens, mode, ctx, indice, expect in cases:
+        vid = [v for v, n in enumerate(lens) for _ in range(n)]
+        if expect == [-1]:
+            n_err += 1
+            with pytest.raises(NotImplementedError):
+                vad_datasets.context_range(indice, mode, ctx, len(vid), vid)
+        else:
+            assert vad_datasets.context_range(indice, mode, ctx, len(vid), vid) == expect, (lens, mode, ctx, indice)
+    assert n_err >= 10

@@ -115,9 +115,46 @@ class CubeStore:
         return self.n
 
 
-def get_foreground(img, bboxes, patch_size):
-    raise NotImplementedError('get_foreground (bbox crop + cv2.resize, reference vad_datasets.py:70-93) is outside the '
-                              'hot path built this round; extract cubes with the reference and set *_foreground_saved = True')
+def context_range(indice, border_mode, context_frame_num, tot_frame_num, frame_video_idx):
+    """Frame indices of the temporal context of frame ``indice`` (reference vad_datasets.py:277-356; the three dataset
+    classes hold identical copies).  'elastic' keeps a full centred window by shifting it, 'predict' takes the frames up
+    to and including ``indice``, anything else ('hard') clips a centred window; frames that would come from a
+    neighbouring video are dropped and the window is refilled by repeating its first / last frame.
+    Raises NotImplementedError where the reference does (video shorter than the window)."""
+    n, last = context_frame_num, tot_frame_num - 1
+    if border_mode == 'elastic':
+        # the reference moves ``indice`` itself, so the 'own video' below is the one of the shifted centre
+        indice = indice if n <= indice <= last - n else (n if indice < n else last - n)
+        start, end, need = indice - n, indice + n, 2 * n + 1
+    elif border_mode == 'predict':
+        start, end, need = max(indice - n, 0), indice, n + 1
+    else:
+        start, end, need = max(indice - n, 0), min(indice + n, last), 2 * n + 1
+    vids = list(frame_video_idx[start:end + 1])
+    pad = need - len(vids)
+    if pad > 0:
+        vids = [vids[0]] * pad + vids if start == 0 else vids + [vids[-1]] * pad
+    rel = [v - frame_video_idx[indice] for v in vids]
+    offset = sum(rel)                              # signed count of frames that belong to a neighbouring video
+    if rel[0] != 0 and rel[-1] != 0:
+        raise NotImplementedError('The video is too short or the context frame number is too large!')
+    if pad == 0 and offset == 0:
+        return list(range(start, end + 1))
+    if border_mode == 'elastic':
+        return list(range(start - offset, end - offset + 1))
+    if pad > 0 and offset != 0:
+        raise NotImplementedError('The video is too short or the context frame number is too large!')
+    if border_mode == 'predict':
+        idx = list(range(start - offset, end + 1))
+        return [idx[0]] * max(abs(offset), pad) + idx
+    if offset > 0:
+        idx = list(range(start, end - offset + 1))
+        return idx + [idx[-1]] * offset
+    if offset < 0:
+        idx = list(range(start - offset, end + 1))
+        return [idx[0]] * (-offset) + idx
+    idx = list(range(start, end + 1))
+    return [idx[0]] * pad + idx if start == 0 else idx + [idx[-1]] * pad
 
 
 def unified_dataset_interface(dataset_name, dir, mode='train', context_frame_num=0, border_mode='elastic',
