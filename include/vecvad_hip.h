@@ -264,6 +264,27 @@ int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32
 int vv_upsample4(const float* src, float* dst, int32_t BC, int32_t H, int32_t W, int32_t bilinear, float scale,
                  vv_stream stream);
 
+/* ---- cube extraction (vad_datasets.py:70-93 get_foreground, calc_optical_flow.py:46-59,82) ----
+ * One launch crops n boxes out of T decoded frames and resizes each crop with cv2.resize's default INTER_LINEAR
+ * arithmetic (uint8: 11-bit fixed point, bit-exact; float32: unfused fp32; exact 2x decimation -> 2x2 area mean;
+ * equal size -> copy).
+ *   frames [T][H][W][C] uint8 (is_f32 = 0) or float32 (is_f32 = 1)  -- the layout cv2.imread / np.load hand over
+ *   crops  int32 [n][4] = x_min, y_min, x_max, y_max with 0 <= min < max <= W|H  (ceil + slice clipping done by the host)
+ *   out    [n][T][oh][ow][C], same dtype  (= the [N,T,32,32,C] cube layout of the *_foreground_*.npy files)        */
+int vv_crop_resize(const void* frames, int32_t is_f32, int32_t T, int32_t H, int32_t W, int32_t C, const int32_t* crops,
+                   int32_t n, int32_t oh, int32_t ow, void* out, vv_stream stream);
+
+/* ---- score aggregation (test.py:330-358,387-399, utils.py:29-41) ----
+ * vv_frame_scores: frame_scores[f] = max(frame_scores[f], max over cubes m in [frame_off[f], frame_off[f+1]) with
+ *   paints[m] != 0 of  cube_stat[m] < 0 ? big : w_raw*(raw[m]-mu_r)/sd_r + w_of*(of[m]-mu_o)/sd_o ), float64;
+ *   stats = double [S][4] (mu_r, sd_r, mu_o, sd_o) indexed by cube_stat[m]; of == NULL drops the flow term (useFlow=False).
+ *   The caller initialises frame_scores to -big (the mask background).
+ * vv_roc_auc_counts: out3[0] = 2*#{pos>neg} + #{pos==neg}, out3[1] = #pos, out3[2] = #neg; AUC = out3[0]/(2*P*N).     */
+int vv_frame_scores(const float* raw, const float* of, const int32_t* frame_off, const int32_t* cube_stat,
+                    const double* stats, const uint8_t* paints, double w_raw, double w_of, double big, int32_t n_frames,
+                    double* frame_scores, vv_stream stream);
+int vv_roc_auc_counts(const double* scores, const uint8_t* labels, int32_t n, uint64_t* out3, vv_stream stream);
+
 /* library self-description */
 const char* vv_version(void);
 /* text of the HIP error behind the last VV_ERR_LAUNCH returned on this thread ("" if none); never printed by the library */

@@ -9,8 +9,10 @@ scores into the bbox rectangles and max-combines them into the per-frame map ``r
 
 Differences on purpose: the reference runs one tiny batch per frame (1-30 cubes); eval-mode BatchNorm makes scores
 batch independent, so many frames are scored per launch (``[mi355x] score_batch``).  Ground-truth frame labels come from
-``<data_root>/<modality>/<ds>_frame_labels_test.npy`` (bool per frame) because reading the datasets' GT masks needs the
-out-of-scope cv2 frame indexers; without that file the evaluation step is skipped.
+``<data_root>/<modality>/<ds>_frame_labels_test.npy`` (bool per frame; write it once from
+``unified_dataset_interface(..., mode='test')`` targets, test.py:366-392); without that file the evaluation step is
+skipped.  Cube errors never leave HBM between the UNet bank and the frame score (``vv_frame_scores``); the h x w masks are
+only painted when ``[mi355x] save_score_masks`` asks for the reference's ``score_mask/<frame>`` files.
 """
 import os
 import sys
@@ -26,6 +28,7 @@ from train import read_config, build_network  # noqa: E402
 from utils import save_roc_pr_curve_data  # noqa: E402
 from vad_datasets import frame_size  # noqa: E402
 from vec_vad_amd.trainer import FusedTrainer  # noqa: E402
+from vec_vad_amd import scoring  # noqa: E402
 
 BIG = 100000
 
@@ -39,38 +42,45 @@ def load_model(net, state_dict, device):
     return net
 
 
-def score_cubes_batched(trainer, cube_list, flow_list, score_batch):
+def score_cubes_device(trainer, cube_list, flow_list, score_batch):
     """cube_list / flow_list: per-frame arrays [n_i,5,32,32,3] uint8 / [n_i,(Tf,)32,32,2] fp32 (n_i may be 0).
-    Returns per-frame (raw_scores [n_i], of_scores [n_i]) with as many frames per launch as fit in score_batch."""
+    Scores as many frames per launch as fit in ``score_batch`` and returns the DEVICE tensors (raw [n], of [n] | None) of
+    all cubes in frame order -- they feed vv_frame_scores without visiting the host."""
     dev = trainer.bank.device
-    out = [None] * len(cube_list)
+    rs, os_ = [], []
     i = 0
     while i < len(cube_list):
         j, tot = i, 0
         while j < len(cube_list) and (tot == 0 or tot + len(cube_list[j]) <= score_batch):
             tot += len(cube_list[j])
             j += 1
-        if tot == 0:
-            for k in range(i, j):
-                out[k] = (np.zeros(0, np.float32), np.zeros(0, np.float32))
-            i = j
-            continue
-        raw = np.concatenate([np.asarray(cube_list[k]) for k in range(i, j) if len(cube_list[k])])
-        flow = np.concatenate([np.asarray(flow_list[k], dtype=np.float32) for k in range(i, j) if len(cube_list[k])])
-        if raw.ndim == 4:
-            raw = raw[:, None]
-        if flow.ndim == 4:
-            flow = flow[:, None]
-        r, o = trainer.score_cubes(torch.from_numpy(np.ascontiguousarray(raw)).to(dev),
-                                   torch.from_numpy(np.ascontiguousarray(flow)).to(dev), None, raw.shape[0])
-        r = r.cpu().numpy()
-        o = o.cpu().numpy() if o is not None else None
-        p = 0
-        for k in range(i, j):
-            n = len(cube_list[k])
-            out[k] = (r[p:p + n], o[p:p + n] if o is not None else None)
-            p += n
+        if tot:
+            raw = np.concatenate([np.asarray(cube_list[k]) for k in range(i, j) if len(cube_list[k])])
+            flow = np.concatenate([np.asarray(flow_list[k], dtype=np.float32) for k in range(i, j) if len(cube_list[k])])
+            if raw.ndim == 4:
+                raw = raw[:, None]
+            if flow.ndim == 4:
+                flow = flow[:, None]
+            r, o = trainer.score_cubes(torch.from_numpy(np.ascontiguousarray(raw)).to(dev),
+                                       torch.from_numpy(np.ascontiguousarray(flow)).to(dev), None, raw.shape[0])
+            rs.append(r.clone())
+            os_.append(o.clone() if o is not None else None)
         i = j
+    if not rs:
+        return torch.zeros(0, device=dev), None
+    return torch.cat(rs), (torch.cat(os_) if os_[0] is not None else None)
+
+
+def score_cubes_batched(trainer, cube_list, flow_list, score_batch):
+    """Host view of ``score_cubes_device``: per-frame (raw_scores [n_i], of_scores [n_i] | None) numpy arrays."""
+    r, o = score_cubes_device(trainer, cube_list, flow_list, score_batch)
+    r = r.cpu().numpy()
+    o = o.cpu().numpy() if o is not None else None
+    out, p = [], 0
+    for c in cube_list:
+        n = len(c)
+        out.append((r[p:p + n], o[p:p + n] if o is not None else None))
+        p += n
     return out
 
 
@@ -87,51 +97,66 @@ def paint_frame(scores, bboxes, h, w):
 
 
 def score_frames(net_set, stats_raw, stats_of, foreground_set, foreground_set2, bbox_set, h, w, w_raw, w_of, useFlow,
-                 device, score_batch=512, scene_idx=None, result_dir=None, log=print):
-    """Per-frame anomaly maps / scores.  ``net_set[(s,)hh][ww]`` is a list with 0 or 1 eval-mode networks;
-    ``stats_*[(s,)hh][ww]`` = (mean, std) of the training scores.  Returns the list of frame scores (map maxima)."""
+                 device, score_batch=512, scene_idx=None, result_dir=None, log=print, return_device=False):
+    """Per-frame anomaly scores.  ``net_set[(s,)hh][ww]`` is a list with 0 or 1 eval-mode networks;
+    ``stats_*[(s,)hh][ww]`` = (mean, std) of the training scores.
+
+    The per-cube errors stay in HBM: ``vv_frame_scores`` z-normalises, weights and max-reduces them per frame
+    (= the maximum of the reference's painted h x w mask, test.py:350-357,391).  Only when ``result_dir`` is given are the
+    masks themselves painted (on the host) and saved as ``<result_dir>/<frame>`` like the reference does."""
     n_frames = len(foreground_set)
     frame_maps = [(-1.0 * np.ones((h, w)) * BIG) for _ in range(n_frames)] if result_dir else None
-    frame_scores = np.full(n_frames, -float(BIG))
+    fs_dev = torch.full((n_frames,), -float(BIG), dtype=torch.float64, device=device)
     hb, wb = len(foreground_set[0]), len(foreground_set[0][0])
     trainers = {}
+    keys = sorted(set(scene_idx[f] - 1 for f in range(n_frames))) if scene_idx is not None else [None]
     for hh in range(hb):
         for ww in range(wb):
-            # group frames by the model that scores them (one per scene for ShanghaiTech)
-            keys = sorted(set(scene_idx[f] - 1 for f in range(n_frames))) if scene_idx is not None else [None]
-            for key in keys:
+            for key in keys:      # frames are grouped by the model that scores them (one per scene for ShanghaiTech)
                 frames = [f for f in range(n_frames) if scene_idx is None or scene_idx[f] - 1 == key]
+                counts = np.zeros(n_frames, np.int64)
+                for f in frames:
+                    counts[f] = len(foreground_set[f][hh][ww])
+                if counts.sum() == 0:
+                    continue
+                frames = [f for f in frames if counts[f]]
                 models = net_set[key][hh][ww] if key is not None else net_set[hh][ww]
-                cubes = [foreground_set[f][hh][ww] for f in frames]
-                flows = [foreground_set2[f][hh][ww] for f in frames]
+                boxes = np.concatenate([np.asarray(bbox_set[f][hh][ww], dtype=np.float64)[:, :4] for f in frames])
+                off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+                n = int(off[-1])
                 if len(models) > 0:
                     net = models[0]
                     if id(net) not in trainers:
                         trainers[id(net)] = FusedTrainer(net)
                     st_r = stats_raw[key][hh][ww] if key is not None else stats_raw[hh][ww]
-                    st_o = (stats_of[key][hh][ww] if key is not None else stats_of[hh][ww]) if useFlow else None
-                    per = score_cubes_batched(trainers[id(net)], cubes, flows, score_batch)
-                for fi, f in enumerate(frames):
-                    n = len(cubes[fi])
-                    if n == 0:
-                        continue
-                    if len(models) > 0:
-                        r, o = per[fi]
-                        r = (r - st_r[0]) / st_r[1]
-                        sc = w_raw * r
-                        if useFlow:
-                            sc = sc + w_of * ((o - st_o[0]) / st_o[1])
-                    else:
-                        sc = np.ones(n) * BIG        # anomaly: no object in the training set in this block (test.py:346-348)
-                    m = paint_frame(sc, bbox_set[f][hh][ww], h, w)
-                    if frame_maps is not None:
-                        np.maximum(frame_maps[f], m, out=frame_maps[f])
-                    frame_scores[f] = max(frame_scores[f], m.max())
+                    st_o = (stats_of[key][hh][ww] if key is not None else stats_of[hh][ww]) if useFlow else (0.0, 1.0)
+                    r, o = score_cubes_device(trainers[id(net)], [foreground_set[f][hh][ww] for f in frames],
+                                              [foreground_set2[f][hh][ww] for f in frames], score_batch)
+                    o = o if useFlow else None
+                    stats = np.array([[st_r[0], st_r[1], st_o[0], st_o[1]]], np.float64)
+                    cube_stat = np.zeros(n, np.int32)
+                else:        # anomaly: no object in the training set in this block (test.py:346-348)
+                    r, o = torch.zeros(n, device=device), None
+                    stats = np.array([[0.0, 1.0, 0.0, 1.0]])
+                    cube_stat = np.full(n, -1, np.int32)
+                scoring.frame_scores(r, o, off, cube_stat, stats, scoring.box_paints(boxes, h, w), w_raw, w_of, out=fs_dev)
+                if frame_maps is not None:
+                    rh = r.cpu().numpy().astype(np.float32)
+                    oh = o.cpu().numpy().astype(np.float32) if o is not None else None
+                    for f in frames:
+                        sl = slice(off[f], off[f + 1])
+                        if len(models) > 0:
+                            sc = w_raw * ((rh[sl] - stats[0, 0]) / stats[0, 1])
+                            if oh is not None:
+                                sc = sc + w_of * ((oh[sl] - stats[0, 2]) / stats[0, 3])
+                        else:
+                            sc = np.ones(counts[f]) * BIG
+                        np.maximum(frame_maps[f], paint_frame(sc, boxes[sl], h, w), out=frame_maps[f])
     if result_dir:
         os.makedirs(result_dir, exist_ok=True)
         for f in range(n_frames):
             torch.save(frame_maps[f], os.path.join(result_dir, '{}'.format(f)))
-    return frame_scores
+    return fs_dev if return_device else fs_dev.cpu().numpy()
 
 
 def main(config_path='config.cfg'):
@@ -200,6 +225,9 @@ def main(config_path='config.cfg'):
         path = os.path.join(results_dir, ds, '{}_{}_{}_frame_results.npz'.format(mod, fg, method))
         print('Results written to {}:'.format(path))
         auc = save_roc_pr_curve_data(fs, labels, path)
+        # the same number from the device-side pair count (vv_roc_auc_counts); the .npz above keeps the reference's layout
+        auc_dev = scoring.roc_auc(torch.from_numpy(np.asarray(fs, np.float64)).to(device), labels)
+        print('AUC@ROC (device pair count) is {}'.format(auc_dev))
     return auc
 
 

@@ -72,3 +72,43 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch):
     auc = save_roc_pr_curve_data(fs, np.array(labels), str(tmp_path / 'roc.npz'), verbose=False)
     assert abs(auc - float(g['auc'])) <= 1e-3
     assert abs(frame_roc_auc(fs, np.array(labels)) - auc) < 1e-12
+
+
+@pytest.mark.gpu
+def test_calc_optical_flow_driver(tmp_path, monkeypatch):
+    """calc_optical_flow.py end to end on a synthetic UCSD-style tree: file layout, border pair selection, and
+    saved flow == resize_back(FlowNet2(resize(pair))) with both resizes checked against the cv2-arithmetic oracle."""
+    from PIL import Image
+    import calc_optical_flow as COF
+    from oracle import resize_oracle as R
+    from vad_datasets import unified_dataset_interface
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(0)
+    H, W = 48, 72
+    frames = {}
+    for v, n in (('Train001', 3), ('Train002', 2)):
+        os.makedirs(os.path.join('raw_datasets', 'UCSDped2', 'Train', v))
+        base = rng.integers(0, 256, (H, W + 8), dtype=np.uint8)
+        for k in range(n):
+            g = np.ascontiguousarray(base[:, k * 2:k * 2 + W])          # a pattern sliding 2 px per frame
+            frames[(v, k)] = g
+            Image.fromarray(g).save(os.path.join('raw_datasets', 'UCSDped2', 'Train', v, '%03d.tif' % (k + 1)))
+    ds = unified_dataset_interface('UCSDped2', os.path.join('raw_datasets', 'UCSDped2'), context_frame_num=1, mode='train',
+                                   border_mode='hard')
+    torch.manual_seed(0)
+    net = COF.FlowNet2().cuda().eval()
+    COF.calc_optical_flow(ds, flownet2=net, log=lambda *a: None)
+    order = [('Train001', 0), ('Train001', 1), ('Train001', 2), ('Train002', 0), ('Train002', 1)]
+    # (first, second) frame matched for each index: border frames use the first two of the clipped context
+    pairs = [(0, 0), (1, 2), (1, 2), (3, 3), (3, 4)]
+    for idx, (v, k) in enumerate(order):
+        path = os.path.join('optical_flow', 'UCSDped2', 'Train', v, '%03d.npy' % (k + 1))
+        got = np.load(path)
+        assert got.shape == (H, W, 2) and got.dtype == np.float32
+        a, b = (frames[order[j]] for j in pairs[idx])
+        im = [np.repeat(R.resize_linear(x, (512, 384))[:, :, None], 3, 2) for x in (a, b)]
+        ims = np.array([im]).transpose((0, 4, 1, 2, 3)).astype(np.float32)
+        flow = net(torch.from_numpy(ims).cuda())[0].cpu().numpy().transpose((1, 2, 0))
+        ref = R.resize_linear(np.ascontiguousarray(flow), (W, H))
+        assert np.array_equal(got, ref), idx
+    assert np.isfinite(got).all()

@@ -163,3 +163,64 @@ def test_context_range_matches_reference_golden():
         else:
             assert vad_datasets.context_range(indice, mode, ctx, len(vid), vid) == expect, (lens, mode, ctx, indice)
     assert n_err >= 10
+
+
+def test_frame_indexers_on_a_synthetic_tree(tmp_path):
+    """ped / avenue / shanghaiTech directory layouts (reference vad_datasets.py:203-275, 432-484, 645-715): frame order,
+    per-video indices, context stacks, ground truth -- on tiny lossless frames written here."""
+    from PIL import Image
+    import vad_datasets as V
+    rng = np.random.default_rng(0)
+
+    def put(path, arr):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        Image.fromarray(arr).save(path)
+
+    # ---- UCSDped2-like: Test001 (3 frames), Test001_gt, Test002 (2 frames), Test002_gt
+    root = str(tmp_path / 'UCSDped2')
+    frames = {}
+    for v, n in (('Test001', 3), ('Test002', 2)):
+        for k in range(n):
+            g = rng.integers(0, 256, (6, 8), dtype=np.uint8)
+            frames[(v, k)] = g
+            put(os.path.join(root, 'Test', v, '%03d.tif' % (k + 1)), g)
+            put(os.path.join(root, 'Test', v + '_gt', '%03d.bmp' % (k + 1)), (g > 128).astype(np.uint8) * 255)
+    ds = V.unified_dataset_interface('UCSDped2', root, mode='test', context_frame_num=1, border_mode='hard')
+    assert isinstance(ds, V.ped_dataset) and len(ds) == 5 and (ds.h, ds.w) == (240, 360)
+    assert ds.frame_video_idx == [1, 1, 1, 2, 2] and ds.return_gt and len(ds.all_gt_addr) == 5
+    img, gt = ds[3]                       # first frame of video 2: context [3,3,4] (video-1 frame dropped, first repeated)
+    assert ds.context_range(3) == [3, 3, 4]
+    assert img.shape == (3, 3, 6, 8) and img.dtype == torch.uint8
+    assert np.array_equal(img[0, 0].numpy(), frames[('Test002', 0)])          # gray replicated to 3 (BGR) channels
+    assert np.array_equal(img[0, 1].numpy(), frames[('Test002', 0)]) and np.array_equal(img[2, 2].numpy(), frames[('Test002', 1)])
+    assert np.array_equal(gt.numpy(), (frames[('Test002', 0)] > 128).astype(np.uint8) * 255)
+    ds0 = V.ped_dataset(dir=root, mode='test', context_frame_num=0)
+    assert ds0[1][0].shape == (3, 6, 8) and ds0.file_format == '.tif'
+
+    # ---- optical-flow tree of the same videos (.npy [h,w,2] float32), train split
+    root2 = str(tmp_path / 'optical_flow' / 'UCSDped2')
+    for k in range(4):
+        os.makedirs(os.path.join(root2, 'Train', 'Train001'), exist_ok=True)
+        np.save(os.path.join(root2, 'Train', 'Train001', '%03d.npy' % k), np.full((6, 8, 2), k, np.float32))
+    os.makedirs(os.path.join(root2, 'Train', 'notes'), exist_ok=True)          # ignored: no 'Train' in the name
+    dsf = V.unified_dataset_interface('UCSDped2', root2, mode='train', context_frame_num=2, border_mode='predict',
+                                      file_format='.npy')
+    assert len(dsf) == 4 and list(dsf.videos) == ['Train001']
+    x, z = dsf[0]
+    assert x.shape == (3, 2, 6, 8) and x.dtype == torch.float32 and z.shape == (1,)
+    assert x[:, 0, 0, 0].tolist() == [0, 0, 0] and dsf[3][0][:, 0, 0, 0].tolist() == [1, 2, 3]
+
+    # ---- ShanghaiTech-like test split (two parts, scene from the folder name, frame-level gt)
+    root3 = str(tmp_path / 'ShanghaiTech')
+    for part, v, n in ((1, '01_0014', 2), (2, '03_0031', 3)):
+        for k in range(n):
+            put(os.path.join(root3, 'Testing', 'frames_part%d' % part, v, '%03d.png' % k),
+                rng.integers(0, 256, (4, 4, 3), dtype=np.uint8))
+    os.makedirs(os.path.join(root3, 'Testing', 'test_frame_mask'))
+    np.save(os.path.join(root3, 'Testing', 'test_frame_mask', '01_0014.npy'), np.array([0, 1]))
+    np.save(os.path.join(root3, 'Testing', 'test_frame_mask', '03_0031.npy'), np.array([0, 0, 1]))
+    dss = V.unified_dataset_interface('ShanghaiTech', root3, mode='test', file_format='.png')
+    assert len(dss) == 5 and dss.save_scene_idx == [1, 1, 3, 3, 3] and dss.scene_idx == [1] * 5 and dss.scene_num == 1
+    assert [int(dss[i][1][0]) for i in range(5)] == [0, 1, 0, 0, 1]
+    with pytest.raises(NotImplementedError):
+        V.unified_dataset_interface('UCF', root3)

@@ -1,15 +1,23 @@
 """Data-layer surface of the reference's ``vad_datasets.py`` that the cube-completion hot path touches.
 
-In scope (kept name- and behaviour-compatible):
+Kept name- and behaviour-compatible:
   * ``cube_to_train_dataset``        reference vad_datasets.py:130-168 -- [T,H,W,C] cube -> ([T*C,H,W] input,
                                      [T_of*2,H,W] flow target, [T*C,H,W] copy); uint8 -> float/255, float32 untouched
   * ``frame_size``, ``img_tensor2numpy``, ``img_batch_tensor2numpy``, ``bbox_collate*``   (:16, :27-66)
-  * ``CubeStore``                    NEW: the same cubes kept resident on the GPU in their on-disk layout; batches are
+  * ``get_inputs`` / ``get_foreground`` (:18-25, :70-93) -- the crop + cv2.resize of every box and context frame is ONE
+                                     launch of the HIP kernel ``vv_crop_resize`` (vec_vad_amd/extract.py)
+  * ``ped_dataset / avenue_dataset / shanghaiTech_dataset / unified_dataset_interface`` (:95-836) -- the frame indexers;
+                                     one shared implementation (the reference carries three copies), ``context_range`` is
+                                     pinned by reference-generated goldens
+  * ``CubeStore``                    NEW: the cubes kept resident on the GPU in their on-disk layout; batches are
                                      gathered + converted by the HIP kernel vv_cube_gather (no per-sample python).
-Out of scope for this round: the video frame indexers ``ped_dataset / avenue_dataset /
-shanghaiTech_dataset`` and ``get_foreground`` (cv2 file IO + cv2.resize); ``unified_dataset_interface`` raises with
-that explanation.  The hot path is fed from the saved cube files (``*_foreground_saved = True`` in config.cfg).
+Image DECODING (cv2.imread in the reference) is outside the hot path: ``get_inputs`` uses cv2 when it is importable and
+Pillow otherwise (BGR channel order like cv2; JPEG decoders may differ by an LSB -- unpinned, there are no frames here).
 """
+import glob
+import os
+from collections import OrderedDict
+
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -157,7 +165,209 @@ def context_range(indice, border_mode, context_frame_num, tot_frame_num, frame_v
     return [idx[0]] * pad + idx if start == 0 else idx + [idx[-1]] * pad
 
 
+def get_inputs(file_addr):
+    """reference vad_datasets.py:18-25: ``.mat`` -> ['uv'], ``.npy`` -> array, anything else -> BGR uint8 image."""
+    file_format = file_addr.split('.')[-1]
+    if file_format == 'mat':
+        import scipy.io as sio
+        return sio.loadmat(file_addr, verify_compressed_data_integrity=False)['uv']
+    if file_format == 'npy':
+        return np.load(file_addr)
+    return _imread(file_addr, gray=False)
+
+
+def _imread(path, gray):
+    try:
+        import cv2
+        return cv2.imread(path, cv2.IMREAD_GRAYSCALE) if gray else cv2.imread(path)
+    except ImportError:
+        from PIL import Image
+        with Image.open(path) as im:
+            if gray:
+                return np.array(im.convert('L'))
+            return np.ascontiguousarray(np.array(im.convert('RGB'))[:, :, ::-1])
+
+
+def get_foreground(img, bboxes, patch_size):
+    """reference vad_datasets.py:70-93 (``[C,H,W]`` or ``[T,C,H,W]`` numpy in, ``[n,(T,)C,P,P]`` numpy out); all boxes and
+    frames go through one ``vv_crop_resize`` launch.  Raises without the HIP library / a GPU (no CPU fallback)."""
+    from vec_vad_amd.extract import get_foreground as _gf
+    return _gf(img, bboxes, patch_size)
+
+
+class _frame_dataset(Dataset):
+    """Frame indexer shared by the three dataset classes (the reference repeats it per dataset, vad_datasets.py:170-836):
+    ``__getitem__(i)`` -> (frame ``[C,H,W]`` | context stack ``[T,C,H,W]`` | foreground patches ``[n,(T,)C,P,P]``, gt)."""
+
+    def __init__(self, dir, mode='train', context_frame_num=0, border_mode='elastic', file_format=None, all_bboxes=None,
+                 patch_size=32):
+        if mode not in ('train', 'test'):
+            raise NotImplementedError
+        self.dir = dir
+        self.mode = mode
+        self.videos = OrderedDict()
+        self.all_frame_addr = list()
+        self.frame_video_idx = list()
+        self.tot_frame_num = 0
+        self.context_frame_num = context_frame_num
+        self.border_mode = border_mode
+        self.file_format = file_format if file_format is not None else self.default_format
+        self.all_bboxes = all_bboxes
+        self.patch_size = patch_size
+        self.return_gt = False
+        self.dataset_init()
+
+    # -- layout hooks -------------------------------------------------------------------------------------------
+    default_format = '.jpg'
+
+    def _video_dirs(self):
+        raise NotImplementedError
+
+    def _load_gt(self):
+        pass
+
+    def _gt(self, indice):
+        raise NotImplementedError
+
+    def _on_video(self, name, n_frames):
+        pass
+
+    # -- shared ---------------------------------------------------------------------------------------------------
+    def dataset_init(self):
+        for vid, video in enumerate(self._video_dirs(), start=1):
+            name = video.split('/')[-1]
+            frames = sorted(glob.glob(os.path.join(video, '*' + self.file_format)))
+            self.videos[name] = {'path': video, 'frame': frames, 'length': len(frames)}
+            self.frame_video_idx += [vid] * len(frames)
+            self.all_frame_addr += frames
+            self._on_video(name, len(frames))
+        self.tot_frame_num = len(self.all_frame_addr)
+        if self.mode == 'test':
+            self._load_gt()
+
+    def __len__(self):
+        return self.tot_frame_num
+
+    def context_range(self, indice):
+        return context_range(indice, self.border_mode, self.context_frame_num, self.tot_frame_num, self.frame_video_idx)
+
+    def frames(self, indice):
+        """Decoded frame ``[C,H,W]`` (no context) or context stack ``[T,C,H,W]`` of frame ``indice``."""
+        if self.context_frame_num == 0:
+            return np.transpose(get_inputs(self.all_frame_addr[indice]), [2, 0, 1])
+        return np.array([np.transpose(get_inputs(self.all_frame_addr[i]), [2, 0, 1])
+                         for i in self.context_range(indice)])
+
+    def __getitem__(self, indice):
+        img_batch = self.frames(indice)
+        if self.all_bboxes is not None:
+            img_batch = get_foreground(img=img_batch, bboxes=self.all_bboxes[indice], patch_size=self.patch_size)
+        img_batch = torch.from_numpy(np.ascontiguousarray(img_batch))
+        if self.mode == 'test' and self.return_gt:
+            return img_batch, torch.from_numpy(self._gt(indice))
+        return img_batch, torch.zeros(1)  # to unify the interface
+
+    def cubes_device(self, indice, device='cuda'):
+        """NEW: foreground cubes of frame ``indice`` as a device tensor ``[n,T,P,P,C]`` (CubeStore layout), without the
+        D2H / H2D round trip of ``__getitem__`` -> ``img_batch_tensor2numpy`` -> ``np.save``."""
+        from vec_vad_amd.extract import foreground_cubes
+        fr = self.frames(indice)
+        fr = fr[None] if fr.ndim == 3 else fr
+        fr = torch.from_numpy(np.ascontiguousarray(np.transpose(fr, [0, 2, 3, 1]))).to(device)
+        return foreground_cubes(fr, self.all_bboxes[indice], self.patch_size)
+
+
+class ped_dataset(_frame_dataset):
+    """UCSD ped1 / ped2 (reference vad_datasets.py:170-402): ``<dir>/Train/Train*/`` and ``<dir>/Test/Test*/`` frame
+    folders, pixel masks in ``Test*_gt/*.bmp``."""
+    default_format = '.tif'
+
+    def __init__(self, dir, **kw):
+        self.h, self.w = (158, 238) if dir[-1] == '1' else (240, 360)
+        self.all_gt_addr = list()
+        self.gts = OrderedDict()
+        super().__init__(dir, **kw)
+
+    def _video_dirs(self):
+        sub = 'Train' if self.mode == 'train' else 'Test'
+        dirs = sorted(glob.glob(os.path.join(self.dir, sub, '*')))
+        self._gt_dirs = [d for d in dirs if '_gt' in d] if self.mode == 'test' else []
+        return [d for d in dirs if '_gt' not in d and sub in d.split('/')[-1]]
+
+    def _load_gt(self):
+        self.return_gt = len(self._gt_dirs) > 0
+        for gt in self._gt_dirs:
+            frames = sorted(glob.glob(os.path.join(gt, '*.bmp')))
+            self.gts[gt.split('/')[-1]] = {'gt_frame': frames}
+            self.all_gt_addr += frames
+
+    def _gt(self, indice):
+        return _imread(self.all_gt_addr[indice], gray=True)
+
+
+class avenue_dataset(_frame_dataset):
+    """CUHK Avenue (reference vad_datasets.py:404-618): ``training|testing/frames/<video>/``, ground truth
+    ``ground_truth_demo/testing_label_mask/<k>_label.mat['volLabel']``."""
+
+    def _video_dirs(self):
+        sub = 'training' if self.mode == 'train' else 'testing'
+        return sorted(glob.glob(os.path.join(self.dir, sub, 'frames', '*')))
+
+    def _load_gt(self):
+        gt_dir = os.path.join(self.dir, 'ground_truth_demo', 'testing_label_mask')
+        self.return_gt = os.path.exists(gt_dir)
+        if self.return_gt:
+            import scipy.io as sio
+            gts = [sio.loadmat(os.path.join(gt_dir, str(x + 1) + '_label.mat'))['volLabel']
+                   for x in range(len(self.videos))]
+            self.all_gt = np.concatenate(gts, axis=1)
+
+    def _gt(self, indice):
+        return self.all_gt[0, indice]
+
+
+class shanghaiTech_dataset(_frame_dataset):
+    """ShanghaiTech (reference vad_datasets.py:620-836): ``training/videosFrame/<scene>_<clip>/`` and
+    ``Testing/frames_part{1,2}/<video>/``; frame-level ground truth ``Testing/test_frame_mask/*.npy``.  ``scene_idx`` is 1
+    for every frame (one model for all scenes, :669), ``save_scene_idx`` keeps the real scene of the folder name."""
+
+    def __init__(self, dir, **kw):
+        self.save_scene_idx = list()
+        self.scene_idx = list()
+        self.scene_num = 0
+        super().__init__(dir, **kw)
+        self.scene_num = len(set(self.scene_idx))
+
+    def _video_dirs(self):
+        if self.mode == 'train':
+            return sorted(glob.glob(os.path.join(self.dir, 'training', 'videosFrame', '*')))
+        base = os.path.join(self.dir, 'Testing', 'frames_part')
+        return [v for j in (1, 2) for v in sorted(glob.glob(os.path.join(base + str(j), '*')))]
+
+    def _on_video(self, name, n_frames):
+        self.save_scene_idx += [int(name[:2])] * n_frames
+        self.scene_idx += [1] * n_frames
+
+    def _load_gt(self):
+        gt_dir = os.path.join(self.dir, 'Testing', 'test_frame_mask')
+        self.return_gt = os.path.exists(gt_dir)
+        if self.return_gt:
+            self.all_gt = np.concatenate([np.load(g) for g in sorted(glob.glob(os.path.join(gt_dir, '*')))], axis=0)
+
+    def _gt(self, indice):
+        return np.array([self.all_gt[indice]])
+
+
 def unified_dataset_interface(dataset_name, dir, mode='train', context_frame_num=0, border_mode='elastic',
                               file_format=None, all_bboxes=None, patch_size=32):
-    raise NotImplementedError('the video frame indexers (reference vad_datasets.py:170-836, cv2 file IO) are out of scope '
-                              'for this round (SURVEY.md section 8 f-1); the hot path is fed from saved cube .npy files')
+    """reference vad_datasets.py:95-113."""
+    if file_format is None:
+        if dataset_name not in frame_size:
+            raise NotImplementedError
+        file_format = frame_size[dataset_name][2]
+    cls = {'UCSDped1': ped_dataset, 'UCSDped2': ped_dataset, 'avenue': avenue_dataset,
+           'ShanghaiTech': shanghaiTech_dataset}.get(dataset_name)
+    if cls is None:
+        raise NotImplementedError
+    return cls(dir=dir, context_frame_num=context_frame_num, mode=mode, border_mode=border_mode, all_bboxes=all_bboxes,
+               patch_size=patch_size, file_format=file_format)

@@ -103,6 +103,10 @@ _SIGS = {
                                          C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
     'vv_resample2d_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_channelnorm_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_crop_resize': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'vv_frame_scores': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_double, C.c_double, C.c_double, c_i32, c_vp,
+                                c_vp]),
+    'vv_roc_auc_counts': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     'vv_version': (C.c_char_p, []),
     'vv_last_hip_error': (C.c_char_p, []),
     'vv_set_last_hip_error': (None, [c_i32]),
