@@ -162,11 +162,11 @@ def score_frames(net_set, stats_raw, stats_of, foreground_set, foreground_set2, 
 def main(config_path='config.cfg'):
     c = read_config(config_path)
     cp, ds, fg, root, mod, method = c['cp'], c['dataset_name'], c['mode_fg'], c['data_root_dir'], c['modality'], c['method']
-    if not cp.getboolean(ds, 'test_foreground_saved'):
-        raise NotImplementedError('test_foreground_saved = False needs the cv2 / mmdet extraction stages of the reference '
-                                  '(test.py:44-180), outside the hot path built here; extract once with the reference.')
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(device)
+    if not cp.getboolean(ds, 'test_foreground_saved') and not cp.getboolean(ds, 'scores_saved'):   # test.py:98-176
+        from foreground import extract_test
+        extract_test(c, device)
     base = os.path.join(root, mod, ds + '_')
     h, w, _, _ = frame_size[ds]
     results_dir = 'results'

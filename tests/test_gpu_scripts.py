@@ -112,3 +112,136 @@ def test_calc_optical_flow_driver(tmp_path, monkeypatch):
         ref = R.resize_linear(np.ascontiguousarray(flow), (W, H))
         assert np.array_equal(got, ref), idx
     assert np.isfinite(got).all()
+
+
+def _synthetic_ped2_tree(rng, n_train=(4, 3), n_test=(4,)):
+    """raw_datasets/ + optical_flow/ + bbox files laid out like UCSDped2 (240x360 grey .tif frames, [h,w,2] flow .npy)."""
+    from PIL import Image
+    H, W = 240, 360
+    frames, flows, boxes = {}, {}, {}
+    for mode, sub, counts in (('train', 'Train', n_train), ('test', 'Test', n_test)):
+        all_boxes = []
+        for v, n in enumerate(counts, start=1):
+            name = '%s%03d' % (sub, v)
+            os.makedirs(os.path.join('raw_datasets', 'UCSDped2', sub, name))
+            os.makedirs(os.path.join('optical_flow', 'UCSDped2', sub, name))
+            if mode == 'test':
+                os.makedirs(os.path.join('raw_datasets', 'UCSDped2', sub, name + '_gt'))
+            for k in range(n):
+                g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+                fl = (rng.standard_normal((H, W, 2)) * 2).astype(np.float32)
+                fl[:60, :90] = 0                                   # a still corner: boxes there fail the motion test
+                frames.setdefault(mode, []).append(g)
+                flows.setdefault(mode, []).append(fl)
+                Image.fromarray(g).save(os.path.join('raw_datasets', 'UCSDped2', sub, name, '%03d.tif' % (k + 1)))
+                np.save(os.path.join('optical_flow', 'UCSDped2', sub, name, '%03d.npy' % (k + 1)), fl)
+                if mode == 'test':
+                    gt = np.zeros((H, W), np.uint8)
+                    if k % 2:
+                        gt[100:120, 100:130] = 255
+                    Image.fromarray(gt).save(os.path.join('raw_datasets', 'UCSDped2', sub, name + '_gt', '%03d.bmp' % (k + 1)))
+                nb = int(rng.integers(0, 4)) if k else 3
+                bb = []
+                for m in range(nb):
+                    x0, y0 = rng.uniform(95, W - 70), rng.uniform(65, H - 70)
+                    bb.append([x0, y0, x0 + rng.uniform(8, 64), y0 + rng.uniform(8, 64), rng.random()])
+                if k == 0:
+                    bb[0] = [5.0, 4.0, 40.0, 50.0, 0.9]            # inside the still corner -> dropped (energy 0)
+                    bb[1] = [200.0, 130.0, 264.0, 194.0, 0.9]      # 64x64 -> exact 2x area path
+                all_boxes.append(np.array(bb).reshape(-1, 5))
+        arr = np.empty(len(all_boxes), dtype=object)
+        for i, b in enumerate(all_boxes):
+            arr[i] = b
+        np.save(os.path.join('raw_datasets', 'UCSDped2', 'bboxes_%s_obj_det_with_motion.npy' % mode), arr, allow_pickle=True)
+        boxes[mode] = all_boxes
+    return frames, flows, boxes
+
+
+def test_extraction_stage_and_full_scripts(tmp_path, monkeypatch):
+    """foreground.extract_train / extract_test (train.py:102-226, test.py:98-176) against the oracle's get_foreground,
+    then ``train.main`` and ``test.main`` end to end from frames on disk to a frame-level AUC."""
+    import shutil
+    import foreground as FG
+    import train as T
+    import test as S
+    import vad_datasets as V
+    from oracle import resize_oracle as R
+    from utils import calc_block_idx
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(11)
+    frames, flows, boxes = _synthetic_ped2_tree(rng)
+    cfg = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config.cfg')).read()
+    cfg = cfg.replace('epochs = 10', 'epochs = 1').replace('batch_size = 128', 'batch_size = 4')
+    import re
+    cfg = re.sub(r'(\[UCSDped2\][^\[]*?)h_block=1\nw_block=1', r'\1h_block=2\nw_block=2', cfg)
+    cfg = re.sub(r'(\[UCSDped2\][^\[]*?)train_block_mode = 1', r'\1train_block_mode = 9', cfg)
+    open('config.cfg', 'w').write(cfg)
+    c = T.read_config('config.cfg')
+    assert c['h_block'] == 2 and c['cp'].getint('UCSDped2', 'train_block_mode') == 9 and c['batch_size'] == 4
+
+    def expected(mode, vid_lens, block_mode):
+        fvi = [v for v, n in enumerate(vid_lens) for _ in range(n)]
+        cells = {}
+        for idx in range(len(fvi)):
+            rng_raw = V.context_range(idx, 'predict', 4, len(fvi), fvi)
+            raw_stack = np.array([np.repeat(frames[mode][i][None], 3, 0) for i in rng_raw])         # [5,3,H,W]
+            fl = np.array([np.transpose(flows[mode][i], [2, 0, 1]) for i in rng_raw])                # [5,2,H,W]
+            bb = boxes[mode][idx]
+            if len(bb) == 0:
+                continue
+            pr = np.transpose(R.get_foreground(raw_stack, bb, 32), [0, 1, 3, 4, 2])                  # [n,5,32,32,3]
+            pf = np.transpose(R.get_foreground(fl, bb, 32), [0, 1, 3, 4, 2])                         # [n,5,32,32,2]
+            mag = (pf.astype(np.float64) ** 2).sum(axis=(2, 3, 4)).mean(axis=1)
+            for m in range(len(bb)):
+                if mag[m] > 0:
+                    for (hi, wi) in calc_block_idx(bb[m, 0], bb[m, 2], bb[m, 1], bb[m, 3], 120.0, 180.0, mode=block_mode):
+                        cells.setdefault((idx, hi, wi), []).append((pr[m], pf[m], bb[m]))
+        return cells
+
+    # ---- train extraction
+    FG.extract_train(c, 'cuda', log=lambda *a: None)
+    fr = np.load('data/raw2flow/UCSDped2_foreground_train_obj_det_with_motion-raw.npy', allow_pickle=True)
+    ff = np.load('data/raw2flow/UCSDped2_foreground_train_obj_det_with_motion-flow.npy', allow_pickle=True)
+    assert fr.shape == (2, 2) and ff.shape == (2, 2)
+    exp = expected('train', (4, 3), 9)
+    n_tot = 0
+    for hi in range(2):
+        for wi in range(2):
+            want = [e for (idx, h2, w2), lst in sorted(exp.items()) if (h2, w2) == (hi, wi) for e in lst]
+            n_tot += len(want)
+            assert len(fr[hi][wi]) == len(want) == len(ff[hi][wi])
+            if want:
+                assert fr[hi][wi].dtype == np.uint8 and fr[hi][wi].shape[1:] == (5, 32, 32, 3)
+                assert ff[hi][wi].dtype == np.float32 and ff[hi][wi].shape[1:] == (5, 32, 32, 2)
+                assert np.array_equal(fr[hi][wi], np.array([e[0] for e in want]))
+                assert np.array_equal(ff[hi][wi], np.array([e[1] for e in want]))
+    assert n_tot >= 8
+    # the two hand-placed boxes of frame 0: one dropped by the motion test, the other present
+    assert not any(np.array_equal(e[2][:4], [5.0, 4.0, 40.0, 50.0]) for lst in exp.values() for e in lst)
+
+    # ---- test extraction (block mode 1) incl. boxes and frame labels
+    FG.extract_test(c, 'cuda', log=lambda *a: None)
+    tr = np.load('data/raw2flow/UCSDped2_foreground_test_obj_det_with_motion-raw.npy', allow_pickle=True)
+    tf = np.load('data/raw2flow/UCSDped2_foreground_test_obj_det_with_motion-flow.npy', allow_pickle=True)
+    tb = np.load('data/raw2flow/UCSDped2_foreground_bbox_test_obj_det_with_motion.npy', allow_pickle=True)
+    assert tr.shape == (4, 2, 2) and tb.shape == (4, 2, 2)
+    exp = expected('test', (4,), 1)
+    for idx in range(4):
+        for hi in range(2):
+            for wi in range(2):
+                want = exp.get((idx, hi, wi), [])
+                assert len(tr[idx][hi][wi]) == len(want)
+                if want:
+                    assert np.array_equal(tr[idx][hi][wi], np.array([e[0] for e in want]))
+                    assert np.array_equal(tf[idx][hi][wi], np.array([e[1] for e in want]))
+                    assert np.array_equal(tb[idx][hi][wi], np.array([e[2] for e in want]))
+    assert np.load('data/raw2flow/UCSDped2_frame_labels_test.npy').tolist() == [False, True, False, True]
+
+    # ---- the scripts themselves, from frames on disk: extraction -> training -> scoring -> AUC
+    shutil.rmtree('data')
+    T.main('config.cfg')
+    assert os.path.exists('data/raw2flow/UCSDped2_model_obj_det_with_motion_SelfComplete.npy')
+    auc = S.main('config.cfg')
+    assert auc is not None and 0.0 <= auc <= 1.0
+    fs = np.load('results/UCSDped2/frame_scores_obj_det_with_motion_SelfComplete.npy')
+    assert fs.shape == (4,) and np.isfinite(fs).all()

@@ -14,8 +14,9 @@ What is different on purpose:
   * ``torchrun --nproc-per-node N train.py`` gives one process per GPU with RCCL gradient all-reduce instead of
     nn.DataParallel; plain ``python train.py`` stays valid (1 GPU);
   * the epoch permutation is seeded (``[mi355x] shuffle_seed``) -- the reference shuffles unseeded.
-Foreground localisation / cube extraction (train.py:44-226) are outside this round's scope: run with
-``train_bbox_saved = True`` and ``train_foreground_saved = True``.
+Cube extraction (train.py:102-226) runs through ``foreground.extract_train`` (crop + resize on the GPU) when
+``train_foreground_saved = False``; the detector stage that produces the boxes (train.py:44-95, mmdet) is outside the hot
+path -- keep ``train_bbox_saved = True``.
 """
 import os
 import sys
@@ -202,15 +203,15 @@ def _gather_var(dist, t, n, world):
 def main(config_path='config.cfg'):
     c = read_config(config_path)
     cp, ds, fg, root, mod, method = c['cp'], c['dataset_name'], c['mode_fg'], c['data_root_dir'], c['modality'], c['method']
-    if not cp.getboolean(ds, 'train_foreground_saved'):
-        raise NotImplementedError(
-            'train_foreground_saved = False needs the frame/bbox/cube extraction stages (reference train.py:44-226: mmdet '
-            'detector, cv2 frame IO, cv2.resize), which are outside the hot path built here. Extract the cubes once with '
-            'the reference (they land in %s/%s/%s_foreground_train_%s-raw.npy / -flow.npy) and set it to True.'
-            % (root, mod, ds, fg))
     dist, rank, world = _dist()
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(device)
+    if not cp.getboolean(ds, 'train_foreground_saved'):      # train.py:102-226, cubes cut on the GPU (vv_crop_resize)
+        if rank == 0:
+            from foreground import extract_train
+            extract_train(c, device)
+        if dist is not None:
+            dist.barrier()
     net = build_network(c)
     base = os.path.join(root, mod, ds + '_')
     shanghai = ds == 'ShanghaiTech'
