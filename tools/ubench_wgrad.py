@@ -35,7 +35,7 @@ def run(H, Cin, Cout, dbg, ks=None, reps=10):
     print('H=%2d Cin=%3d Cout=%3d ks=%3d dbg=%d : %7.1f us  %6.1f TF/s' % (H, Cin, Cout, ks, dbg, t * 1e6, fl / t / 1e12), flush=True)
 
 for (H, ci, co) in ((32, 32, 32), (16, 64, 64), (8, 256, 128)):
-    for dbg in (0, 1):        # 1 = skip staging (how much of the time is the MFMA loop + epilogue alone)
+    for dbg in (0, 1, 2):        # 1 = skip staging (how much of the time is the MFMA loop + epilogue alone)
         run(H, ci, co, dbg)
     for ks in (21, 42, 85, 170):
         if H == 32:

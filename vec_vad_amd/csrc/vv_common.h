@@ -2,12 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/vecvad_hip.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define VV_WG 256
+
+// compile-time counted loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void vv_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    vv_static_for<B + 1, E>(f);
+  }
+}
 
 // hipGetLastError() is sticky per thread: clear anything an earlier, unrelated runtime call left behind so that
 // VV_CHECK_LAUNCH reports only this launch.
@@ -225,6 +235,50 @@ struct VVStagerB {
       valid |= ok ? (1u << k) : 0u;
       const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
       r[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  }
+
+  // ---- piecewise interface: the same loads / LDS writes, one item per call with a compile-time item index, for
+  // callers that spread the staging of the NEXT tile over the MFMA loop of the current one (begin() once per tile, then
+  // load_piece<0..NIT-1>, later commit_piece<0..NIT-1>).  VV_IN_PLAIN / VV_IN_ACT / VV_IN_CAT sources only (the engine
+  // materialises pooled and frame-erased inputs, so these are the modes the kernels see).  live = false turns every item into an out-of-range load (zeros,
+  // no memory traffic): the tail of the pipeline stays branch-free.
+  const float* base_;
+  int cs_, c_, tile_, img0_, y0_;
+  bool cok_;
+  __device__ __forceinline__ void begin(const VVSrc& s, int img0, int y0, int x0, int c0, int tid, int cmax, bool live) {
+    const int q = tid % Q;
+    c_ = c0 + q * 4;
+    valid = 0;
+    act = (s.mode == VV_IN_ACT) || (s.mode == VV_IN_CAT && c_ < s.csplit);
+    if (act && c_ < cmax) {
+      sa = *reinterpret_cast<const float4*>(s.a + c_);
+      sb = *reinterpret_cast<const float4*>(s.b + c_);
+    }
+    const bool second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit)) != 0;
+    base_ = second ? s.p1 + s.co1 - s.csplit : s.p0 + s.co0;
+    cs_ = second ? s.cs1 : s.cs0;
+    tile_ = (img0 * s.SH + y0) * s.SW + x0;
+    img0_ = img0; y0_ = y0;
+    cok_ = live && c_ < cmax;
+  }
+  template <int K>
+  __device__ __forceinline__ void load_piece(const VVSrc& s, int x0, int tid) {
+    const int y = y0_ + hy[K];
+    const bool ok = cok_ && (unsigned)y < (unsigned)s.SH && (img0_ + im[K]) < s.B && pix[K] >= 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned off = ok ? (unsigned)((tile_ + pix[K]) * cs_ + c_) * 4u : OOB;
+    valid |= ok ? (1u << K) : 0u;
+    const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    r[K] = make_float4(v.x, v.y, v.z, v.w);
+  }
+  template <int K>
+  __device__ __forceinline__ void commit_piece(float* lds, int tid) const {
+    const int it = tid + K * VV_WG;
+    if (NITEMS % VV_WG == 0 || it < NITEMS) {
+      float4 v = r[K];
+      if (act && ((valid >> K) & 1u)) v = vv_act4(v, sa, sb);
+      *reinterpret_cast<float4*>(lds + (it / Q) * S + (tid % Q) * 4) = v;
     }
   }
 

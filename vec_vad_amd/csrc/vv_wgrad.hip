@@ -25,8 +25,11 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   // act tile / dy tile geometry
   constexpr int AHH = CT ? TH : TH + 2, AHW = CT ? TW : TW + 2;
   constexpr int BHH = CT ? 2 * TH + 1 : TH, BHW = CT ? 2 * TW + 1 : TW;
-  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * BHH * BHW * 32;
-  __shared__ float lds[ASZ + BSZ];
+  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * BHH * BHW * 32, TSZ = ASZ + BSZ;
+  // 3x3 convolutions: two LDS tile buffers, the staging of tile t+1 (loads, BN+ReLU, LDS writes) is spread over the MFMA
+  // loop of tile t.  Transposed convolutions (larger dy halo tiles, 4 % of the weight-gradient time) keep one buffer.
+  constexpr bool DB = !CT && 2 * TSZ * 4 <= 160 * 1024;
+  __shared__ float lds[DB ? 2 * TSZ : TSZ];
   float* lA = lds;
   float* lB = lds + ASZ;
 
@@ -70,9 +73,94 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   stA.init(sa, CT ? 0 : -1, tid);
   stB.init(sb, CT ? -1 : 0, tid);
   const int dbg = p.pad0;                   // bring-up switch (0 in production): 1 = skip staging (timing experiments)
+
+  // operand addressing of k-step kk (pixel pair 2kk, 2kk+1 of this wave's quarter of the tile)
+  auto addr = [&](const float* tA, const float* tB, const int kk, const float*& pa, const float*& pb) {
+    const int pp = wave * PPW + 2 * kk + half;
+    const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+    if constexpr (CT) {
+      pa = tA + pp * 32 + l31;
+      pb = tB + ((im * BHH + 2 * r) * BHW + 2 * c) * 32 + l31;
+    } else {
+      pa = tA + ((im * AHH + r) * AHW + c) * 32 + l31;
+      pb = tB + pp * 32 + l31;
+    }
+  };
+  auto rd = [&](const float* pa, const float* pb, const int t) -> float {      // the tap-shifted operand of tap t
+    if constexpr (CT) return pb[((t / 3) * BHW + (t % 3)) * 32];
+    else return pa[((t / 3) * AHW + (t % 3)) * 32];
+  };
+  auto rd1 = [&](const float* pa, const float* pb) -> float {                   // the un-shifted operand
+    if constexpr (CT) return pa[0];
+    else return pb[0];
+  };
+  auto mfma1 = [&](const int t, const float sh, const float un) {
+    if constexpr (CT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(un, sh, acc[t], 0, 0, 0);   // A = act, B = dy(tap)
+    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sh, un, acc[t], 0, 0, 0);                // A = act(tap), B = dy
+  };
+  constexpr int NK = PPW / 2;
+  static_assert(NK % 2 == 0, "k-loop is unrolled by two");
+
+  if constexpr (DB) {
+    // ---- double-buffered pipeline.  Slot s = kk*9 + t is "MFMA t of k-step kk, one ds_read of step kk+1, one staging
+    // piece".  Slots [0, NP) issue the buffer loads of the next tile into registers, slots [C0, C0+NP) apply BN+ReLU and
+    // write them to the OTHER LDS buffer; one barrier per tile.  The workgroup's last tile stages a dead tile (all
+    // loads out of range) so the loop stays branch-free.
+    constexpr int NPA = decltype(stA)::NIT, NPB = decltype(stB)::NIT, NP = NPA + NPB;
+    constexpr int NSLOT = NK * 9, C0 = NSLOT - NP - 9;
+    static_assert(C0 >= 2 * NP, "not enough MFMA slots between load issue and commit");
+    auto begin_tile = [&](const int pt, const bool live) {
+      const int img0 = (pt / tpi) * NI;
+      const int trem = pt % tpi;
+      const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+      stA.begin(sa, img0, ty0 - 1, tx0 - 1, cit * 32, tid, p.CinP, live);
+      stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
+    };
+    begin_tile(ks, true);
+    vv_static_for<0, NPA>([&](auto K) { stA.template load_piece<K.value>(sa, -1, tid); });
+    vv_static_for<0, NPB>([&](auto K) { stB.template load_piece<K.value>(sb, 0, tid); });
+    vv_static_for<0, NPA>([&](auto K) { stA.template commit_piece<K.value>(lA, tid); });
+    vv_static_for<0, NPB>([&](auto K) { stB.template commit_piece<K.value>(lB, tid); });
+    __syncthreads();
+    int cur = 0;
+    for (int pt = ks; pt < NT; pt += KS) {
+      const float* tA = lds + cur * TSZ;
+      const float* tB = tA + ASZ;
+      float* nA = lds + (cur ^ 1) * TSZ;
+      float* nB = nA + ASZ;
+      const bool live = (pt + KS < NT) && !(dbg & 2);
+      begin_tile(live ? pt + KS : ks, live);
+      float a[2][9], b[2];
+      const float *pa, *pb;
+      addr(tA, tB, 0, pa, pb);
+      b[0] = rd1(pa, pb);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a[0][t] = rd(pa, pb, t);
+      vv_static_for<0, NK>([&](auto KK) {
+        constexpr int kk = KK.value, c = kk & 1, n = c ^ 1;
+        addr(tA, tB, kk + 1 < NK ? kk + 1 : 0, pa, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        vv_static_for<0, 9>([&](auto T) {
+          constexpr int t = T.value, slot = kk * 9 + t;
+          mfma1(t, a[c][t], b[c]);
+          if constexpr (kk + 1 < NK) {
+            if constexpr (t == 0) b[n] = rd1(pa, pb);
+            a[n][t] = rd(pa, pb, t);
+          }
+          if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
+          else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
+          else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
+          else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      __syncthreads();                        // next buffer complete, current buffer no longer read
+      if (!(dbg & 2)) cur ^= 1;             // dbg 2: stage the first tile only (k-loop on real data)
+    }
+  } else {
   if (!(dbg & 1)) issue(ks);
   for (int pt = ks; pt < NT; pt += KS) {
-    if (!(dbg & 1)) {
+    if (!(dbg & 1) && !((dbg & 2) && pt != ks)) {      // dbg 2: stage the first tile only (k-loop on real data)
       if (pt != ks) __syncthreads();          // every wave is done reading the previous tile
       stA.commit(lA, tid);
       stB.commit(lB, tid);
@@ -83,40 +171,15 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     // k-loop over pixel pairs.  The LDS operands of step k+1 are read into a second register set while step k runs:
     // each MFMA is followed by exactly one ds_read of the next step (pinned with sched_barrier), so the matrix pipe
     // never waits behind a block of LDS issue slots and no ds_read is waited on right after it was issued.
-    auto addr = [&](const int kk, const float*& pa, const float*& pb) {
-      const int pp = wave * PPW + 2 * kk + half;
-      const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
-      if constexpr (CT) {
-        pa = lA + pp * 32 + l31;
-        pb = lB + ((im * BHH + 2 * r) * BHW + 2 * c) * 32 + l31;
-      } else {
-        pa = lA + ((im * AHH + r) * AHW + c) * 32 + l31;
-        pb = lB + pp * 32 + l31;
-      }
-    };
-    auto rd = [&](const float* pa, const float* pb, const int t) -> float {      // the tap-shifted operand of tap t
-      if constexpr (CT) return pb[((t / 3) * BHW + (t % 3)) * 32];
-      else return pa[((t / 3) * AHW + (t % 3)) * 32];
-    };
-    auto rd1 = [&](const float* pa, const float* pb) -> float {                   // the un-shifted operand
-      if constexpr (CT) return pa[0];
-      else return pb[0];
-    };
-    auto mfma1 = [&](const int t, const float sh, const float un) {
-      if constexpr (CT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(un, sh, acc[t], 0, 0, 0);   // A = act, B = dy(tap)
-      else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sh, un, acc[t], 0, 0, 0);                // A = act(tap), B = dy
-    };
-    constexpr int NK = PPW / 2;
-    static_assert(NK % 2 == 0, "k-loop is unrolled by two");
     float a0[9], a1[9], b0, b1;
     const float *pa, *pb;
-    addr(0, pa, pb);
+    addr(lA, lB, 0, pa, pb);
     b0 = rd1(pa, pb);
 #pragma unroll
     for (int t = 0; t < 9; ++t) a0[t] = rd(pa, pb, t);
 #pragma unroll 1
     for (int kk = 0; kk < NK; kk += 2) {
-      addr(kk + 1, pa, pb);
+      addr(lA, lB, kk + 1, pa, pb);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -125,7 +188,7 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
         a1[t] = rd(pa, pb, t);
         __builtin_amdgcn_sched_barrier(0);
       }
-      addr(kk + 2 < NK ? kk + 2 : 0, pa, pb);
+      addr(lA, lB, kk + 2 < NK ? kk + 2 : 0, pa, pb);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -136,10 +199,11 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
       }
     }
   }
+  }
 
   // cross-wave (K-split) reduction through LDS in fixed wave order, then one slab per workgroup:
   // slab = (cit*NCO + cot)*KS + ks ; layout [tap][ci(32)][co(32)]
-  static_assert(ASZ + BSZ >= 9 * 1024, "LDS too small for the slab");
+  static_assert(TSZ >= 9 * 1024, "LDS too small for the slab");
   __syncthreads();
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
@@ -229,6 +293,8 @@ extern "C" int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W) {
 extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
   if (!p || !p->src0.ptr || !p->dy.ptr || !p->partial) return VV_ERR_BAD_ARG;
   if (p->Cout % 32 || p->ksplit < 1) return VV_ERR_BAD_ARG;
+  if (p->kind == VV_CONV3 && (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE))
+    return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
   if (p->kind == VV_CONV3) {
     switch (p->H) {
