@@ -96,8 +96,9 @@ def main():
     ap.add_argument('--model', default='net4', choices=['net4', 'full'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
-    ap.add_argument('--overlap', action='store_true', help='run the weight-gradient kernels on a side stream (about +4 %% cubes/s; '
-                    'per-kernel timings then include the contention, so the default keeps one stream)')
+    ap.add_argument('--overlap', nargs='?', const='free', default='none', choices=('none', 'free', 'paired'),
+                    help="side stream for the weight-gradient kernels: 'free' = under everything that follows (conv launches "
+                         "are then contended), 'paired' = only under the next layer's BatchNorm backward (conv launches run alone)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,7 +130,7 @@ def main():
     net = cls(features_root=32, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=None, useFlow=True,
               padding=False).to(dev)
     trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
-                           overlap=args.overlap)
+                           overlap={'none': False, 'free': True, 'paired': 'paired'}[args.overlap])
     bank = trainer.bank
     B = args.batch
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
@@ -164,7 +165,7 @@ def main():
     trainer.event_hook = None
     # a few extra (untimed) steps with the side stream disabled: the same launches without a concurrent weight-grad kernel
     iso = []
-    if args.overlap:
+    if args.overlap == 'free':
         trainer.event_hook = lambda label, a, b: iso.append((label, a, b))
         trainer.event_labels = set(fl.keys())
         trainer.overlap = False
@@ -173,6 +174,20 @@ def main():
         torch.cuda.synchronize()
         trainer.overlap = True
         trainer.event_hook = None
+    # forward-only rate (BASELINE.json north_star: ">= 50 % of the MFMA roofline on the UNet forward at batch 256"):
+    # cube gather + train-mode forward (BatchNorm batch statistics, loss + per-cube scores), outside the timed region
+    fwd_n = 10
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    bufs, nbt = bank.bufs.clone(), bank.nbt.clone()          # forward(train=True) moves the BatchNorm running statistics
+    f0.record()
+    for it in range(fwd_n):
+        bank.set_input_cubes(raw, flow, perm[it], B)
+        bank.forward(ws, True)
+    f1.record()
+    torch.cuda.synchronize()
+    bank.bufs.copy_(bufs)
+    bank.nbt.copy_(nbt)
+    fwd_ms = f0.elapsed_time(f1) / fwd_n
     iso_t = sum(a.elapsed_time(b) * 1e-3 for _, a, b in iso)
     iso_f = sum(fl[label] for label, _, _ in iso)
     l_raw, l_of = bank.losses(ws)
@@ -200,6 +215,7 @@ def main():
     cubes = B * world * args.steps
     value = cubes / dt
     flop_per_cube = TRAIN_FLOP_NET4 if args.model == 'net4' else 9206169600
+    fwd_flop_per_cube = 1855520768 if args.model == 'net4' else 3092316160
     out = {
         'metric': 'spatio-temporal cubes/sec (train step)', 'value': value, 'unit': 'cubes/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
@@ -210,6 +226,8 @@ def main():
                    'batch_per_gpu': B, 'global_batch': B * world, 'cube': '32x32x5 RGB uint8 + flow fp32',
                    'parallelism': 'dp%d' % world, 'train_tflops_per_gpu': value / world * flop_per_cube / 1e12,
                    'frac_of_fp32_mfma_peak_whole_step': value / world * flop_per_cube / FP32_MFMA_PEAK,
+                   'forward_ms': fwd_ms, 'forward_tflops_per_gpu': B * fwd_flop_per_cube / (fwd_ms * 1e-3) / 1e12,
+                   'forward_frac_of_fp32_mfma_peak': B * fwd_flop_per_cube / (fwd_ms * 1e-3) / FP32_MFMA_PEAK,
                    'loss_raw': loss_now[0], 'loss_of': loss_now[1]},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 implicit-GEMM, forward + data-gradient launches)',
                      'achieved': (conv_f / conv_t / 1e12) if conv_t > 0 else None, 'peak': FP32_MFMA_PEAK / 1e12,
@@ -217,7 +235,7 @@ def main():
                      'traffic': pmc_traffic(), 'launches_timed': conv_n,
                      'avg_launch_us': (1e6 * conv_t / conv_n) if conv_n else None,
                      'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None,
-                     'side_stream_weight_grad': bool(args.overlap),
+                     'side_stream_weight_grad': args.overlap,
                      'isolated_frac': (iso_f / iso_t / FP32_MFMA_PEAK) if iso_t > 0 else None},
     }
     if not args.no_cpu_baseline and world == 1:

@@ -229,6 +229,13 @@ int vv_correlation_fwd(const float* in1, const float* in2, float* out, int32_t B
 int vv_correlation_out_shape(int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
                              int32_t max_displacement, int32_t stride1, int32_t stride2, int32_t* oC, int32_t* oH,
                              int32_t* oW);
+/* The same op specialised to how FlowNetC uses it (FlowNetC.py:41-47,92-93,120: pad 20, kernel 1, max_displacement 20,
+ * stride1 1, stride2 2, then LeakyReLU(0.1), then torch.cat with conv_redir): NHWC maps in (pixel stride `cstride` floats,
+ * C % 32 == 0, 16-byte aligned), result * 1/C through y = v > 0 ? v : slope*v written to channels
+ * [out_coff, out_coff+441) of an NHWC buffer with pixel stride out_cstride.  W in {64, 128} (512- and 1024-wide
+ * inputs); other widths return VV_ERR_UNSUPPORTED -> use vv_correlation_fwd. */
+int vv_correlation_nhwc(const float* f1, const float* f2, int32_t cstride, int32_t B, int32_t C, int32_t H, int32_t W,
+                        float* out, int32_t out_cstride, int32_t out_coff, float slope, vv_stream stream);
 /* Resample2d_cuda_forward (ops/resample2d/src/Resample2d_cuda.c:8-11, Resample2d_kernel.cu:20-66) */
 int vv_resample2d_fwd(const float* img, const float* flow, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
                       int32_t fH, int32_t fW, int32_t kernel_size, vv_stream stream);

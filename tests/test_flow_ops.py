@@ -84,3 +84,32 @@ def test_correlation_flownetc_size_properties():
     c1 = cab[0, (tj + 10) * 21 + (ti + 10)]
     c2 = cba[0, (-tj + 10) * 21 + (-ti + 10)]
     torch.testing.assert_close(c1[:56 - 2 * tj, -2 * ti:], c2[2 * tj:, :128 + 2 * ti], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,H,W', [(1, 32, 5, 64), (2, 64, 7, 128), (1, 256, 56, 128), (1, 256, 48, 64)])
+def test_correlation_nhwc_fused_vs_oracle(B, C, H, W):
+    """vv_correlation_nhwc (FlowNetC's geometry, NHWC in, 1/C + LeakyReLU(0.1) fused, written into a channel slice) vs
+    the numpy oracle at small sizes and vs the generic NCHW kernel at BASELINE config-5 size; untouched channels of the
+    destination buffer keep their contents."""
+    import ctypes as C_
+    from vec_vad_amd import _lib as L
+    from vec_vad_amd.flow_ops import correlation
+    g = torch.Generator(device='cpu').manual_seed(5)
+    a = torch.randn(B, H, W, C, generator=g).cuda()
+    b = torch.randn(B, H, W, C, generator=g).cuda()
+    out = torch.full((B, H, W, 476), 7.0, device='cuda')
+    L.check(L.lib().vv_correlation_nhwc(a.data_ptr(), b.data_ptr(), C, B, C, H, W, out.data_ptr(), 476, 32, 0.1,
+                                       torch.cuda.current_stream().cuda_stream), 'correlation_nhwc')
+    assert torch.all(out[..., :32] == 7.0) and torch.all(out[..., 473:] == 7.0)
+    got = out[..., 32:473].permute(0, 3, 1, 2)
+    an, bn = a.permute(0, 3, 1, 2).contiguous(), b.permute(0, 3, 1, 2).contiguous()
+    if H * W <= 1024:
+        ref = torch.from_numpy(F.correlation_fwd(an.cpu().numpy(), bn.cpu().numpy(), 20, 1, 20, 1, 2)).cuda()
+    else:
+        ref = correlation(an, bn, 20, 1, 20, 1, 2, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.1)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-6)
+    # widths outside {64, 128} are refused (the caller falls back to the generic op)
+    assert L.lib().vv_correlation_nhwc(a.data_ptr(), b.data_ptr(), C, B, C, H, 96, out.data_ptr(), 476, 32, 0.1,
+                                       torch.cuda.current_stream().cuda_stream) == 3

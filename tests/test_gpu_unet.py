@@ -169,20 +169,20 @@ def test_batch_independence_and_determinism_large():
 
 
 def test_side_stream_weight_grad_is_bitwise_identical():
-    """overlap=True (weight gradients on a side stream, double-buffered dy) must not change a single bit."""
+    """overlap=True / 'paired' (weight gradients on a side stream, double-buffered dy) must not change a single bit."""
     from oracle import unet_oracle as O
     from vec_vad_amd.trainer import FusedTrainer
     raw, flow = O.seeded_cubes(40, 1, 9)
     rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
     outs = []
-    for overlap in (False, True):
+    for overlap in (False, True, 'paired'):
         net, _, _ = _build('net4', False)
         net.train()
         tr = FusedTrainer(net, overlap=overlap)
         for s in range(3):
             tr.step_cubes(rawd, flowd, torch.arange(40, device='cuda'))
         outs.append(tr.bank.params.clone())
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_odd_batch_sizes_train():

@@ -101,6 +101,7 @@ _SIGS = {
                                    c_i32, c_vp]),
     'vv_correlation_out_shape': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                          C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
+    'vv_correlation_nhwc': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_f32, c_vp]),
     'vv_resample2d_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_channelnorm_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_crop_resize': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -140,9 +140,11 @@ class _Plan:
         self.meta = []      # per call: (stream id 0|1, events to wait for, event to record) for the two-stream executor
         self.keep = []      # ctypes objects that must stay alive
 
-    def add(self, fn, args, label, stream=0, wait=(), record=None):
+    def add(self, fn, args, label, stream=0, wait=(), record=None, pwait=None):
+        """wait / pwait: events this launch waits for in the 'free' / 'paired' two-stream schedules; the tokens '*main' and
+        '*side' mean "everything enqueued so far on that stream"."""
         self.calls.append((fn, args, label))
-        self.meta.append((stream, tuple(wait), record))
+        self.meta.append((stream, tuple(wait), record, tuple(wait if pwait is None else pwait)))
 
     def run(self, stream):
         for fn, args, label in self.calls:
@@ -444,15 +446,6 @@ class UNetBank:
             P.add(lib.vv_bn_bwd_apply, (C.byref(bp), pbase + 4 * lay.p['c%d.g' % i][0], U, gbase + 4 * lay.p['c%d.g' % i][0],
                                         gbase + 4 * lay.p['c%d.beta' % i][0], U, ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
                   record='dy%d' % i)
-            # weight gradient (side stream: only depends on dy_i and forward products)
-            mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
-            ks, nslab = wplan['c%d' % i]
-            wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit, 0, chmap,
-                               L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
-            P.keep.append(wp)
-            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,), record='wdone%d' % i)
-            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks, ws.wpart.data_ptr(), wpg,
-                                        gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i, stream=1)
             # data gradient
             if i > 0:
                 Dl = ws.D[i]
@@ -460,7 +453,20 @@ class UNetBank:
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, 0, None,
                                   kbase + 4 * lay.pk['c%d.d' % i][0], UP, None, 0, L.view(Dl, l.cin, 0, Dl.stride(0)), None)
                 P.keep.append(cp)
-                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i)
+                # paired schedule: the MFMA data-gradient runs alone (the side stream has drained) ...
+                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i, pwait=('*side',))
+            # weight gradient (side stream: only depends on dy_i and forward products).  Paired schedule: ... and the
+            # weight-gradient starts when it is done, sharing the chip with the HBM-bound BatchNorm backward of the
+            # next layer only.
+            mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
+            ks, nslab = wplan['c%d' % i]
+            wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit, 0, chmap,
+                               L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
+            P.keep.append(wp)
+            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,), record='wdone%d' % i,
+                  pwait=('*main',))
+            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks, ws.wpart.data_ptr(), wpg,
+                                        gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i, stream=1)
 
         def convT_bwd(u, m):
             """m: the CAT conv layer that consumed convT u; its data gradient holds d(convT out) in channels [skipC, cin)."""
@@ -468,9 +474,14 @@ class UNetBank:
             dcat = ws.D[m.idx]
             skipc = lay.convs[m.skip].cout
             dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
+            DT = ws.DT[u]
+            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, 0, None,
+                              kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
+            P.keep.append(cp)
+            P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
             P.add(lib.vv_bias_grad, (Ga, B * (2 * H) * (2 * H), co, dcat.data_ptr(), dcat.stride(0), m.cin, skipc,
                                      ws.bscr.data_ptr(), gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u, stream=1,
-                  wait=('D%d' % m.idx,))
+                  wait=('D%d' % m.idx,), pwait=('*main',))
             y = ws.y[sidx]
             ks, nslab = wplan['t%d' % u]
             wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
@@ -480,11 +491,6 @@ class UNetBank:
             P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1)
             P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks, ws.wpart.data_ptr(), wpg,
                                         gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
-            DT = ws.DT[u]
-            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, 0, None,
-                              kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
-            P.keep.append(cp)
-            P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u)
 
         for l in reversed(lay.convs):
             conv_bwd(l)

@@ -87,6 +87,118 @@ correlation_k1_kernel(const float* __restrict__ in1, const float* __restrict__ i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FlowNetC's correlation layer on NHWC maps (pad 20, kernel 1, max_displacement 20, stride1 1, stride2 2:
+// FlowNetC.py:41-47), with the 1/C normalisation (correlation_cuda_kernel.cu:65,93-99) and FlowNetC's LeakyReLU
+// (FlowNetC.py:92-93) fused, written straight into a channel slice of the consumer's NHWC concat buffer.
+//
+//   out[y][x][ti*21 + tj] = leaky( 1/C * sum_c f1[y][x][c] * f2[y + 2(ti-10)][x + 2(tj-10)][c] )
+//
+// fp32 VALU kernel (an MFMA Gram-matrix formulation would throw away 78 % of each 32x32 block).  One workgroup = one
+// output row y and DYB of the 21 row displacements; a thread owns two same-parity columns (x, x+2) and all 21 column
+// displacements of one row displacement: 42 accumulators, whose 22-wide window of f2 is shared by both columns.
+// Both maps go through LDS in 32-channel chunks as float4 planes [c4][pos mod 4][pos div 4] (+1 float4 of plane padding):
+// with that split a wave's ds_read_b128 of "position 4j + const" walks consecutive float4 slots (conflict free in the
+// hardware's 16-lane groups) and the staging writes of 8 consecutive channel groups land in 8 different bank quads.
+// Zero padding = LDS slots that are never written.  The next chunk's global loads fly (in registers) under the FMAs.
+template <int W_>
+__global__ void __launch_bounds__(VV_WG, 1)
+correlation_nhwc_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const int cs, const int C,
+                        const int H, float* __restrict__ out, const int ocs, const int ocoff, const float slope,
+                        const int NG) {
+  constexpr int D = 21, MD = 20, CK = 32, NC4 = CK / 4;
+  constexpr int DPW = 128 / W_;                 // row displacements per wave
+  constexpr int DYB = 4 * DPW;                  // ... per workgroup
+  constexpr int LPD = W_ / 2;                   // lanes per row displacement
+  constexpr int NJ = W_ / 4;
+  constexpr int QS = ((W_ + 2 * MD + 3) / 4 + 15) / 16 * 16;      // slots per pos-mod-4 plane of f2 (multiple of 16)
+  constexpr int Q1 = (NJ + 15) / 16 * 16;
+  constexpr int P2 = 4 * QS + 1, P1 = 4 * Q1 + 1;                 // float4 per channel-group plane (+1: bank shift)
+  constexpr int F1SZ = NC4 * P1, F2SZ = NC4 * P2;                 // float4 per tile
+  constexpr int N1 = W_ * NC4, N2 = DYB * W_ * NC4;               // float4 items per chunk
+  constexpr int NIT = (N1 + N2) / VV_WG;
+  static_assert((N1 + N2) % VV_WG == 0 && N1 % VV_WG == 0, "item split");
+  extern __shared__ float4 cl[];
+  float4* F1 = cl;
+  float4* F2 = cl + F1SZ;
+
+  const int y = blockIdx.x / NG, grp = blockIdx.x % NG, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane % LPD, j = li % NJ, par = li / NJ;
+  const int slot = wave * DPW + lane / LPD;
+  const int ti = grp * DYB + slot;              // row displacement index of this thread
+  const float* p1 = f1 + (int64_t)b * H * W_ * cs;
+  const float* p2 = f2 + (int64_t)b * H * W_ * cs;
+
+  for (int e = tid; e < F1SZ + DYB * F2SZ; e += VV_WG) cl[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // staging items: [0, N1) the f1 row, then DYB displaced f2 rows; consecutive threads = consecutive channel groups
+  float4 r[NIT];
+  int ldsoff[NIT];
+  const float* gsrc[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int it = tid + k * VV_WG;
+    const int c4 = it % NC4, x = (it / NC4) % W_, row = it / (NC4 * W_);      // row 0 = f1, 1.. = f2 slot row-1
+    if (row == 0) {
+      ldsoff[k] = c4 * P1 + (x & 3) * Q1 + (x >> 2);
+      gsrc[k] = p1 + ((int64_t)y * W_ + x) * cs + c4 * 4;
+    } else {
+      const int sl = row - 1, t2 = grp * DYB + sl;
+      const int yy = y + 2 * (t2 - MD / 2);
+      const int pos = x + MD;
+      ldsoff[k] = F1SZ + sl * F2SZ + c4 * P2 + (pos & 3) * QS + (pos >> 2);
+      gsrc[k] = (t2 < D && (unsigned)yy < (unsigned)H) ? p2 + ((int64_t)yy * W_ + x) * cs + c4 * 4 : nullptr;
+    }
+  }
+  auto issue = [&](const int c0) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (gsrc[k]) r[k] = *reinterpret_cast<const float4*>(gsrc[k] + c0);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (gsrc[k]) cl[ldsoff[k]] = r[k];
+  };
+
+  float aa[D], ab[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { aa[k] = 0.f; ab[k] = 0.f; }
+  const float4* q1 = F1 + par * Q1 + j;
+  const float4* q2 = F2 + slot * F2SZ + par * QS + j;
+
+  issue(0);
+  for (int c0 = 0; c0 < C; c0 += CK) {
+    __syncthreads();                       // previous chunk fully consumed (first pass: zero fill done)
+    commit();
+    __syncthreads();
+    if (c0 + CK < C) issue(c0 + CK);
+#pragma unroll 2
+    for (int c4 = 0; c4 < NC4; ++c4) {
+      const float4 va = q1[c4 * P1], vb = q1[c4 * P1 + 2 * Q1];      // columns x = 4j+par and x+2
+#pragma unroll
+      for (int m = 0; m <= D; ++m) {
+        const float4 v = q2[c4 * P2 + 2 * (m & 1) * QS + (m >> 1)];   // f2 position x - 20 + 2m
+        if (m < D) aa[m] = fmaf(va.w, v.w, fmaf(va.z, v.z, fmaf(va.y, v.y, fmaf(va.x, v.x, aa[m]))));
+        if (m > 0) ab[m - 1] = fmaf(vb.w, v.w, fmaf(vb.z, v.z, fmaf(vb.y, v.y, fmaf(vb.x, v.x, ab[m - 1]))));
+      }
+    }
+  }
+  if (ti < D) {
+    const float scale = 1.f / (float)C;
+    const int x = 4 * j + par;
+    float* o = out + ((int64_t)(b * H + y) * W_ + x) * ocs + ocoff + ti * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      float v = aa[k] * scale;
+      o[k] = v > 0.f ? v : v * slope;
+      v = ab[k] * scale;
+      o[2 * ocs + k] = v > 0.f ? v : v * slope;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(VV_WG)
 resample2d_kernel(const int64_t npix, const float* __restrict__ img, const float* __restrict__ flow,
                   float* __restrict__ out, const int C, const int H, const int W, const int fH, const int fW) {
@@ -169,6 +281,38 @@ extern "C" int vv_correlation_fwd(const float* in1, const float* in2, float* out
                      H, W, oC, oH, oW, pad_size, max_displacement, stride1, stride2, dr, xtiles);
   VV_CHECK_LAUNCH();
   return VV_OK;
+}
+
+template <int W_>
+static int launch_corr_nhwc(const float* f1, const float* f2, int cs, int B, int C, int H, float* out, int ocs, int ocoff,
+                            float slope, hipStream_t st) {
+  constexpr int DYB = 4 * (128 / W_);
+  constexpr int QS = ((W_ + 40 + 3) / 4 + 15) / 16 * 16, Q1 = (W_ / 4 + 15) / 16 * 16;
+  constexpr size_t bytes = (size_t)(8 * (4 * Q1 + 1) + DYB * 8 * (4 * QS + 1)) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(correlation_nhwc_kernel<W_>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+      return VV_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int NG = (21 + DYB - 1) / DYB;
+  VV_LAUNCH(correlation_nhwc_kernel<W_>, dim3(H * NG, B), dim3(VV_WG), bytes, st, f1, f2, cs, C, H, out, ocs, ocoff,
+            slope, NG);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_correlation_nhwc(const float* f1, const float* f2, int32_t cstride, int32_t B, int32_t C, int32_t H,
+                                   int32_t W, float* out, int32_t out_cstride, int32_t out_coff, float slope,
+                                   vv_stream stream) {
+  if (!f1 || !f2 || !out || B <= 0 || H <= 0) return VV_ERR_BAD_ARG;
+  if (C % 32 || cstride % 4 || cstride < C) return VV_ERR_UNSUPPORTED;
+  if (((uintptr_t)f1 | (uintptr_t)f2) & 15) return VV_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (W == 128) return launch_corr_nhwc<128>(f1, f2, cstride, B, C, H, out, out_cstride, out_coff, slope, st);
+  if (W == 64) return launch_corr_nhwc<64>(f1, f2, cstride, B, C, H, out, out_cstride, out_coff, slope, st);
+  return VV_ERR_UNSUPPORTED;   /* other widths: vv_correlation_fwd (generic, NCHW) */
 }
 
 extern "C" int vv_resample2d_fwd(const float* img, const float* flow, float* out, int32_t B, int32_t C, int32_t H,

@@ -61,12 +61,44 @@ def _xavier_init(module):
             nn.init.xavier_uniform_(m.weight)
 
 
+class _Pool:
+    """Activation buffers of one forward, handed out in call order and kept per input shape: the zero fill (pad channels
+    must be finite, producers only ever write real channels) happens once, not ~90 times per forward."""
+
+    def __init__(self):
+        self.by_key, self.cur, self.i = {}, None, 0
+
+    def begin(self, key):
+        self.cur, self.i = self.by_key.setdefault(key, []), 0
+
+    def end(self):
+        self.cur = None
+
+    def take(self, shape, device):
+        if self.cur is None:
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        if self.i < len(self.cur) and tuple(self.cur[self.i].shape) == tuple(shape) and self.cur[self.i].device == device:
+            t = self.cur[self.i]
+        else:
+            t = torch.zeros(shape, device=device, dtype=torch.float32)
+            del self.cur[self.i:]
+            self.cur.append(t)
+        self.i += 1
+        return t
+
+
+_ACTIVE_POOL = [None]
+
+
 class _Buf:
     """NHWC activation buffer [B,H,W,ceil4(C)] (zero initialised so pad channels are finite)."""
 
     def __init__(self, B, H, W, C, device):
         self.B, self.H, self.W, self.C, self.cs = B, H, W, C, _c4(C)
-        self.t = torch.zeros(B, H, W, self.cs, device=device, dtype=torch.float32)
+        pool = _ACTIVE_POOL[0]
+        shape = (B, H, W, self.cs)
+        self.t = pool.take(shape, torch.device(device)) if pool is not None else \
+            torch.zeros(shape, device=device, dtype=torch.float32)
 
     def view(self, coff=0):
         return L.View(self.t.data_ptr(), 0, self.cs, coff)
@@ -241,8 +273,15 @@ class FlowNetC(nn.Module):
         c3a, c3b = nb(H // 8, W // 8, 256), nb(H // 8, W // 8, 256)
         run(self.conv3, c2a_view, c3a); run(self.conv3, c2b, c3b)
         in31 = nb(H // 8, W // 8, 473)
-        corr = correlation(c3a.nchw(), c3b.nchw(), 20, 1, 20, 1, 2, 1)
-        in31.t[..., 32:473] = torch.where(corr > 0, corr, corr * 0.1).permute(0, 2, 3, 1)      # corr_activation
+        # corr + corr_activation + the cat with conv_redir (FlowNetC.py:88-96,120): one launch on the NHWC maps, written
+        # into channels [32, 473) of conv3_1's input; widths the specialised kernel does not cover take the generic op
+        rc = L.lib().vv_correlation_nhwc(c3a.t.data_ptr(), c3b.t.data_ptr(), c3a.cs, B, 256, H // 8, W // 8, in31.t.data_ptr(),
+                                         in31.cs, 32, 0.1, torch.cuda.current_stream(dev).cuda_stream)
+        if rc == 3:       # VV_ERR_UNSUPPORTED
+            corr = correlation(c3a.nchw(), c3b.nchw(), 20, 1, 20, 1, 2, 1)
+            in31.t[..., 32:473] = torch.where(corr > 0, corr, corr * 0.1).permute(0, 2, 3, 1)
+        else:
+            L.check(rc, 'correlation_nhwc')
         run(self.conv_redir, c3a, in31, 0)
         cat3 = nb(H // 8, W // 8, 386)
         run(self.conv3_1, in31, cat3, 0)
@@ -443,6 +482,7 @@ class FlowNet2(nn.Module):
         _xavier_init(self)
         self._runner = None
         self._graphs = {}
+        self._pool = _Pool()
 
     @torch.no_grad()
     def forward(self, inputs):
@@ -455,7 +495,21 @@ class FlowNet2(nn.Module):
             self._runner = _Runner()
         run = self._runner
         inputs = inputs.float()
-        rgb_mean = inputs.contiguous().view(inputs.size()[:2] + (-1,)).mean(dim=-1).view(inputs.size()[:2] + (1, 1, 1))
+        self._pool.begin((tuple(inputs.shape), str(inputs.device)))
+        _ACTIVE_POOL[0] = self._pool
+        try:
+            return self._forward(run, inputs)
+        finally:
+            _ACTIVE_POOL[0] = None
+            self._pool.end()
+
+    def _forward(self, run, inputs):
+        # per-image, per-colour mean over both frames (flownet2.py:67); two-level sum: a [B,3]-row reduction over ~1e6
+        # elements per row is a 3-workgroup kernel in torch
+        flat = inputs.contiguous().view(inputs.size()[:2] + (-1,))
+        n = flat.shape[-1]
+        k = 1024 if n % 1024 == 0 else 1
+        rgb_mean = (flat.view(flat.shape[0], flat.shape[1], n // k, k).sum(dim=-1).sum(dim=-1) / n).view(inputs.size()[:2] + (1, 1, 1))
         x = (inputs - rgb_mean) / self.rgb_max
         x1, x2 = x[:, :, 0].contiguous(), x[:, :, 1].contiguous()
         xcat = torch.cat((x1, x2), dim=1)

@@ -91,12 +91,14 @@ class FusedTrainer:
             lay = self.bank.lay
             split = lay.p['c8.w'][0]          # [0, split): encoder convs, [split, U): decoder convs, convT, 1x1 out
             self.buckets = GradBuckets(self.bank.grads, [0, split, lay.U], process_group)
-            self.split_label = 'dgradT0'      # last launch of the decoder half of the backward plan
+            self.split_label = 'wgradT_reduce0'   # last launch of the decoder half of the backward plan
         self.event_hook = None
         self.event_labels = None
-        # overlap=True: weight gradients (MFMA-bound, one workgroup per CU) run on a side stream under the BatchNorm-backward
-        # passes (HBM-bound) and the data gradients of the following layers; measured +4 % cubes/s at B=256.  Off by default
-        # so that per-kernel timings (bench roofline, rocprof) are not contended.
+        # overlap=True ('free'): weight gradients (MFMA-bound, one workgroup per CU) run on a side stream under the
+        # BatchNorm-backward passes (HBM-bound) AND the data gradients of the following layers; measured +4 % cubes/s at B=256
+        # but the conv launches are then contended.  overlap='paired': each weight gradient starts when its layer's data
+        # gradient is done and the next data gradient waits for it, so the only thing sharing the chip with a weight
+        # gradient is the next layer's HBM-bound BatchNorm backward; every conv_mfma launch still runs alone.
         self.overlap = overlap
         self.side = torch.cuda.Stream(device=self.bank.device) if overlap else None
 
@@ -125,10 +127,16 @@ class FusedTrainer:
         self.side.wait_stream(main)
         events = {}
         hook, labels = self.event_hook, self.event_labels
-        for (fn, args, label), (sid, waits, rec) in zip(plan.calls, plan.meta):
+        paired = self.overlap == 'paired'
+        for (fn, args, label), (sid, waits, rec, pwaits) in zip(plan.calls, plan.meta):
             st = streams[sid]
-            for w in waits:
-                st.wait_event(events[w])
+            for w in (pwaits if paired else waits):
+                if w == '*main':
+                    st.wait_stream(main)
+                elif w == '*side':
+                    st.wait_stream(self.side)
+                else:
+                    st.wait_event(events[w])
             timed = hook is not None and (labels is None or label in labels)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
