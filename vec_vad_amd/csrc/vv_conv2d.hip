@@ -26,9 +26,17 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
   constexpr int S = CK + 4, S4 = S / 4;
   constexpr int MR = 2, TN = NR * 32;
   constexpr int NTAP = DECONV ? 4 : R * R;
-  __shared__ float4 lds4[HH * HW * S4];
+  // 3x3 convolutions and the transposed convolution run the software pipeline of the UNet kernel (vv_conv.hip): the
+  // activation halo tile AND the chunk's weight panel go global -> registers -> LDS one chunk ahead of the MFMA loop,
+  // which reads only LDS, one ds_read_b128 after every group of 4 MFMAs.  5x5 / 7x7 (two layers per sub-network, weight
+  // panels of 51 / 100 KB per chunk) keep the direct form: tile staged per chunk, weights from global/L2.
+  constexpr bool PIPE = DECONV || R == 3;
+  constexpr int KGC = CK / 8;
+  constexpr int A4 = HH * HW * S4;
+  constexpr int B4 = PIPE ? NTAP * KGC * 2 * TN : 0;
+  constexpr int NBT = PIPE ? (B4 + VV_WG - 1) / VV_WG : 1;
+  __shared__ float4 lds4[A4 + B4];
   float* lds = reinterpret_cast<float*>(lds4);
-
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
   const int KS = p.pad0 > 1 ? p.pad0 : 1;        // split-K over input-channel chunks (tiny-M, huge-K layers)
@@ -74,24 +82,112 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
 
   const int nchunk = CinP / CK;
   const int cbeg = (nchunk * ks / KS) * CK, cend = (nchunk * (ks + 1) / KS) * CK;
+  if constexpr (PIPE) {
+    const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
+    const v4f* ldsB = reinterpret_cast<const v4f*>(lds4) + A4;
+    // tap t of this workgroup: offset of its input pixel inside the halo tile, and its weight-panel index
+    int aofft[NTAP], wtap[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      if constexpr (DECONV) {
+        // oy = 2*iy - 1 + ky: even rows use ky=1 (iy=r) and ky=3 (iy=r-1); odd rows ky=2 (iy=r) and ky=0 (iy=r+1)
+        const int ty_ = t >> 1, tx_ = t & 1;
+        const int dy = py ? (ty_ ? 1 : 0) : (ty_ ? -1 : 0), ky = py ? (ty_ ? 0 : 2) : (ty_ ? 3 : 1);
+        const int dx = px ? (tx_ ? 1 : 0) : (tx_ ? -1 : 0), kx = px ? (tx_ ? 0 : 2) : (tx_ ? 3 : 1);
+        aofft[t] = ((1 + dy) * HW + (1 + dx)) * S4;
+        wtap[t] = ky * 4 + kx;
+      } else {
+        aofft[t] = ((t / R) * HW + (t % R)) * S4;
+        wtap[t] = t;
+      }
+    }
+    VVStagerB<1, HH, HW, S, CK> stA;
+    stA.init(s, ox0, tid);
+    unsigned boff[NBT];
+    float4 rb[NBT];
+#pragma unroll
+    for (int k = 0; k < NBT; ++k) {
+      const int it = tid + k * VV_WG;
+      const int col = it % TN, row = it / TN;            // row = (tap*KGC + kg)*2 + half
+      const int hf = row & 1, tk = row >> 1;
+      const int kg = tk % KGC, tp = tk / KGC;
+      int wt = 0;
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) wt = tp == t ? wtap[t] : wt;
+      boff[k] = (B4 % VV_WG == 0 || it < B4) ? (unsigned)(((wt * KQ + kg) * 2 + hf) * CoutP + co0 + col) * 16u : 0x80000000u;
+    }
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](const int c0) {
+      stA.prefetch(s, img, oy0, ox0, c0, tid, p.src.cstride);
+      const int so = (c0 >> 3) * 2 * CoutP * 16;
+#pragma unroll
+      for (int k = 0; k < NBT; ++k) {
+        const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rsW, boff[k], so, 0);
+        rb[k] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    };
+    auto commit = [&]() {
+      stA.commit(lds, tid);
+#pragma unroll
+      for (int k = 0; k < NBT; ++k) {
+        const int it = tid + k * VV_WG;
+        if (B4 % VV_WG == 0 || it < B4) lds4[A4 + it] = rb[k];
+      }
+    };
+    constexpr int NIT = NTAP * KGC;
+    auto rdA = [&](const int it, const int m) -> v4f {
+      v4f v = ldsA[abase[m] + aofft[it / KGC] + (it % KGC) * 2];
+      asm volatile("" : "+v"(v));
+      return v;
+    };
+    auto rdB = [&](const int it, const int n) -> v4f {
+      v4f v = ldsB[(it * 2 + half) * TN + n * 32 + l31];
+      asm volatile("" : "+v"(v));
+      return v;
+    };
+    if (cbeg < cend) issue(cbeg);
+    for (int c0 = cbeg; c0 < cend; c0 += CK) {
+      if (c0 != cbeg) __syncthreads();      // every wave finished reading the previous chunk
+      commit();
+      __syncthreads();
+      if (c0 + CK < cend) issue(c0 + CK);
+      v4f fa[2][MR], fb[2][NR];
+#pragma unroll
+      for (int m = 0; m < MR; ++m) fa[0][m] = rdA(0, m);
+#pragma unroll
+      for (int n = 0; n < NR; ++n) fb[0][n] = rdB(0, n);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        int piece = 0;                       // pieces of the next step's fragments: A[0..MR), then B[0..NR)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][n], 0, 0, 0);
+            if (it + 1 < NIT) {
+              const int last = (m == MR - 1 && n == NR - 1);
+              do {
+                if (piece < MR) fa[nxt][piece] = rdA(it + 1, piece);
+                else if (piece < MR + NR) fb[nxt][piece - MR] = rdB(it + 1, piece - MR);
+                ++piece;
+              } while (last && piece < MR + NR);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+    }
+  } else {
   for (int c0 = cbeg; c0 < cend; c0 += CK) {
     if (c0 != cbeg) __syncthreads();
     vv_stage_tile<1, HH, HW, S, CK>(lds, s, img, oy0, ox0, c0, tid, p.src.cstride);
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < NTAP; ++t) {
-      int aoff, wt;
-      if constexpr (DECONV) {
-        // oy = 2*iy - 1 + ky: even rows use ky=1 (iy=r) and ky=3 (iy=r-1); odd rows ky=2 (iy=r) and ky=0 (iy=r+1)
-        const int ty_ = t >> 1, tx_ = t & 1;
-        const int dy = py ? (ty_ ? 1 : 0) : (ty_ ? -1 : 0), ky = py ? (ty_ ? 0 : 2) : (ty_ ? 3 : 1);
-        const int dx = px ? (tx_ ? 1 : 0) : (tx_ ? -1 : 0), kx = px ? (tx_ ? 0 : 2) : (tx_ ? 3 : 1);
-        aoff = ((1 + dy) * HW + (1 + dx)) * S4;
-        wt = ky * 4 + kx;
-      } else {
-        aoff = ((t / R) * HW + (t % R)) * S4;
-        wt = t;
-      }
+      const int aoff = ((t / R) * HW + (t % R)) * S4, wt = t;
 #pragma unroll
       for (int kg = 0; kg < CK / 8; ++kg) {
         v4f a[MR];
@@ -115,6 +211,7 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
           }
       }
     }
+  }
   }
 
   // ---- epilogue: bias, LeakyReLU, masked NHWC store into the (possibly shared concat) output buffer
