@@ -263,6 +263,18 @@ typedef struct vv_conv2d_params {
 int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream);
 int vv_conv2d_splitk_finish(const float* ws, int32_t ksplit, int64_t M, int32_t Cout, int32_t CoutP, const float* bias,
                             float slope, float* out, int32_t out_cstride, int32_t out_coff, vv_stream stream);
+/* The two-channel flow heads, where a 32-wide MFMA tile would be 94 % padding:
+ *  vv_conv3x3_n2  : predict_flow = nn.Conv2d(Cin, 2, 3, 1, 1) (components/misc.py:42-44).  wq = weights repacked as
+ *                   [tap 9][C4P][out 2][4] (Cin zero-padded to 4*C4P, C4P*4 a multiple of 32), bias[2] or NULL.
+ *  vv_deconv4x4_c2: upsampled_flow = nn.ConvTranspose2d(2, 2, 4, 2, 1) (FlowNetS.py:40-47 ...), w in PyTorch layout
+ *                   [2][2][4][4].
+ * NHWC in (pixel stride src_cstride, channels from 0), result through y = v > 0 ? v : slope*v into channels
+ * [out_coff, out_coff+2) of an NHWC buffer with pixel stride out_cstride. */
+int vv_conv3x3_n2(const float* src, int32_t src_cstride, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* wq,
+                  int32_t C4P, const float* bias, float slope, float* out, int32_t out_cstride, int32_t out_coff,
+                  vv_stream stream);
+int vv_deconv4x4_c2(const float* src, int32_t src_cstride, int32_t B, int32_t H, int32_t W, const float* w,
+                    const float* bias, float slope, float* out, int32_t out_cstride, int32_t out_coff, vv_stream stream);
 /* w: Conv2d [N][K][R][R] (transposed = 0) or ConvTranspose2d [K][N][4][4] (transposed = 1); taps = R*R */
 int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32_t KP, int32_t N, int32_t NP,
                    int32_t transposed, vv_stream stream);

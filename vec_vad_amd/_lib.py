@@ -72,6 +72,8 @@ _SIGS = {
     'vv_conv2d_mfma': (c_i32, [C.POINTER(Conv2dParams), c_vp]),
     'vv_conv2d_splitk_finish': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_i32, c_i32, c_vp]),
     'vv_pack_conv2d': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_conv3x3_n2': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_f32, c_vp, c_i32, c_i32, c_vp]),
+    'vv_deconv4x4_c2': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_vp]),
     'vv_upsample4': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     'vv_conv_mfma': (c_i32, [C.POINTER(ConvParams), c_vp]),
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),

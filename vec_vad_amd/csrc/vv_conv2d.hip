@@ -328,6 +328,132 @@ upsample4_kernel(const int64_t n, const float* __restrict__ src, float* __restri
   dst[e] = v * scale;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// predict_flow: nn.Conv2d(Cin, 2, 3, 1, 1) (components/misc.py:42-44), twelve of them per FlowNet2 forward on inputs of
+// up to 1026 channels.  With two output channels a 32-wide MFMA tile wastes 94 % of the matrix core and the layer is a
+// bandwidth problem: one thread per output pixel, the input halo tile staged through LDS in 32-channel chunks (read once
+// from HBM/L2), weights [tap][Cin/4][2][4] are wave-uniform and arrive through the scalar cache.
+__global__ void __launch_bounds__(VV_WG)
+conv3x3_n2_kernel(const float* __restrict__ src, const int scs, const int B, const int H, const int W, const int Cin,
+                  const float* __restrict__ wq, const int C4P, const float* __restrict__ bias, const float slope,
+                  float* __restrict__ out, const int ocs, const int tilesX, const int tilesY) {
+  constexpr int TH = 8, TW = 32, CK = 32, S = CK + 4, HH = TH + 2, HW = TW + 2;
+  __shared__ float4 lds4[HH * HW * (S / 4)];
+  float* lds = reinterpret_cast<float*>(lds4);
+  int w = blockIdx.x;
+  const int tx = w % tilesX; w /= tilesX;
+  const int ty = w % tilesY;
+  const int img = w / tilesY;
+  const int tid = threadIdx.x, r = tid / TW, c = tid % TW;
+  VVSrc s;
+  s.p0 = src; s.cs0 = scs; s.co0 = 0; s.a = s.b = nullptr; s.p1 = nullptr; s.cs1 = s.co1 = 0;
+  s.chmap = nullptr; s.csplit = 0; s.mode = VV_IN_PLAIN; s.SH = H; s.SW = W; s.B = B;
+  float a0 = 0.f, a1 = 0.f;
+  const float4* wq4 = reinterpret_cast<const float4*>(wq);
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    if (c0) __syncthreads();
+    vv_stage_tile<1, HH, HW, S, CK>(lds, s, img, ty * TH - 1, tx * TW - 1, c0, tid, (Cin + 3) & ~3);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4* pa = lds4 + ((r + t / 3) * HW + (c + t % 3)) * (S / 4);
+      const float4* pw = wq4 + ((int64_t)t * C4P + (c0 >> 2)) * 2;
+#pragma unroll
+      for (int k = 0; k < CK / 4; ++k) {
+        const float4 v = pa[k], w0 = pw[2 * k], w1 = pw[2 * k + 1];
+        a0 = fmaf(v.w, w0.w, fmaf(v.z, w0.z, fmaf(v.y, w0.y, fmaf(v.x, w0.x, a0))));
+        a1 = fmaf(v.w, w1.w, fmaf(v.z, w1.z, fmaf(v.y, w1.y, fmaf(v.x, w1.x, a1))));
+      }
+    }
+  }
+  const int oy = ty * TH + r, ox = tx * TW + c;
+  if (oy < H && ox < W) {
+    float v0 = a0 + (bias ? bias[0] : 0.f), v1 = a1 + (bias ? bias[1] : 0.f);
+    v0 = v0 > 0.f ? v0 : v0 * slope;
+    v1 = v1 > 0.f ? v1 : v1 * slope;
+    float* o = out + ((int64_t)(img * H + oy) * W + ox) * ocs;
+    o[0] = v0;
+    o[1] = v1;
+  }
+}
+
+// Same layer when the image is small and the channel count large (the H/8 ... H/64 pyramid levels: 112 .. 28k pixels x up
+// to 1026 channels): LPP lanes share one output pixel, each takes every LPP-th group of 4 input channels straight from
+// global memory (the 9x re-read of the small map is served by L2), partial sums meet in a shuffle tree.
+template <int LPP>
+__global__ void __launch_bounds__(VV_WG)
+conv3x3_n2_split_kernel(const float* __restrict__ src, const int scs, const int B, const int H, const int W, const int Cin,
+                        const float* __restrict__ wq, const int C4P, const float* __restrict__ bias, const float slope,
+                        float* __restrict__ out, const int ocs) {
+  const int64_t pix = ((int64_t)blockIdx.x * VV_WG + threadIdx.x) / LPP;
+  const int sub = threadIdx.x % LPP;
+  const int64_t npix = (int64_t)B * H * W;
+  const bool live = pix < npix;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), img = (int)(pix / ((int64_t)W * H));
+  const int C4 = (Cin + 3) >> 2;            // source pixels hold ceil4(Cin) finite floats
+  const float4* wq4 = reinterpret_cast<const float4*>(wq);
+  float a0 = 0.f, a1 = 0.f;
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+      const float4* pa = reinterpret_cast<const float4*>(src + ((int64_t)(img * H + yy) * W + xx) * scs);
+      const float4* pw = wq4 + (int64_t)t * C4P * 2;
+      for (int k = sub; k < C4; k += LPP) {
+        const float4 v = pa[k], w0 = pw[2 * k], w1 = pw[2 * k + 1];
+        a0 = fmaf(v.w, w0.w, fmaf(v.z, w0.z, fmaf(v.y, w0.y, fmaf(v.x, w0.x, a0))));
+        a1 = fmaf(v.w, w1.w, fmaf(v.z, w1.z, fmaf(v.y, w1.y, fmaf(v.x, w1.x, a1))));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o);
+    a1 += __shfl_xor(a1, o);
+  }
+  if (live && sub == 0) {
+    float v0 = a0 + (bias ? bias[0] : 0.f), v1 = a1 + (bias ? bias[1] : 0.f);
+    float* o = out + pix * ocs;
+    o[0] = v0 > 0.f ? v0 : v0 * slope;
+    o[1] = v1 > 0.f ? v1 : v1 * slope;
+  }
+}
+
+// upsampled_flow*: nn.ConvTranspose2d(2, 2, 4, 2, 1[, bias]) (FlowNetC.py:53-60, FlowNetS.py:40-47, FlowNetSD.py:45-52,
+// FlowNetFusion.py:35-36): 2x2 taps x 2 channels per output -- one thread per output pixel.
+__global__ void __launch_bounds__(VV_WG)
+deconv4x4_c2_kernel(const float* __restrict__ src, const int scs, const int B, const int H, const int W,
+                    const float* __restrict__ wt, const float* __restrict__ bias, const float slope,
+                    float* __restrict__ out, const int ocs) {
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  if (e >= (int64_t)B * OH * OW) return;
+  const int ox = (int)(e % OW), oy = (int)((e / OW) % OH), img = (int)(e / ((int64_t)OW * OH));
+  float v0 = bias ? bias[0] : 0.f, v1 = bias ? bias[1] : 0.f;
+  // oy = 2*iy - 1 + ky  ->  ky has the parity of oy+1
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ky = ((oy + 1) & 1) + 2 * a, iy = (oy + 1 - ky) >> 1;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kx = ((ox + 1) & 1) + 2 * b, ix = (ox + 1 - kx) >> 1;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float* p = src + ((int64_t)(img * H + iy) * W + ix) * scs;
+      const float x0 = p[0], x1 = p[1];
+      // weight [Cin][Cout][4][4]
+      v0 = fmaf(x0, wt[(0 * 2 + 0) * 16 + ky * 4 + kx], v0);
+      v0 = fmaf(x1, wt[(1 * 2 + 0) * 16 + ky * 4 + kx], v0);
+      v1 = fmaf(x0, wt[(0 * 2 + 1) * 16 + ky * 4 + kx], v1);
+      v1 = fmaf(x1, wt[(1 * 2 + 1) * 16 + ky * 4 + kx], v1);
+    }
+  }
+  float* o = out + e * ocs;
+  o[0] = v0 > 0.f ? v0 : v0 * slope;
+  o[1] = v1 > 0.f ? v1 : v1 * slope;
+}
+
 template <int R, int STRIDE, int DECONV, int CK>
 int launch2d(const vv_conv2d_params* p, hipStream_t st) {
   const int pad = (R - 1) / 2;
@@ -365,6 +491,39 @@ extern "C" int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream) {
     case 72: return launch2d<7, 2, 0, 8>(p, st);
   }
   return VV_ERR_UNSUPPORTED;
+}
+
+extern "C" int vv_conv3x3_n2(const float* src, int32_t src_cstride, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                             const float* wq, int32_t C4P, const float* bias, float slope, float* out, int32_t out_cstride,
+                             int32_t out_coff, vv_stream stream) {
+  if (!src || !wq || !out || src_cstride % 4 || C4P * 4 < ((Cin + 31) & ~31)) return VV_ERR_BAD_ARG;
+  if ((int64_t)B * H * W * src_cstride >= (1ll << 31)) return VV_ERR_UNSUPPORTED;
+  const int64_t npix = (int64_t)B * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (npix >= 100000) {                     // full / half resolution: enough pixels to fill the chip one per thread
+    const int tilesY = (H + 7) / 8, tilesX = (W + 31) / 32;
+    VV_LAUNCH(conv3x3_n2_kernel, dim3(B * tilesY * tilesX), dim3(VV_WG), 0, st, src, src_cstride, B, H, W, Cin, wq, C4P, bias,
+              slope, out + out_coff, out_cstride, tilesX, tilesY);
+  } else if (npix >= 4096) {
+    VV_LAUNCH(conv3x3_n2_split_kernel<8>, dim3((unsigned)((npix * 8 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,
+              src_cstride, B, H, W, Cin, wq, C4P, bias, slope, out + out_coff, out_cstride);
+  } else {
+    VV_LAUNCH(conv3x3_n2_split_kernel<64>, dim3((unsigned)((npix * 64 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,
+              src_cstride, B, H, W, Cin, wq, C4P, bias, slope, out + out_coff, out_cstride);
+  }
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_deconv4x4_c2(const float* src, int32_t src_cstride, int32_t B, int32_t H, int32_t W, const float* w,
+                               const float* bias, float slope, float* out, int32_t out_cstride, int32_t out_coff,
+                               vv_stream stream) {
+  if (!src || !w || !out) return VV_ERR_BAD_ARG;
+  const int64_t n = (int64_t)B * 4 * H * W;
+  VV_LAUNCH(deconv4x4_c2_kernel, dim3((unsigned)((n + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream, src,
+            src_cstride, B, H, W, w, bias, slope, out + out_coff, out_cstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
 }
 
 extern "C" int vv_conv2d_splitk_finish(const float* ws, int32_t ksplit, int64_t M, int32_t Cout, int32_t CoutP,

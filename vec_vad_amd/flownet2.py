@@ -132,6 +132,39 @@ class _Runner:
         self.cache[key] = (ver, packed, K, KP, N, NP)
         return packed
 
+    def _flow_head(self, m, de, src, dst, dst_coff, slope, stream):
+        """Two-channel layers (predict_flow 3x3 conv, upsampled_flow 4x4 deconv): dedicated bandwidth kernels."""
+        bias = m.bias.data_ptr() if m.bias is not None else None
+        assert m.in_channels == src.C, (m.in_channels, src.C)
+        if de:
+            if m.in_channels != 2 or m.kernel_size != (4, 4) or m.stride != (2, 2) or m.padding != (1, 1):
+                return False
+            assert (dst.H, dst.W) == (2 * src.H, 2 * src.W) and dst_coff + 2 <= dst.cs
+            w = m.weight.detach()
+            assert w.is_contiguous() and w.dtype == torch.float32
+            L.check(self.lib.vv_deconv4x4_c2(src.t.data_ptr(), src.cs, src.B, src.H, src.W, w.data_ptr(), bias, slope,
+                                             dst.t.data_ptr(), dst.cs, dst_coff, stream), 'deconv4x4_c2')
+            return True
+        if m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1):
+            return False
+        assert (dst.H, dst.W) == (src.H, src.W) and dst_coff + 2 <= dst.cs
+        key = ('n2', id(m))
+        ver = (m.weight.data_ptr(), m.weight._version)
+        ent = self.cache.get(key)
+        if ent is None or ent[0] != ver:
+            w = m.weight.detach().float()                      # [2][Cin][3][3]
+            cin = w.shape[1]
+            cp = (cin + 31) // 32 * 32
+            wq = torch.zeros(9, cp // 4, 2, 4, device=w.device, dtype=torch.float32)
+            wp = torch.zeros(2, cp, 3, 3, device=w.device, dtype=torch.float32)
+            wp[:, :cin] = w
+            wq.copy_(wp.permute(2, 3, 1, 0).reshape(9, cp // 4, 4, 2).permute(0, 1, 3, 2))
+            ent = (ver, wq.contiguous(), cp // 4)
+            self.cache[key] = ent
+        L.check(self.lib.vv_conv3x3_n2(src.t.data_ptr(), src.cs, src.B, src.H, src.W, m.in_channels, ent[1].data_ptr(), ent[2],
+                                       bias, slope, dst.t.data_ptr(), dst.cs, dst_coff, stream), 'conv3x3_n2')
+        return True
+
     def __call__(self, layer, src, dst, dst_coff=0):
         """layer: nn.Sequential(Conv2d|ConvTranspose2d[, LeakyReLU]) or a bare Conv2d / ConvTranspose2d."""
         if isinstance(layer, nn.Sequential):
@@ -139,10 +172,13 @@ class _Runner:
             slope = 0.1 if len(layer) > 1 else 1.0
         else:
             m, slope = layer, 1.0
+        de = isinstance(m, nn.ConvTranspose2d)
+        stream = torch.cuda.current_stream(src.t.device).cuda_stream
+        if m.out_channels == 2 and self._flow_head(m, de, src, dst, dst_coff, slope, stream):
+            return dst
         packed = self._packed(m)
         _, _, K, KP, N, NP = self.cache[id(m)]
         assert K == src.C, (K, src.C)
-        de = isinstance(m, nn.ConvTranspose2d)
         if de:
             assert m.kernel_size == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
             OH, OW = 2 * src.H, 2 * src.W
@@ -154,7 +190,6 @@ class _Runner:
             OH, OW = (src.H + 2 * pad - R) // stride + 1, (src.W + 2 * pad - R) // stride + 1
         assert (dst.H, dst.W) == (OH, OW), ((dst.H, dst.W), (OH, OW))
         assert dst_coff + N <= dst.cs
-        stream = torch.cuda.current_stream(src.t.device).cuda_stream
         bias = m.bias.data_ptr() if m.bias is not None else None
         # tiny-M / huge-K layers (the H/32 and H/64 levels): split the input-channel loop over workgroups
         lh, lw = (src.H, src.W) if de else (OH, OW)
