@@ -181,37 +181,65 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
       }
     }
   } else {
-  for (int c0 = cbeg; c0 < cend; c0 += CK) {
-    if (c0 != cbeg) __syncthreads();
-    vv_stage_tile<1, HH, HW, S, CK>(lds, s, img, oy0, ox0, c0, tid, p.src.cstride);
-    __syncthreads();
-#pragma unroll 1
-    for (int t = 0; t < NTAP; ++t) {
-      const int aoff = ((t / R) * HW + (t % R)) * S4, wt = t;
+    // 1x1 / 5x5 / 7x7: the activation tile is pipelined through registers like above; a chunk's weight panel (up to
+    // 100 KB for 7x7) does not fit beside it in LDS, so the B fragments come from global/L2 -- two steps ahead of their
+    // use (ring of three register sets), while the A fragments of the next step are read from LDS under the MFMAs.
+    const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
+    VVStagerB<1, HH, HW, S, CK> stA;
+    stA.init(s, ox0, tid);
+    constexpr int NST = NTAP * KGC;
+    const int tapstride = KQ * 2 * CoutP * 4;                     // floats between consecutive taps of the packed panel
+    auto rdA = [&](const int st, const int m) -> v4f {
+      const int t = st / KGC, kg = st % KGC;
+      v4f v = ldsA[abase[m] + ((t / R) * HW + (t % R)) * S4 + kg * 2];
+      asm volatile("" : "+v"(v));
+      return v;
+    };
+    if (cbeg < cend) stA.prefetch(s, img, oy0, ox0, cbeg, tid, p.src.cstride);
+    for (int c0 = cbeg; c0 < cend; c0 += CK) {
+      if (c0 != cbeg) __syncthreads();
+      stA.commit(lds, tid);
+      __syncthreads();
+      if (c0 + CK < cend) stA.prefetch(s, img, oy0, ox0, c0 + CK, tid, p.src.cstride);
+      const float* wbase = wg + ((int64_t)(((c0 >> 3)) * 2 + half) * CoutP + co0 + l31) * 4;
+      auto ldB = [&](const int st, const int n) -> float4 {
+        const int t = st / KGC, kg = st % KGC;
+        return *reinterpret_cast<const float4*>(wbase + (int64_t)t * tapstride + kg * 2 * CoutP * 4 + n * 128);
+      };
+      v4f fa[2][MR];
+      float4 fb[3][NR];
 #pragma unroll
-      for (int kg = 0; kg < CK / 8; ++kg) {
-        v4f a[MR];
-        float4 b[NR];
+      for (int m = 0; m < MR; ++m) fa[0][m] = rdA(0, m);
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          a[m] = reinterpret_cast<const v4f*>(lds4)[abase[m] + aoff + kg * 2];
-          asm volatile("" : "+v"(a[m]));
-        }
-        const float* wp = wg + ((int64_t)((wt * KQ + (c0 >> 3) + kg) * 2 + half) * CoutP + co0 + l31) * 4;
+      for (int n = 0; n < NR; ++n) {
+        fb[0][n] = ldB(0, n);
+        if (NST > 1) fb[1][n] = ldB(1, n);
+      }
 #pragma unroll
-        for (int n = 0; n < NR; ++n) b[n] = *reinterpret_cast<const float4*>(wp + n * 128);
+      for (int st = 0; st < NST; ++st) {
+        const int cur = st & 1, nxt = cur ^ 1, bc = st % 3, bn = (st + 2) % 3;
+        int piece = 0;                       // next step's A fragments, then the B fragments of step st+2
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[bc][n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[bc][n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[bc][n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[bc][n].w, acc[m][n], 0, 0, 0);
+            const int last = (m == MR - 1 && n == NR - 1);
+            do {
+              if (piece < MR) {
+                if (st + 1 < NST) fa[nxt][piece] = rdA(st + 1, piece);
+              } else if (piece < MR + NR) {
+                if (st + 2 < NST) fb[bn][piece - MR] = ldB(st + 2, piece - MR);
+              }
+              ++piece;
+            } while (last && piece < MR + NR);
+            __builtin_amdgcn_sched_barrier(0);
           }
       }
     }
-  }
   }
 
   // ---- epilogue: bias, LeakyReLU, masked NHWC store into the (possibly shared concat) output buffer
