@@ -132,6 +132,16 @@ int vv_pack_weights(const vv_pack_entry* table_dev, int32_t nentries, int32_t G,
                     int64_t params_gstride, float* packed, int64_t packed_gstride, int32_t max_elems,
                     vv_stream stream);
 
+/* ---- Winograd F(2x2,3x3) form of the same 3x3 / stride 1 / pad 1 convolution (forward and data-gradient) ----
+ * vv_conv_wino takes the vv_conv_params of a VV_CONV3 launch with `w` = panels from vv_pack_wino
+ * ([16 = xi*4+nu][CinP/8][2][Cout][4], U = G g G^T; mode 0 forward, mode 1 data-gradient i.e. flipped + transposed filter);
+ * 2.25x fewer MFMA cycles than vv_conv_mfma, fp32 throughout (results differ from the direct form by a few ulp).
+ * in_mode PLAIN / ACT / CAT; CinP % 8 == 0; `stats` has vv_wino_ntiles(B, H) rows per UNet. */
+int vv_conv_wino(const vv_conv_params* p, vv_stream stream);
+int vv_wino_ntiles(int32_t B, int32_t H);
+int vv_pack_wino(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params, int64_t params_gstride,
+                 float* packed, int64_t packed_gstride, int32_t max_kn, vv_stream stream);
+
 /* ---- BatchNorm (nn.BatchNorm2d(eps=1e-5, momentum=0.1), model/unet.py:11,14) ----
  * train != 0: batch statistics from the conv's partial sums; writes scale/shift a,b for the consumer's load,
  *             mean / invstd for the backward pass, and updates running_mean / running_var (unbiased) in place.

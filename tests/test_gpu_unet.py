@@ -221,3 +221,53 @@ def test_state_dict_roundtrip_and_move():
     assert all(torch.equal(net.state_dict()[k], sd[k]) for k in sd)
     with pytest.raises(Exception):
         net(torch.zeros(1, 15, 32, 32), torch.zeros(1, 2, 32, 32))      # no CPU fallback
+
+
+@pytest.mark.parametrize('H,Cin,Cout,B', [(32, 16, 32, 3), (32, 32, 32, 2), (16, 64, 64, 5), (8, 256, 128, 9), (4, 128, 256, 33),
+                                           (16, 32, 64, 1)])
+def test_winograd_conv_matches_direct_conv(H, Cin, Cout, B):
+    """vv_conv_wino (Winograd F(2x2,3x3) on the matrix cores) against vv_conv_mfma (direct implicit GEMM) on the same
+    tensors, forward panel and data-gradient panel, BatchNorm+ReLU-on-load input, bias and BatchNorm partial sums:
+    agreement to fp32 round-off of the transforms (ragged last workgroup: B is not a multiple of the images per tile)."""
+    import ctypes as C
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H * 1000 + Cin)
+    x = torch.randn(G, B * H * H, Cin, generator=g).cuda()
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()          # nn.Conv2d layout per group
+    bias = torch.randn(G, Cout, generator=g).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    U = Cout * Cin * 9
+
+    def pack(fn, mode, K, N, taps):
+        ent = (L.PackEntry * 1)(L.PackEntry(0, 0, mode, K, K, N))
+        tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()
+        out = torch.zeros(G, taps * K * N, device='cuda')
+        L.check(fn(tab.data_ptr(), 1, G, w.data_ptr(), U, out.data_ptr(), out.stride(0), (9 if taps == 9 else 1) * K * N, st), 'pack')
+        return out
+
+    for dgrad in (False, True):
+        K, N = (Cout, Cin) if dgrad else (Cin, Cout)
+        if N % 32:
+            continue
+        src = torch.randn(G, B * H * H, K, generator=g).cuda() if dgrad else x
+        pd, pw = pack(lib.vv_pack_weights, 1 if dgrad else 0, K, N, 9), pack(lib.vv_pack_wino, 1 if dgrad else 0, K, N, 16)
+        outs, stats = [], []
+        for fn, pk, nt in ((lib.vv_conv_mfma, pd, lib.vv_conv_ntiles(B, H, H)), (lib.vv_conv_wino, pw, lib.vv_wino_ntiles(B, H))):
+            y = torch.full((G, B * H * H, N), 3.0, device='cuda')
+            s_ = torch.zeros(G, nt, 2, N, device='cuda')
+            mode = L.IN_PLAIN if dgrad else L.IN_ACT
+            cp = L.ConvParams(L.CONV3, mode, G, B, H, H, K, K, N, L.view(src, K, 0, src.stride(0)),
+                              None if dgrad else a.data_ptr(), None if dgrad else b.data_ptr(), K, L.NULL_VIEW, 0, 0, None,
+                              pk.data_ptr(), pk.stride(0), None if dgrad else bias.data_ptr(), N, L.view(y, N, 0, y.stride(0)),
+                              None if dgrad else s_.data_ptr())
+            L.check(fn(C.byref(cp), st), 'conv')
+            outs.append(y)
+            stats.append(s_.sum(1))
+        scale = outs[0].abs().max().item()
+        assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale, (dgrad, (outs[0] - outs[1]).abs().max().item(), scale)
+        if not dgrad:
+            torch.testing.assert_close(stats[0], stats[1], rtol=2e-4, atol=2e-3)

@@ -106,7 +106,7 @@ def test_bank_layout_and_plan_construction():
     units = [UnitSpec('raw', i, i) for i in range(5)] + [UnitSpec('of', 4, 0)]
     b = UNetBank(units, nf=32, device='cpu')
     ws = b.workspace(5)
-    assert len(ws.fwd[True].calls) == 37      # pack, cube_erase, 14 x (conv + bn), 3 pool, 3 convT, 1x1 out
+    assert len(ws.fwd[True].calls) == 37 + int(b.wino)   # pack (+ pack_wino), cube_erase, 14 x (conv + bn), 3 pool, 3 convT, 1x1 out
     ws.bwd = b._plan_backward(ws, 5)
     labels = [c[2] for c in ws.bwd.calls]
     assert labels.index('dgradT0') < labels.index('bn_bwd_reduce7')      # decoder bucket is complete before the encoder

@@ -76,6 +76,9 @@ _SIGS = {
     'vv_deconv4x4_c2': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_vp]),
     'vv_upsample4': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     'vv_conv_mfma': (c_i32, [C.POINTER(ConvParams), c_vp]),
+    'vv_conv_wino': (c_i32, [C.POINTER(ConvParams), c_vp]),
+    'vv_wino_ntiles': (c_i32, [c_i32, c_i32]),
+    'vv_pack_wino': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
     'vv_wgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),

@@ -15,6 +15,7 @@ Reference semantics implemented (paths relative to the reference root):
 """
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -110,6 +111,12 @@ class BankLayout:
         for u, (_, _, ci, co) in enumerate(self.convT):
             self.pk['t%d.f' % u] = (off, 2, ci, ci, co, 't%d.w' % u); off += 9 * ci * co
             self.pk['t%d.d' % u] = (off, 3, co, co, ci, 't%d.w' % u); off += 9 * ci * co
+        # Winograd F(2x2,3x3) panels of the 3x3 convolutions (16 transformed taps; vv_pack_wino): mode 0 forward, 1 dgrad
+        self.pkw = OrderedDict()
+        for l in Ls:
+            self.pkw['c%d.f' % l.idx] = (off, 0, l.cin, l.cinp, l.cout, 'c%d.w' % l.idx); off += 16 * l.cinp * l.cout
+            if l.idx > 0:
+                self.pkw['c%d.d' % l.idx] = (off, 1, l.cout, l.cout, l.cin, 'c%d.w' % l.idx); off += 16 * l.cout * l.cin
         self.UP = _ceil(off, 4)
         self.cmax = 8 * nf
 
@@ -197,19 +204,30 @@ class UNetBank:
             tsrc[g] = 0 if u.role == 'raw' else 1
             tcoff[g] = u.tgt * (RAW_C if u.role == 'raw' else OF_C)
         self.chmap, self.oc, self.tsrc, self.tcoff = chmap.to(d), oc.to(d), tsrc.to(d), tcoff.to(d)
-        ents = (L.PackEntry * len(lay.pk))()
+        # VV_WINOGRAD=0 keeps the direct implicit-GEMM kernel for the 3x3 convolutions (A/B comparisons, bit-for-bit fmaf
+        # chains); default: Winograd F(2x2,3x3) for forward and data-gradient (2.25x fewer MFMA cycles, a few ulp apart)
+        self.wino = os.environ.get('VV_WINOGRAD', '1') != '0'
+        direct = [(k, v) for k, v in lay.pk.items() if not (self.wino and k[0] == 'c')]
+        ents = (L.PackEntry * len(direct))()
         mx = 0
-        for i, (k, (off, mode, K, KP, N, src)) in enumerate(lay.pk.items()):
+        for i, (k, (off, mode, K, KP, N, src)) in enumerate(direct):
             ents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
             mx = max(mx, 9 * KP * N)
         self.pack_table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(d)
-        self.pack_n, self.pack_max = len(lay.pk), mx
+        self.pack_n, self.pack_max = len(direct), mx
+        wents = (L.PackEntry * len(lay.pkw))()
+        wmx = 0
+        for i, (k, (off, mode, K, KP, N, src)) in enumerate(lay.pkw.items()):
+            wents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
+            wmx = max(wmx, KP * N)
+        self.pack_table_w = torch.frombuffer(bytearray(bytes(wents)), dtype=torch.uint8).to(d)
+        self.pack_w_n, self.pack_w_max = len(lay.pkw), wmx
 
     def to(self, device):
         device = torch.device(device)
         if device == self.device:
             return self
-        for n in ('params', 'bufs', 'grads', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table'):
+        for n in ('params', 'bufs', 'grads', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table', 'pack_table_w'):
             setattr(self, n, getattr(self, n).to(device))
         if self.adam_m is not None:
             self.adam_m, self.adam_v = self.adam_m.to(device), self.adam_v.to(device)
@@ -261,7 +279,7 @@ class UNetBank:
         ws.t = [f(Ga, B * (2 * H) * (2 * H), co) for (_, H, ci, co) in lay.convT]
         ws.pooled = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.mode == L.IN_POOL}
         ws.erased = f(Ga, B * HWp, lay.convs[0].cinp)
-        nt = [lib.vv_conv_ntiles(B, l.H, l.H) for l in lay.convs]
+        nt = [max(lib.vv_conv_ntiles(B, l.H, l.H), lib.vv_wino_ntiles(B, l.H)) for l in lay.convs]
         ws.stats = f(Ga, max(n * 2 * l.cout for n, l in zip(nt, lay.convs)))
         ws.ab = torch.zeros(4, len(lay.convs), Ga, lay.cmax, device=d)
         ws.out4 = f(Ga, B * HWp, 4)
@@ -306,17 +324,21 @@ class UNetBank:
         P = _Plan()
         pbase, bbase, kbase = self._p(self.params, g0 * U), self._p(self.bufs, g0 * UB), self._p(self.packed, g0 * UP)
         P.add(lib.vv_pack_weights, (self.pack_table.data_ptr(), self.pack_n, Ga, pbase, U, kbase, UP, self.pack_max), 'pack')
+        if self.wino:
+            P.add(lib.vv_pack_wino, (self.pack_table_w.data_ptr(), self.pack_w_n, Ga, pbase, U, kbase, UP, self.pack_w_max),
+                  'pack_wino')
         abg = lay.cmax
 
         def conv(l):
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             y = ws.y[l.idx]
+            panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
             cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, 0, chmap,
-                              kbase + 4 * lay.pk['c%d.f' % l.idx][0], UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
+                              kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
-            P.add(lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
-            nt = lib.vv_conv_ntiles(B, l.H, l.H)
+            P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
+            nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles(B, l.H, l.H)
             P.add(lib.vv_bn_finalize,
                   (Ga, l.cout, nt, B * l.H * l.H, 1 if train else 0, 0.1, 1e-5, ws.stats.data_ptr(), nt * 2 * l.cout,
                    pbase + 4 * lay.p['c%d.g' % l.idx][0], pbase + 4 * lay.p['c%d.beta' % l.idx][0], U,
@@ -451,10 +473,12 @@ class UNetBank:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, 0, None,
-                                  kbase + 4 * lay.pk['c%d.d' % i][0], UP, None, 0, L.view(Dl, l.cin, 0, Dl.stride(0)), None)
+                                  kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
+                                  L.view(Dl, l.cin, 0, Dl.stride(0)), None)
                 P.keep.append(cp)
                 # paired schedule: the MFMA data-gradient runs alone (the side stream has drained) ...
-                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i, pwait=('*side',))
+                P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i,
+                      pwait=('*side',))
             # weight gradient (side stream: only depends on dy_i and forward products).  Paired schedule: ... and the
             # weight-gradient starts when it is done, sharing the chip with the HBM-bound BatchNorm backward of the
             # next layer only.
