@@ -8,8 +8,9 @@
 // Cout): 16 MFMA-K steps per 4 output pixels instead of 36 for the direct form (2.25x fewer matrix-core cycles).  All in fp32;
 // the transforms only add / subtract and halve, so the result differs from the direct convolution by a few ulp.
 //
-// One workgroup = 512 threads = 8 waves = 128 tiles (512 output pixels) x 32 output channels of one UNet.
-//   wave = (tile group tg = 0..3 of 32 tiles) x (xi half xh): its 8 GEMMs (xi in {2xh, 2xh+1}, nu = 0..3) live in 128
+// One workgroup = 256 threads = 4 waves = 64 tiles (256 output pixels) x 32 output channels of one UNet, two workgroups
+// per CU (<= 256 registers per lane) so that one's staging / epilogue phases run under the other's MFMAs.
+//   wave = (tile group tg = 0..1 of 32 tiles) x (xi half xh): its 8 GEMMs (xi in {2xh, 2xh+1}, nu = 0..3) live in 128
 //   accumulator registers; lane l owns tile l&31, channel half l>>5 (A operand) / output channel l&31 (B operand, result).
 //   Input halo tile [NI][HH][HW][8+4] and the chunk's transformed filter panel [16][2][32] float4 go
 //   global -> registers -> LDS one 8-channel chunk ahead (the producer's BatchNorm+ReLU is applied on the way in, like in
@@ -21,21 +22,23 @@
 
 namespace {
 
-constexpr int WN = 512;   // threads per workgroup
+constexpr int NTG = 2;                 // tile groups (of 32 tiles) per workgroup
+constexpr int WN = NTG * 2 * 64;       // threads per workgroup: (tile group) x (xi half) waves
+constexpr int WT = NTG * 32;           // tiles per workgroup
 
 template <int H_>
 struct WGeo {
   static constexpr int TPI = H_ / 2;                       // tiles per image side
   static constexpr int TP = TPI * TPI;                     // tiles per image
-  static constexpr int TPW = TP < 128 ? TP : 128;          // tiles of one image handled by one workgroup
-  static constexpr int NI = 128 / TPW;                     // images per workgroup
-  static constexpr int PARTS = TP / TPW;                   // workgroups per image (H=32: 2)
+  static constexpr int TPW = TP < WT ? TP : WT;          // tiles of one image handled by one workgroup
+  static constexpr int NI = WT / TPW;                     // images per workgroup
+  static constexpr int PARTS = TP / TPW;                   // workgroups per image
   static constexpr int TROWS = TPW / TPI;                  // tile rows per part
   static constexpr int HH = 2 * TROWS + 2, HW = H_ + 2;
 };
 
 template <int H_>
-__global__ void __launch_bounds__(WN, 1)
+__global__ void __launch_bounds__(WN, 2)
 wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = WGeo<H_>;
   constexpr int TPI = G_::TPI, TPW = G_::TPW, NI = G_::NI, PARTS = G_::PARTS, HH = G_::HH, HW = G_::HW, HWH = HW / 2;
@@ -45,7 +48,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr int NITEMS = NI * HH * HW * Q;
   constexpr int NIT = (NITEMS + WN - 1) / WN;
   constexpr int NBT = B4 / WN;
-  constexpr int EX4 = 4 * 4 * 16 * 64 / 4;                 // epilogue exchange: [tg][2x2][16 regs][64 lanes] floats
+  constexpr int EX4 = NTG * 4 * 16 * 64 / 4;               // epilogue exchange: [tg][2x2][16 regs][64 lanes] floats
   constexpr int LDS4 = (A4 + B4) > EX4 ? (A4 + B4) : EX4;
   static_assert(B4 % WN == 0 && WN % Q == 0, "staging geometry");
   __shared__ float4 lds4[LDS4];
@@ -146,9 +149,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   // patch pixel (a, b): halo row 2*tyl + a, halo column 2*tx + b -> plane (b & 1), slot tx + (b >> 1)
   const int pbase = ((tim * HH + 2 * tyl) * HW + tx) * S4 + half;
   auto patch = [&](const int a, const int b) -> v4f {
-    v4f v = ldsA[pbase + (a * HW + (b & 1) * HWH + (b >> 1)) * S4];
-    asm volatile("" : "+v"(v));
-    return v;
+    return ldsA[pbase + (a * HW + (b & 1) * HWH + (b >> 1)) * S4];
   };
 
   v16f acc[2][4];
@@ -184,8 +185,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       V[3] = R[1] - R[3];
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        v4f u = ldsB[((xi * 4 + n) * 2 + half) * 32 + l31];
-        asm volatile("" : "+v"(u));
+        const v4f u = ldsB[((xi * 4 + n) * 2 + half) * 32 + l31];
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u.x, acc[x][n], 0, 0, 0);
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u.y, acc[x][n], 0, 0, 0);
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u.z, acc[x][n], 0, 0, 0);
@@ -246,12 +246,16 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     s2 += __shfl_xor(s2, 32);
     if (xh == 0 && half == 0) {
       lds[tg * 32 + l31] = s1;
-      lds[128 + tg * 32 + l31] = s2;
+      lds[NTG * 32 + tg * 32 + l31] = s2;
     }
     __syncthreads();
     if (tid < 32) {
-      const float t1 = lds[tid] + lds[32 + tid] + lds[64 + tid] + lds[96 + tid];
-      const float t2 = lds[128 + tid] + lds[160 + tid] + lds[192 + tid] + lds[224 + tid];
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NTG; ++k) {
+        t1 += lds[k * 32 + tid];
+        t2 += lds[NTG * 32 + k * 32 + tid];
+      }
       float* st = p.stats + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
       st[0] = t1;
       st[Cout] = t2;
