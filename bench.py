@@ -48,7 +48,8 @@ def pmc_traffic():
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed."""
     p = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
     try:
-        return json.load(open(p))['conv_mfma_family']['hbm_bytes_per_launch_corrected']
+        d = json.load(open(p))
+        return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected']
     except Exception:
         return None
 
@@ -229,12 +230,18 @@ def main():
                    'forward_ms': fwd_ms, 'forward_tflops_per_gpu': B * fwd_flop_per_cube / (fwd_ms * 1e-3) / 1e12,
                    'forward_frac_of_fp32_mfma_peak': B * fwd_flop_per_cube / (fwd_ms * 1e-3) / FP32_MFMA_PEAK,
                    'loss_raw': loss_now[0], 'loss_of': loss_now[1]},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 implicit-GEMM, forward + data-gradient launches)',
+        'roofline': {'bound': 'mfma',
+                     'kernel': ('wino_conv_kernel (3x3 conv as Winograd F(2x2,3x3) on MFMA, forward + data-gradient launches): '
+                                'achieved = ALGORITHMIC (direct-convolution) FLOP / time, so it can exceed the peak; '
+                                'executed_* = the 2.25x fewer multiply-adds the matrix cores actually run')
+                     if bank.wino else 'conv_mfma_kernel (3x3 implicit-GEMM, forward + data-gradient launches)',
                      'achieved': (conv_f / conv_t / 1e12) if conv_t > 0 else None, 'peak': FP32_MFMA_PEAK / 1e12,
                      'unit': 'TFLOP/s', 'frac': (conv_f / conv_t / FP32_MFMA_PEAK) if conv_t > 0 else None,
                      'traffic': pmc_traffic(), 'launches_timed': conv_n,
                      'avg_launch_us': (1e6 * conv_t / conv_n) if conv_n else None,
                      'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None,
+                     'executed_tflops': (conv_f / conv_t / 1e12 / (2.25 if bank.wino else 1.0)) if conv_t > 0 else None,
+                     'executed_frac': (conv_f / conv_t / FP32_MFMA_PEAK / (2.25 if bank.wino else 1.0)) if conv_t > 0 else None,
                      'side_stream_weight_grad': args.overlap,
                      'isolated_frac': (iso_f / iso_t / FP32_MFMA_PEAK) if iso_t > 0 else None},
     }
