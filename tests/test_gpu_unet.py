@@ -271,3 +271,36 @@ def test_winograd_conv_matches_direct_conv(H, Cin, Cout, B):
         assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale, (dgrad, (outs[0] - outs[1]).abs().max().item(), scale)
         if not dgrad:
             torch.testing.assert_close(stats[0], stats[1], rtol=2e-4, atol=2e-3)
+
+
+def test_full_bank_b512_linearity_and_determinism():
+    """BASELINE config 4 size (SelfCompleteNetFull = 10 UNets, B = 512, fp32): size-independent properties of the whole
+    backward pass -- it is linear in d(loss)/d(out) (doubling dout doubles every gradient bit for bit: scaling by 2 is exact
+    in fp32 and the reductions run in a fixed order), it is run-to-run deterministic, and the loss / per-cube scores of the
+    forward agree with the oracle on a few cubes of the batch."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    net, sd, tot_of = _build('full', False)
+    raw, flow = O.seeded_cubes(512, tot_of, 3, smooth=False)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    # eval-mode scores of the first cubes vs the oracle (batch independent in eval mode; before any train-mode forward moves
+    # the BatchNorm running statistics)
+    net.eval()
+    r, o = FusedTrainer(net, reset_optimizer=False).score_cubes(rawd, flowd)
+    x, x_of = O.cubes_to_inputs(raw[:3], flow[:3])
+    rs, os_ = O.score_pass(sd, O.bank_spec('full'), x, x_of, 3)
+    np.testing.assert_allclose(r[:3].cpu().numpy(), rs, rtol=1e-3)
+    np.testing.assert_allclose(o[:3].cpu().numpy(), os_, rtol=1e-3)
+    net.train()
+    bank = net.bank()
+    ws = bank.set_input_cubes(rawd, flowd, None, 512)
+    bank.forward(ws, True)
+    bank.backward(ws)
+    g1 = bank.grads.clone()
+    bank.backward(ws)
+    assert torch.equal(bank.grads, g1)                      # deterministic
+    ws.dout4.mul_(2.0)
+    bank.backward(ws)
+    g2 = bank.grads.clone()
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert torch.equal(g2, 2.0 * g1)                        # linear, bit for bit
