@@ -24,7 +24,7 @@ struct Geo {
 };
 
 template <int TH, int TW, int NI, int NR, int KIND, int CK>
-__global__ void __launch_bounds__(VV_WG, (NR == 1 ? 3 : 2))
+__global__ void __launch_bounds__(VV_WG, ((NR == 1 && KIND != VV_CONVT_FWD) ? 3 : 2))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
@@ -46,10 +46,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   if (w >= total) return;
   const int pt = w % NT; w /= NT;
   const int nn = w % NN; w /= NN;
-  constexpr int NPH = KIND == VV_CONVT_FWD ? 4 : 1;
-  const int ph = w % NPH;
-  const int g = w / NPH;
-  const int py = ph >> 1, px = ph & 1;
+  const int g = w;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int H = p.H, W = p.W;
@@ -77,11 +74,15 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     abase[m] = ((im * HH + r * SP) * HW + c * SP) * S4 + half;
   }
 
-  v16f acc[MR][NR];
+  // transposed conv: one accumulator set per output parity phase (py, px) -- all 9 taps of a chunk run in ONE workgroup,
+  // each tap feeding the phase it belongs to, so the staged tile + weight panel serve 9 taps like in the 3x3 conv
+  constexpr int NACC = KIND == VV_CONVT_FWD ? 4 : NR;
+  static_assert(KIND != VV_CONVT_FWD || NR == 1, "transposed conv forward: 32-wide N tiles");
+  v16f acc[MR][NACC];
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int n = 0; n < NR; ++n)
+    for (int n = 0; n < NACC; ++n)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
@@ -118,10 +119,6 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
   };
 
-  // tap ranges
-  const int nty = KIND == VV_CONVT_FWD ? (py ? 2 : 1) : 3;
-  const int ntx = KIND == VV_CONVT_FWD ? (px ? 2 : 1) : 3;
-
   issue(0);
   for (int c0 = 0; c0 < CinP; c0 += CK) {
     if (c0) __syncthreads();            // every wave finished reading the previous chunk
@@ -129,31 +126,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     __syncthreads();
     if (c0 + CK < CinP) issue(c0 + CK);
 
-    if constexpr (KIND == VV_CONVT_FWD) {
-      // output parity phase (py,px): oy = 2*iy - 1 + ky  ->  py=0: ky=1 (iy=r) ; py=1: ky=2 (iy=r), ky=0 (iy=r+1)
-      for (int ty = 0; ty < nty; ++ty)
-        for (int tx = 0; tx < ntx; ++tx) {
-          const int ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1;
-          const int aoff = (ty * HW + tx) * S4, wt = ky * 3 + kx;
-#pragma unroll
-          for (int kg = 0; kg < KGC; ++kg) {
-            v4f a[MR], b[NR];
-#pragma unroll
-            for (int m = 0; m < MR; ++m) { a[m] = ldsA[abase[m] + aoff + kg * 2]; asm volatile("" : "+v"(a[m])); }
-#pragma unroll
-            for (int n = 0; n < NR; ++n) { b[n] = ldsB[((wt * KGC + kg) * 2 + half) * TN + n * 32 + l31]; asm volatile("" : "+v"(b[n])); }
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-#pragma unroll
-              for (int n = 0; n < NR; ++n) {
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
-              }
-          }
-        }
-    } else {
+    {
       // 9 taps x CK/8 channel groups, fully unrolled.  The A / B fragments of step it+1 are read from LDS while step it
       // runs: one ds_read_b128 after each group of 4 MFMAs (pinned with sched_barrier), never a block of LDS issue
       // slots in front of the matrix pipe and never a read that is waited on right after it was issued.
@@ -161,7 +134,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       v4f fa[2][MR], fb[2][NR];
       auto rdA = [&](const int it, const int m) -> v4f {
         const int tap = it / KGC, kg = it % KGC;
-        v4f v = ldsA[abase[m] + ((tap / 3) * HW + (tap % 3)) * S4 + kg * 2];
+        // transposed conv: oy = 2*iy - 1 + ky  ->  ky = 1: iy = r (even rows), ky = 2: iy = r, ky = 0: iy = r + 1 (odd rows)
+        const int dy = KIND == VV_CONVT_FWD ? (tap / 3 == 0) : tap / 3, dx = KIND == VV_CONVT_FWD ? (tap % 3 == 0) : tap % 3;
+        v4f v = ldsA[abase[m] + (dy * HW + dx) * S4 + kg * 2];
         asm volatile("" : "+v"(v));
         return v;
       };
@@ -179,14 +154,17 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       for (int it = 0; it < NIT; ++it) {
         const int cur = it & 1, nxt = cur ^ 1;
         int piece = 0;                       // pieces of the next step's fragments: A[0..MR), then B[0..NR)
+        const int tapc = it / KGC;
+        const int phc = ((tapc / 3 != 1) ? 2 : 0) + ((tapc % 3 != 1) ? 1 : 0);   // output phase of this tap (transposed conv)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[cur][n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[cur][n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][n], 0, 0, 0);
+            const int an = KIND == VV_CONVT_FWD ? phc : n;
+            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[cur][n].x, acc[m][an], 0, 0, 0);
+            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[cur][n].y, acc[m][an], 0, 0, 0);
+            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][an], 0, 0, 0);
+            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][an], 0, 0, 0);
             if (it + 1 < NIT) {
               const int last = (m == MR - 1 && n == NR - 1);
               // spread MR+NR reads over MR*NR MFMA groups (the last group takes whatever is left)
@@ -221,14 +199,18 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
       const int img = img0 + im;
       if (img < p.B) {
-        const int oy = KIND == VV_CONVT_FWD ? 2 * (ty0 + r) + py : ty0 + r;
-        const int ox = KIND == VV_CONVT_FWD ? 2 * (tx0 + c) + px : tx0 + c;
-        float* o = outg + ((int64_t)(img * OH + oy) * OW + ox) * ocs + co0 + l31;
+        if constexpr (KIND == VV_CONVT_FWD) {
+          float* o = outg + ((int64_t)(img * OH + 2 * (ty0 + r)) * OW + 2 * (tx0 + c)) * ocs + co0 + l31;
 #pragma unroll
-        for (int n = 0; n < NR; ++n) {
-          const float v = acc[m][n][i] + bias[n];
-          o[n * 32] = v;
-          s1[n] += v; s2[n] = fmaf(v, v, s2[n]);
+          for (int ph = 0; ph < 4; ++ph) o[((ph >> 1) * OW + (ph & 1)) * ocs] = acc[m][ph][i] + bias[0];
+        } else {
+          float* o = outg + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs + co0 + l31;
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            const float v = acc[m][n][i] + bias[n];
+            o[n * 32] = v;
+            s1[n] += v; s2[n] = fmaf(v, v, s2[n]);
+          }
         }
       }
     }
@@ -274,8 +256,7 @@ template <int TH, int TW, int NI, int NR, int KIND, int CK>
 int launch(const vv_conv_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NN = p->Cout / (NR * 32);
-  const int NPH = KIND == VV_CONVT_FWD ? 4 : 1;
-  const int total = p->G * NPH * NN * NT;
+  const int total = p->G * NN * NT;
   const int nper = (total + 7) / 8;
   VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
                      total, nper);
@@ -290,14 +271,22 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   // 64-wide N tiles halve the activation re-staging but also halve the workgroup count; with 2 workgroups per CU
   // (512 slots) a launch needs >= 2 full rounds of them, otherwise 32-wide tiles fill the machine better.
   const int nt = ((p->B + t.NI - 1) / t.NI) * (p->H / t.TH) * (p->W / t.TW);
-  const int nph = KIND == VV_CONVT_FWD ? 4 : 1;
-  const bool wide = (p->Cout % 64) == 0 && (int64_t)p->G * nph * nt * (p->Cout / 64) >= 1024;
+  const bool wide = KIND != VV_CONVT_FWD && (p->Cout % 64) == 0 && (int64_t)p->G * nt * (p->Cout / 64) >= 1024;
   constexpr int CKD = KIND == VV_CONVT_DGRAD ? 8 : 16;
-  switch (p->H) {
-    case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD>(p, st) : launch<8, 32, 1, 1, KIND, CKD>(p, st);
-    case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD>(p, st) : launch<16, 16, 1, 1, KIND, CKD>(p, st);
-    case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD>(p, st) : launch<8, 8, 4, 1, KIND, CKD>(p, st);
-    case 4: return wide ? launch<4, 4, 16, 2, KIND, 8>(p, st) : launch<4, 4, 16, 1, KIND, 8>(p, st);   // 16 images x 6x6 halo: small chunks
+  if constexpr (KIND == VV_CONVT_FWD) {        // four phase accumulators: 32-wide N tiles only
+    switch (p->H) {
+      case 32: return launch<8, 32, 1, 1, KIND, CKD>(p, st);
+      case 16: return launch<16, 16, 1, 1, KIND, CKD>(p, st);
+      case 8: return launch<8, 8, 4, 1, KIND, CKD>(p, st);
+      case 4: return launch<4, 4, 16, 1, KIND, 8>(p, st);
+    }
+  } else {
+    switch (p->H) {
+      case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD>(p, st) : launch<8, 32, 1, 1, KIND, CKD>(p, st);
+      case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD>(p, st) : launch<16, 16, 1, 1, KIND, CKD>(p, st);
+      case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD>(p, st) : launch<8, 8, 4, 1, KIND, CKD>(p, st);
+      case 4: return wide ? launch<4, 4, 16, 2, KIND, 8>(p, st) : launch<4, 4, 16, 1, KIND, 8>(p, st);   // 16 images x 6x6 halo: small chunks
+    }
   }
   return VV_ERR_UNSUPPORTED;
 }
