@@ -39,6 +39,30 @@ pack_weights_kernel(const vv_pack_entry* __restrict__ table, const float* __rest
   }
 }
 
+// Sum of the per-tile partials [n][2][C] of one channel over tiles part, part+8, ...: four independent fp64 accumulators so
+// that the (L2-resident, latency-bound) loads of consecutive tiles overlap.  Fixed order -> deterministic.
+__device__ __forceinline__ void vv_sum_partials(const float* __restrict__ st, const int n, const int C, const int part,
+                                                double& s1, double& s2) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  const int64_t step = (int64_t)2 * C;
+  int t = part;
+  for (; t + 24 < n; t += 32) {
+    const float* q = st + t * step;
+    const float x0 = q[0], y0 = q[C], x1 = q[8 * step], y1 = q[8 * step + C];
+    const float x2 = q[16 * step], y2 = q[16 * step + C], x3 = q[24 * step], y3 = q[24 * step + C];
+    a0 += (double)x0; b0 += (double)y0;
+    a1 += (double)x1; b1 += (double)y1;
+    a2 += (double)x2; b2 += (double)y2;
+    a3 += (double)x3; b3 += (double)y3;
+  }
+  for (; t < n; t += 8) {
+    a0 += (double)st[t * step];
+    b0 += (double)st[t * step + C];
+  }
+  s1 = (a0 + a1) + (a2 + a3);
+  s2 = (b0 + b1) + (b2 + b3);
+}
+
 // ------------------------------------------------------------------------------------------------ BN finalise
 // grid (C/32, G); 256 threads = 32 channels x 8 partial-sum lanes; fp64 accumulation of the fp32 tile partials.
 __global__ void __launch_bounds__(VV_WG)
@@ -56,10 +80,7 @@ bn_finalize_kernel(const int C, const int ntiles, const double count, const int 
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
       const float* st = stats + (int64_t)g * stats_gstride + c;
-      for (int t = part; t < ntiles; t += 8) {
-        s1 += (double)st[(int64_t)t * 2 * C];
-        s2 += (double)st[(int64_t)t * 2 * C + C];
-      }
+      vv_sum_partials(st, ntiles, C, part, s1, s2);
     }
     sh[0][part][cl] = s1;
     sh[1][part][cl] = s2;
@@ -212,10 +233,7 @@ bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __re
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float* st = partial + (int64_t)g * nblk * 2 * C + c;
-    for (int t = part; t < nblk; t += 8) {
-      s1 += (double)st[(int64_t)t * 2 * C];
-      s2 += (double)st[(int64_t)t * 2 * C + C];
-    }
+    vv_sum_partials(st, nblk, C, part, s1, s2);
   }
   sh[0][part][cl] = s1;
   sh[1][part][cl] = s2;
