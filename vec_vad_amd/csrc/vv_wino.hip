@@ -270,14 +270,19 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 __global__ void __launch_bounds__(VV_WG)
 wino_pack_kernel(const vv_pack_entry* __restrict__ table, const float* __restrict__ params, const int64_t params_gstride,
                  float* __restrict__ packed, const int64_t packed_gstride) {
+  // one workgroup = one 8-channel K group (kq) x 32 output channels: 256 (k, n) filters, one per thread.  Reads run along k
+  // (8 filters = 288 contiguous bytes per n), the 16 transformed taps are exchanged through LDS so that every tap leaves as
+  // two contiguous 512-byte runs [half][n][4].
+  __shared__ float ex[16][256];
   const vv_pack_entry e = table[blockIdx.y];
   const int g = blockIdx.z;
-  const int total = 4 * e.KP * e.N;                        // one thread per (k, n): all 16 transformed taps
   const float* src = params + (int64_t)g * params_gstride + e.src_off;
   float* dst = packed + (int64_t)g * packed_gstride + e.dst_off;
-  const int KQ = e.KP >> 3;
-  for (int d = blockIdx.x * VV_WG + threadIdx.x; d < e.KP * e.N; d += gridDim.x * VV_WG) {
-    const int n = d % e.N, k = d / e.N;
+  const int KQ = e.KP >> 3, NB = e.N >> 5;
+  const int t = threadIdx.x, kl = t & 7, nl = t >> 3;
+  for (int blk = blockIdx.x; blk < KQ * NB; blk += gridDim.x) {
+    const int kq = blk / NB, nb = blk % NB;
+    const int k = kq * 8 + kl, n = nb * 32 + nl;
     float gk[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -288,26 +293,29 @@ wino_pack_kernel(const vv_pack_entry* __restrict__ table, const float* __restric
                                      : src[((int64_t)k * e.N + n) * 9 + (2 - a) * 3 + (2 - b)];
         gk[a][b] = v;
       }
-    float t[4][3];
+    float r[4][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      t[0][b] = gk[0][b];
-      t[1][b] = 0.5f * (gk[0][b] + gk[1][b] + gk[2][b]);
-      t[2][b] = 0.5f * (gk[0][b] - gk[1][b] + gk[2][b]);
-      t[3][b] = gk[2][b];
+      r[0][b] = gk[0][b];
+      r[1][b] = 0.5f * (gk[0][b] + gk[1][b] + gk[2][b]);
+      r[2][b] = 0.5f * (gk[0][b] - gk[1][b] + gk[2][b]);
+      r[3][b] = gk[2][b];
     }
-    const int kq = k >> 3, hf = (k >> 2) & 1, j = k & 3;
+    const int slot = (kl >> 2) * 128 + nl * 4 + (kl & 3);          // [half][n][j]
+    __syncthreads();                                               // previous block's exchange fully read
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) {
-      const float u0 = t[xi][0], u1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), u2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]),
-                  u3 = t[xi][2];
-      const float u[4] = {u0, u1, u2, u3};
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu)
-        dst[((((int64_t)(xi * 4 + nu) * KQ + kq) * 2 + hf) * e.N + n) * 4 + j] = u[nu];
+      ex[xi * 4 + 0][slot] = r[xi][0];
+      ex[xi * 4 + 1][slot] = 0.5f * (r[xi][0] + r[xi][1] + r[xi][2]);
+      ex[xi * 4 + 2][slot] = 0.5f * (r[xi][0] - r[xi][1] + r[xi][2]);
+      ex[xi * 4 + 3][slot] = r[xi][2];
     }
+    __syncthreads();
+    const int hf = t >> 7, rem = t & 127;
+#pragma unroll
+    for (int xn = 0; xn < 16; ++xn)
+      dst[((((int64_t)xn * KQ + kq) * 2 + hf) * e.N + nb * 32) * 4 + rem] = ex[xn][t];
   }
-  (void)total;
 }
 
 template <int H_>
