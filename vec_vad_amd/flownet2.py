@@ -11,6 +11,7 @@ views, packing 12/11-channel network inputs) uses torch tensor ops.  No torch.nn
 ``with_bn`` must be False and ``fp16`` False (what VEC_VAD instantiates, flownet2.py:12-17).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -197,7 +198,7 @@ class _Runner:
         nchunk = KP // (16 if (de or stride == 1) else 8)
         ks = 1
         if wgs < 256 and nchunk >= 4:
-            ks = max(1, min(nchunk // 2, 512 // wgs, 32))
+            ks = max(1, min(nchunk // 2, 512 // wgs, 16))
         if ks > 1:
             M = src.B * OH * OW
             ws = torch.empty(ks * M * NP, device=src.t.device, dtype=torch.float32)
