@@ -169,6 +169,10 @@ class UNetBank:
         self.nf, self.tot_raw, self.tot_of, self.padding = nf, tot_raw_num, tot_of_num, padding
         if nf % 32:
             raise L.VecVadHipError('features_root must be a multiple of 32 for the MFMA tiles (got %d)' % nf)
+        if nf != 32:
+            raise L.VecVadHipError('features_root = %d: only nf = 32 (the value of every shipped config.cfg) is implemented -- the '
+                                   'fused 1x1 output conv + loss kernel and the BatchNorm-backward kernels are specialised for it '
+                                   '(C = 32 / C <= 256)' % nf)
         self.in_ch = RAW_C * (tot_raw_num if padding else tot_raw_num - 1)
         self.lay = BankLayout(nf, self.in_ch)
         self.g0, self.Ga = active if active is not None else (0, self.G)
