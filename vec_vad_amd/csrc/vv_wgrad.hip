@@ -225,6 +225,201 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   for (int j = 0; j < 9; ++j) out[tid + j * VV_WG] = l4[tid + j * VV_WG];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) weight gradient of the 3x3 / stride 1 / pad 1 convolution:
+//     dU[xi,nu][ci][co] = sum over 2x2 output tiles of  V[xi,nu][tile][ci] * dM[xi,nu][tile][co],     dg = G^T dU G
+// with V = B^T d B (the forward's input transform of the 4x4 input patch) and dM = A dY A^T (the 2x2 output gradients of the
+// tile): 16 multiply-adds per tile (4 pixels) and (ci, co) pair instead of 36 -- 2.25x fewer MFMA cycles than the direct form
+// above.  Same workgroup / staging structure (32 ci x 32 co x k-split, 4 waves over the tiles of each staged pixel tile, two
+// LDS buffers, staging of the next tile interleaved into the MFMA stream), but the GEMM-K index is the 2x2 tile: lanes 0-31
+// take tile 2j, lanes 32-63 tile 2j+1, lane&31 = channel, so both operands are built per lane from ds_read_b32 (conflict
+// free: consecutive lanes = consecutive channels): one xi row of V (8 patch reads, 8 adds) and of dM (<= 5 ops) per group
+// of 4 MFMAs, written into the registers of the row that was consumed one group earlier.  The 16 accumulators (256
+// registers) are folded to the 9 filter taps in the epilogue (dg = G^T dU G is linear, so it commutes with the k-split
+// sum) and leave through the same slab / vv_wgrad_reduce path as the direct kernel.
+template <int TH, int TW, int NI>
+__global__ void __launch_bounds__(VV_WG, 1)
+wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+  constexpr int AHH = TH + 2, AHW = TW + 2;
+  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * TH * TW * 32, TSZ = ASZ + BSZ;
+  static_assert(2 * TSZ * 4 <= 160 * 1024, "two LDS buffers");
+  constexpr int TXT = TW / 2, TYT = TH / 2, TPI = TXT * TYT;       // 2x2 tiles per image inside a staged pixel tile
+  constexpr int NTL = NI * TPI;                                    // tiles per staged pixel tile
+  constexpr int TPWV = NTL / 4;                                    // per wave
+  constexpr int NKS = TPWV / 2;                                    // k-steps (tile pairs) per wave and staged tile
+  static_assert(NTL % 8 == 0, "tile pairs per wave");
+  __shared__ float lds[2 * TSZ];
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int KS = p.ksplit;
+  const int ks = w % KS; w /= KS;
+  const int cot = w % NCO; w /= NCO;
+  const int cit = w % NCI;
+  const int g = w / NCI;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int H = p.H, W = p.W;
+  const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
+
+  const VVSrc sa = vv_make_src(p, g, H, W);
+  VVSrc sb;
+  sb.p0 = p.dy.ptr + (int64_t)g * p.dy.gstride; sb.cs0 = p.dy.cstride; sb.co0 = p.dy.coff;
+  sb.a = sb.b = nullptr; sb.p1 = nullptr; sb.cs1 = sb.co1 = 0; sb.chmap = nullptr; sb.csplit = 0;
+  sb.mode = VV_IN_PLAIN; sb.SH = H; sb.SW = W; sb.B = p.B;
+
+  v16f acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  VVStagerB<NI, AHH, AHW, 32, 32> stA;
+  VVStagerB<NI, TH, TW, 32, 32> stB;
+  stA.init(sa, -1, tid);
+  stB.init(sb, 0, tid);
+  constexpr int NPA = decltype(stA)::NIT, NPB = decltype(stB)::NIT, NP = NPA + NPB;
+  constexpr int NSLOT = NKS * 16, C0 = NSLOT - NP - 4;
+  static_assert(C0 >= NP, "not enough MFMA slots between load issue and commit");
+  auto begin_tile = [&](const int pt, const bool live) {
+    const int img0 = (pt / tpi) * NI;
+    const int trem = pt % tpi;
+    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+    stA.begin(sa, img0, ty0 - 1, tx0 - 1, cit * 32, tid, p.CinP, live);
+    stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
+  };
+
+  // operand rows: V[xi][nu] / M[xi][nu] of the k-step in flight; row xi of the NEXT step overwrites row xi of this one
+  float V[4][4], M[4][4], dq[2][2];
+  const float *pA, *pB;                 // patch origin / dy origin of the step whose rows are being generated
+  auto step_addr = [&](const float* tA, const float* tB, const int j) {
+    const int tt = wave * TPWV + 2 * j + half;
+    const int im = tt / TPI, rem = tt % TPI;
+    const int tyl = rem / TXT, txl = rem % TXT;
+    pA = tA + ((im * AHH + 2 * tyl) * AHW + 2 * txl) * 32 + l31;
+    pB = tB + ((im * TH + 2 * tyl) * TW + 2 * txl) * 32 + l31;
+  };
+  auto read_dy = [&]() {
+    dq[0][0] = pB[0]; dq[0][1] = pB[32];
+    dq[1][0] = pB[TW * 32]; dq[1][1] = pB[TW * 32 + 32];
+  };
+  // row xi of V = B^T d B and of dM = A dY A^T      B^T rows: d0-d2, d1+d2, d2-d1, d1-d3      A rows: (1,0) (1,1) (1,-1) (0,-1)
+  auto gen_row = [&](auto XI) {
+    constexpr int xi = XI.value;
+    constexpr int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+    float r[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float d1 = pA[(a1 * AHW + b) * 32], d2 = pA[(a2 * AHW + b) * 32];
+      r[b] = xi == 1 ? d1 + d2 : d1 - d2;
+    }
+    V[xi][0] = r[0] - r[2];
+    V[xi][1] = r[1] + r[2];
+    V[xi][2] = r[2] - r[1];
+    V[xi][3] = r[1] - r[3];
+    float t0, t1;                       // T[xi][q] = sum_p A[xi][p] dY[p][q]
+    if constexpr (xi == 0) { t0 = dq[0][0]; t1 = dq[0][1]; }
+    else if constexpr (xi == 1) { t0 = dq[0][0] + dq[1][0]; t1 = dq[0][1] + dq[1][1]; }
+    else if constexpr (xi == 2) { t0 = dq[0][0] - dq[1][0]; t1 = dq[0][1] - dq[1][1]; }
+    else { t0 = -dq[1][0]; t1 = -dq[1][1]; }
+    M[xi][0] = t0;
+    M[xi][1] = t0 + t1;
+    M[xi][2] = t0 - t1;
+    M[xi][3] = -t1;
+  };
+
+  begin_tile(ks, true);
+  vv_static_for<0, NPA>([&](auto K) { stA.template load_piece<K.value>(sa, -1, tid); });
+  vv_static_for<0, NPB>([&](auto K) { stB.template load_piece<K.value>(sb, 0, tid); });
+  vv_static_for<0, NPA>([&](auto K) { stA.template commit_piece<K.value>(lds, tid); });
+  vv_static_for<0, NPB>([&](auto K) { stB.template commit_piece<K.value>(lds + ASZ, tid); });
+  __syncthreads();
+  int cur = 0;
+  for (int pt = ks; pt < NT; pt += KS) {
+    const float* tA = lds + cur * TSZ;
+    const float* tB = tA + ASZ;
+    float* nA = lds + (cur ^ 1) * TSZ;
+    float* nB = nA + ASZ;
+    const bool live = pt + KS < NT;
+    begin_tile(live ? pt + KS : ks, live);
+    // rows 0..2 of the first step (row 3 is generated under the first group of MFMAs, like in every later step)
+    step_addr(tA, tB, 0);
+    read_dy();
+    gen_row(std::integral_constant<int, 0>{});
+    gen_row(std::integral_constant<int, 1>{});
+    gen_row(std::integral_constant<int, 2>{});
+    vv_static_for<0, NKS>([&](auto JJ) {
+      constexpr int j = JJ.value;
+      vv_static_for<0, 4>([&](auto GG) {
+        constexpr int grp = GG.value;                  // MFMA row xi = grp of step j
+        // One scheduling region per group of 4 MFMAs: the row generated under it (row 3 of step j in group 0, rows 0..2 of
+        // step j+1 in groups 1..3 -- each overwrites a row consumed at least one group earlier) and up to four staging
+        // pieces may be interleaved with the MFMAs freely.
+        vv_static_for<0, 4>([&](auto NN) {
+          constexpr int nu = NN.value;
+          acc[grp * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[grp][nu], M[grp][nu], acc[grp * 4 + nu], 0, 0, 0);
+        });
+        if constexpr (grp == 0) gen_row(std::integral_constant<int, 3>{});
+        if constexpr (j + 1 < NKS) {
+          if constexpr (grp == 1) { step_addr(tA, tB, j + 1); read_dy(); gen_row(std::integral_constant<int, 0>{}); }
+          if constexpr (grp == 2) gen_row(std::integral_constant<int, 1>{});
+          if constexpr (grp == 3) gen_row(std::integral_constant<int, 2>{});
+        }
+        vv_static_for<0, 4>([&](auto NN) {
+          constexpr int slot = j * 16 + grp * 4 + NN.value;
+          if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
+          else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
+          else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
+          else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    __syncthreads();                        // next buffer complete, current buffer no longer read
+    cur ^= 1;
+  }
+
+  // ---- epilogue: dg = G^T dU G per (ci, co),  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]; then the direct kernel's slab path
+  v16f tap[9];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float c[3][4];                          // G^T dU  (rows)
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const float u0 = acc[0 * 4 + nu][i], u1 = acc[1 * 4 + nu][i], u2 = acc[2 * 4 + nu][i], u3 = acc[3 * 4 + nu][i];
+      c[0][nu] = u0 + 0.5f * (u1 + u2);
+      c[1][nu] = 0.5f * (u1 - u2);
+      c[2][nu] = u3 + 0.5f * (u1 + u2);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      tap[a * 3 + 0][i] = c[a][0] + 0.5f * (c[a][1] + c[a][2]);
+      tap[a * 3 + 1][i] = 0.5f * (c[a][1] - c[a][2]);
+      tap[a * 3 + 2][i] = c[a][3] + 0.5f * (c[a][1] + c[a][2]);
+    }
+  }
+  static_assert(2 * TSZ >= 9 * 1024, "LDS too small for the slab");
+  __syncthreads();
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+          float* q = lds + t * 1024 + row * 32 + l31;
+          *q = wv ? *q + tap[t][i] : tap[t][i];
+        }
+    }
+    __syncthreads();
+  }
+  float4* out = reinterpret_cast<float4*>(p.partial + (int64_t)g * p.partial_gstride +
+                                          ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024));
+  const float4* l4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) out[tid + j * VV_WG] = l4[tid + j * VV_WG];
+}
+
 __global__ void __launch_bounds__(VV_WG)
 wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO, const int nslab,
                     const float* __restrict__ partial, const int64_t partial_gstride, float* __restrict__ grad,
@@ -270,6 +465,17 @@ inline bool wgeo(int kind, int H, int W, WGeo* t) {
   return false;
 }
 
+template <int TH, int TW, int NI>
+int launch_ww(const vv_wgrad_params* p, hipStream_t st) {
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  const int total = p->G * NCI * NCO * p->ksplit;
+  const int nper = (total + 7) / 8;
+  VV_LAUNCH((wgrad_wino_kernel<TH, TW, NI>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
 template <int TH, int TW, int NI, int KIND>
 int launch_w(const vv_wgrad_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
@@ -296,6 +502,15 @@ extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
   if (p->kind == VV_CONV3 && (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE))
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
+  if (p->kind == VV_CONV3 && (p->pad0 & 256)) {           // Winograd F(2x2,3x3) form (same tiles, same slabs)
+    switch (p->H) {
+      case 32: return launch_ww<8, 32, 1>(p, st);
+      case 16: return launch_ww<16, 16, 1>(p, st);
+      case 8: return launch_ww<8, 8, 2>(p, st);
+      case 4: return launch_ww<4, 4, 8>(p, st);
+    }
+    return VV_ERR_UNSUPPORTED;
+  }
   if (p->kind == VV_CONV3) {
     switch (p->H) {
       case 32: return launch_w<8, 32, 1, VV_CONV3>(p, st);
