@@ -303,16 +303,22 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     dq[0][0] = pB[0]; dq[0][1] = pB[32];
     dq[1][0] = pB[TW * 32]; dq[1][1] = pB[TW * 32 + 32];
   };
-  // row xi of V = B^T d B and of dM = A dY A^T      B^T rows: d0-d2, d1+d2, d2-d1, d1-d3      A rows: (1,0) (1,1) (1,-1) (0,-1)
-  auto gen_row = [&](auto XI) {
+  // Row xi of V = B^T d B and of dM = A dY A^T is produced in two stages one MFMA group apart: read_row issues its 8 patch
+  // reads into pr[], xform_row (a group later, the reads have landed) does the arithmetic.
+  //   B^T rows: d0-d2, d1+d2, d2-d1, d1-d3          A rows: (1,0) (1,1) (1,-1) (0,-1)
+  float pr[8];
+  auto read_row = [&](auto XI, auto HALF) {             // HALF 0: patch row a1, HALF 1: patch row a2
     constexpr int xi = XI.value;
     constexpr int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+    constexpr int a = HALF.value ? a2 : a1;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pr[HALF.value * 4 + b] = pA[(a * AHW + b) * 32];
+  };
+  auto xform_row = [&](auto XI) {
+    constexpr int xi = XI.value;
     float r[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float d1 = pA[(a1 * AHW + b) * 32], d2 = pA[(a2 * AHW + b) * 32];
-      r[b] = xi == 1 ? d1 + d2 : d1 - d2;
-    }
+    for (int b = 0; b < 4; ++b) r[b] = xi == 1 ? pr[b] + pr[4 + b] : pr[b] - pr[4 + b];
     V[xi][0] = r[0] - r[2];
     V[xi][1] = r[1] + r[2];
     V[xi][2] = r[2] - r[1];
@@ -326,6 +332,11 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     M[xi][1] = t0 + t1;
     M[xi][2] = t0 - t1;
     M[xi][3] = -t1;
+  };
+  auto gen_row = [&](auto XI) {                         // both stages back to back (start of a staged tile only)
+    read_row(XI, std::integral_constant<int, 0>{});
+    read_row(XI, std::integral_constant<int, 1>{});
+    xform_row(XI);
   };
 
   begin_tile(ks, true);
@@ -342,36 +353,35 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     float* nB = nA + ASZ;
     const bool live = pt + KS < NT;
     begin_tile(live ? pt + KS : ks, live);
-    // rows 0..2 of the first step (row 3 is generated under the first group of MFMAs, like in every later step)
+    // rows 0..2 of the first step, and the reads of its row 3 (transformed under the first MFMA group)
     step_addr(tA, tB, 0);
     read_dy();
     gen_row(std::integral_constant<int, 0>{});
     gen_row(std::integral_constant<int, 1>{});
     gen_row(std::integral_constant<int, 2>{});
+    read_row(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+    read_row(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
     vv_static_for<0, NKS>([&](auto JJ) {
       constexpr int j = JJ.value;
-      vv_static_for<0, 4>([&](auto GG) {
-        constexpr int grp = GG.value;                  // MFMA row xi = grp of step j
-        // One scheduling region per group of 4 MFMAs: the row generated under it (row 3 of step j in group 0, rows 0..2 of
-        // step j+1 in groups 1..3 -- each overwrites a row consumed at least one group earlier) and up to four staging
-        // pieces may be interleaved with the MFMAs freely.
-        vv_static_for<0, 4>([&](auto NN) {
-          constexpr int nu = NN.value;
-          acc[grp * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[grp][nu], M[grp][nu], acc[grp * 4 + nu], 0, 0, 0);
-        });
-        if constexpr (grp == 0) gen_row(std::integral_constant<int, 3>{});
-        if constexpr (j + 1 < NKS) {
-          if constexpr (grp == 1) { step_addr(tA, tB, j + 1); read_dy(); gen_row(std::integral_constant<int, 0>{}); }
-          if constexpr (grp == 2) gen_row(std::integral_constant<int, 1>{});
-          if constexpr (grp == 3) gen_row(std::integral_constant<int, 2>{});
+      constexpr bool more = j + 1 < NKS;
+      vv_static_for<0, 16>([&](auto SS) {
+        constexpr int sl = SS.value, grp = sl >> 2, nu = sl & 3, slot = j * 16 + sl;
+        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[grp][nu], M[grp][nu], acc[sl], 0, 0, 0);
+        // under group g: the row whose reads were issued one group earlier is transformed -- row 3 of this step (g = 0) or
+        // row g-1 of the next step -- into registers consumed at least one group ago; then the reads of the following row.
+        constexpr int rowa = grp == 0 ? 3 : grp - 1, rowb = grp;         // rowb: row of step j+1 whose reads are issued
+        if constexpr (nu == 0 && (grp == 0 || more)) xform_row(std::integral_constant<int, rowa>{});
+        if constexpr (more) {
+          if constexpr (nu == 1) {
+            if constexpr (grp == 0) { step_addr(tA, tB, j + 1); read_dy(); }
+            read_row(std::integral_constant<int, rowb>{}, std::integral_constant<int, 0>{});
+          }
+          if constexpr (nu == 2) read_row(std::integral_constant<int, rowb>{}, std::integral_constant<int, 1>{});
         }
-        vv_static_for<0, 4>([&](auto NN) {
-          constexpr int slot = j * 16 + grp * 4 + NN.value;
-          if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
-          else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
-          else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
-          else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
-        });
+        if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
+        else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
+        else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
+        else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
         __builtin_amdgcn_sched_barrier(0);
       });
     });
