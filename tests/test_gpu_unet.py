@@ -304,3 +304,42 @@ def test_full_bank_b512_linearity_and_determinism():
     g2 = bank.grads.clone()
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
     assert torch.equal(g2, 2.0 * g1)                        # linear, bit for bit
+
+
+@pytest.mark.parametrize('H,Cin,Cout,B', [(32, 32, 32, 3), (16, 64, 64, 5), (8, 256, 128, 9), (4, 128, 256, 33), (32, 16, 32, 2)])
+def test_winograd_weight_gradient_matches_direct(H, Cin, Cout, B):
+    """vv_wgrad_mfma with pad0 bit 8 (Winograd F(2x2,3x3) weight gradient: dU = sum_tiles V^T dM, dg = G^T dU G) against the
+    direct tap-by-tap kernel on the same activation / gradient tensors (BatchNorm+ReLU-on-load input, ragged batch), through
+    the same slab reduction into the nn.Conv2d weight layout, and against a float64 evaluation on a sample of entries."""
+    import ctypes as C
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H * 100 + Cin)
+    x = torch.randn(G, B * H * H, Cin, generator=g).cuda()
+    dy = torch.randn(G, B * H * H, Cout, generator=g).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    nci, nco = (Cin + 31) // 32, Cout // 32
+    nt = lib.vv_wgrad_ntiles(L.CONV3, B, H, H)
+    ks = max(1, min(nt, 3))
+    outs = []
+    for flag in (0, 256):
+        part = torch.zeros(G, nci * nco * ks * 9 * 1024, device='cuda')
+        grad = torch.zeros(G, Cout * Cin * 9, device='cuda')
+        wp = L.WgradParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, Cin, Cout, ks, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(),
+                           Cin, L.NULL_VIEW, 0, flag, None, L.View(dy.data_ptr(), dy.stride(0), Cout, 0), part.data_ptr(), part.stride(0))
+        L.check(lib.vv_wgrad_mfma(C.byref(wp), st), 'wgrad')
+        L.check(lib.vv_wgrad_reduce(L.CONV3, G, Cin, Cin, Cout, ks, part.data_ptr(), part.stride(0), grad.data_ptr(), grad.stride(0),
+                                    st), 'reduce')
+        outs.append(grad.view(G, Cout, Cin, 3, 3).clone())
+    scale = outs[0].abs().max().item()
+    assert (outs[0] - outs[1]).abs().max().item() <= 5e-5 * scale, ((outs[0] - outs[1]).abs().max().item(), scale)
+    # float64 spot check: dW[co,ci,ky,kx] = sum_{b,y,x} act[b,y+ky-1,x+kx-1,ci] * dy[b,y,x,co]
+    act = torch.relu(x.double() * a.double()[:, None, :] + b.double()[:, None, :]).view(G, B, H, H, Cin)
+    dyd = dy.double().view(G, B, H, H, Cout)
+    pad = torch.nn.functional.pad(act, (0, 0, 1, 1, 1, 1))
+    for (gi, co, ci, ky, kx) in ((0, 0, 0, 0, 0), (1, Cout - 1, Cin - 1, 2, 1), (0, 5, 7, 1, 1), (1, 17, 3, 0, 2)):
+        ref = (pad[gi, :, ky:ky + H, kx:kx + H, ci] * dyd[gi, :, :, :, co]).sum().item()
+        assert abs(outs[1][gi, co, ci, ky, kx].item() - ref) <= 2e-4 * scale + 1e-4 * abs(ref), (gi, co, ci, ky, kx)
