@@ -212,6 +212,7 @@ class UNetBank:
         # chains); default: Winograd F(2x2,3x3) for forward and data-gradient (2.25x fewer MFMA cycles, a few ulp apart)
         self.wino = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino_wgrad = self.wino and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
+        self.wgrad_flag = int(os.environ.get('VV_WGRAD_FLAG', '256'))     # 256: Winograd (variant per level), 512: eight-wave form
         direct = [(k, v) for k, v in lay.pk.items() if not (self.wino and k[0] == 'c')]
         ents = (L.PackEntry * len(direct))()
         mx = 0
@@ -491,7 +492,7 @@ class UNetBank:
             ks, nslab = wplan['c%d' % i]
             # pad0 bit 8: Winograd F(2x2,3x3) form of the weight gradient (same tiles / slabs, 2.25x fewer MFMA cycles)
             wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit,
-                               256 if self.wino_wgrad else 0, chmap,
+                               self.wgrad_flag if self.wino_wgrad else 0, chmap,
                                L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,), record='wdone%d' % i,

@@ -169,12 +169,12 @@ __device__ __forceinline__ void vv_stage_tile(float* lds, const VVSrc& s, int im
 // the hardware bounds check returns 0.0f (the convolution's zero padding) without a branch.  Per item and tile the
 // address math is ~5 VALU instructions instead of ~30 (the staging code was issue-bound, not latency-bound).
 // VV_IN_POOL / VV_IN_CUBE items (4-tap max-pool, channel gather) keep the generic immediate path.
-template <int NI, int HH, int HW, int S, int NCH>
+template <int NI, int HH, int HW, int S, int NCH, int NTH = VV_WG>      // NTH: threads of the workgroup
 struct VVStagerB {
   static constexpr int Q = NCH / 4;
   static constexpr int NITEMS = NI * HH * HW * Q;
-  static constexpr int NIT = (NITEMS + VV_WG - 1) / VV_WG;
-  static_assert(VV_WG % Q == 0 && NIT <= 32, "stager geometry");
+  static constexpr int NIT = (NITEMS + NTH - 1) / NTH;
+  static_assert(NTH % Q == 0 && NIT <= 32, "stager geometry");
   static constexpr unsigned OOB = 0x80000000u;
   float4 r[NIT];
   int pix[NIT];        // (im*SH + hy)*SW + hx relative to the tile origin, or INT_MIN/2 when the column is never valid
@@ -186,14 +186,14 @@ struct VVStagerB {
   __device__ __forceinline__ void init(const VVSrc& s, int x0, int tid) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int it = tid + k * VV_WG;
+      const int it = tid + k * NTH;
       const int hp = it / Q;
       const int hx = hp % HW;
       const int t = hp / HW;
       hy[k] = (short)(t % HH);
       im[k] = (short)(t / HH);
       const int x = x0 + hx;
-      const bool ok = (NITEMS % VV_WG == 0 || it < NITEMS) && (unsigned)x < (unsigned)s.SW;
+      const bool ok = (NITEMS % NTH == 0 || it < NITEMS) && (unsigned)x < (unsigned)s.SW;
       pix[k] = ok ? (im[k] * s.SH + hy[k]) * s.SW + hx : -(1 << 30);
     }
   }
@@ -211,7 +211,7 @@ struct VVStagerB {
     if (s.mode == VV_IN_POOL || s.mode == VV_IN_CUBE) {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
-        const int img = img0 + im[k], y = y0 + hy[k], x = x0 + ((tid + k * VV_WG) / Q) % HW;
+        const int img = img0 + im[k], y = y0 + hy[k], x = x0 + ((tid + k * NTH) / Q) % HW;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pix[k] >= 0 && img < s.B && (unsigned)y < (unsigned)s.SH && c < cmax) v = vv_fetch4(s, img, y, x, c);
         r[k] = v;
@@ -274,8 +274,8 @@ struct VVStagerB {
   }
   template <int K>
   __device__ __forceinline__ void commit_piece(float* lds, int tid) const {
-    const int it = tid + K * VV_WG;
-    if (NITEMS % VV_WG == 0 || it < NITEMS) {
+    const int it = tid + K * NTH;
+    if (NITEMS % NTH == 0 || it < NITEMS) {
       float4 v = r[K];
       if (act && ((valid >> K) & 1u)) v = vv_act4(v, sa, sb);
       *reinterpret_cast<float4*>(lds + (it / Q) * S + (tid % Q) * 4) = v;
@@ -286,8 +286,8 @@ struct VVStagerB {
     const int q = tid % Q;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int it = tid + k * VV_WG;
-      if (NITEMS % VV_WG == 0 || it < NITEMS) {
+      const int it = tid + k * NTH;
+      if (NITEMS % NTH == 0 || it < NITEMS) {
         float4 v = r[k];
         if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
         *reinterpret_cast<float4*>(lds + (it / Q) * S + q * 4) = v;

@@ -430,6 +430,199 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   for (int j = 0; j < 9; ++j) out[tid + j * VV_WG] = l4[tid + j * VV_WG];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eight-wave form of the Winograd weight gradient: 512 threads, wave = (K quarter kq of the staged tile's 2x2 tiles) x
+// (xi half xh).  A wave keeps only the 8 GEMMs of its xi half (128 accumulator registers, <= 256 registers per lane), so
+// two waves share every SIMD and one's operand arithmetic / barrier waits run under the other's MFMAs -- the four-wave
+// form above has nobody to hide them (measured MFMA utilisation 0.5 even with the staging switched off).
+template <int TH, int TW, int NI>
+__global__ void __launch_bounds__(512, 1)
+wgrad_wino8_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+  constexpr int NTH = 512;
+  constexpr int AHH = TH + 2, AHW = TW + 2;
+  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * TH * TW * 32, TSZ = ASZ + BSZ;
+  static_assert(2 * TSZ * 4 <= 160 * 1024, "two LDS buffers");
+  constexpr int TXT = TW / 2, TYT = TH / 2, TPI = TXT * TYT;       // 2x2 tiles per image inside a staged pixel tile
+  constexpr int NTL = NI * TPI;                                    // tiles per staged pixel tile
+  constexpr int TPWV = NTL / 4;                                    // per K quarter
+  constexpr int NKS = TPWV / 2;                                    // k-steps (tile pairs) per wave and staged tile
+  static_assert(NTL % 8 == 0, "tile pairs per wave");
+  constexpr int LSZ = 2 * TSZ > 4 * 9 * 1024 ? 2 * TSZ : 4 * 9 * 1024;      // epilogue: one tap slab per K quarter
+  __shared__ float lds[LSZ];
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int KS = p.ksplit;
+  const int ks = w % KS; w /= KS;
+  const int cot = w % NCO; w /= NCO;
+  const int cit = w % NCI;
+  const int g = w / NCI;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int kq = wave >> 1, xh = wave & 1;
+  const int H = p.H, W = p.W;
+  const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
+
+  const VVSrc sa = vv_make_src(p, g, H, W);
+  VVSrc sb;
+  sb.p0 = p.dy.ptr + (int64_t)g * p.dy.gstride; sb.cs0 = p.dy.cstride; sb.co0 = p.dy.coff;
+  sb.a = sb.b = nullptr; sb.p1 = nullptr; sb.cs1 = sb.co1 = 0; sb.chmap = nullptr; sb.csplit = 0;
+  sb.mode = VV_IN_PLAIN; sb.SH = H; sb.SW = W; sb.B = p.B;
+
+  v16f acc[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[x][n][i] = 0.f;
+
+  VVStagerB<NI, AHH, AHW, 32, 32, NTH> stA;
+  VVStagerB<NI, TH, TW, 32, 32, NTH> stB;
+  stA.init(sa, -1, tid);
+  stB.init(sb, 0, tid);
+  constexpr int NPA = decltype(stA)::NIT, NPB = decltype(stB)::NIT, NP = NPA + NPB;
+  constexpr int NSLOT = NKS * 8, C0 = NSLOT - NP - 2;
+  static_assert(C0 >= NP, "not enough MFMA slots between load issue and commit");
+  auto begin_tile = [&](const int pt, const bool live) {
+    const int img0 = (pt / tpi) * NI;
+    const int trem = pt % tpi;
+    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+    stA.begin(sa, img0, ty0 - 1, tx0 - 1, cit * 32, tid, p.CinP, live);
+    stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
+  };
+
+  // this wave's two xi rows (x = 0, 1 -> xi = 2 xh + x):   B^T row xi: d[a1] + sg d[a2]      A row xi: (c0, c1)
+  //   xi 0: d0 - d2, (1, 0)     1: d1 + d2, (1, 1)     2: d2 - d1, (1, -1)     3: d1 - d3, (0, -1)
+  int ao1[2], ao2[2];
+  float sg[2], c0[2], c1[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int xi = 2 * xh + x;
+    const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+    ao1[x] = a1 * AHW * 32;
+    ao2[x] = a2 * AHW * 32;
+    sg[x] = xi == 1 ? 1.f : -1.f;
+    c0[x] = xi == 3 ? 0.f : 1.f;
+    c1[x] = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
+  }
+  float V[2][4], M[2][4], dq[2][2], pr[8];
+  const float *pA, *pB;
+  auto step_addr = [&](const float* tA, const float* tB, const int j) {
+    const int tt = kq * TPWV + 2 * j + half;
+    const int im = tt / TPI, rem = tt % TPI;
+    const int tyl = rem / TXT, txl = rem % TXT;
+    pA = tA + ((im * AHH + 2 * tyl) * AHW + 2 * txl) * 32 + l31;
+    pB = tB + ((im * TH + 2 * tyl) * TW + 2 * txl) * 32 + l31;
+  };
+  auto read_dy = [&]() {
+    dq[0][0] = pB[0]; dq[0][1] = pB[32];
+    dq[1][0] = pB[TW * 32]; dq[1][1] = pB[TW * 32 + 32];
+  };
+  auto read_row = [&](const int x) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { pr[b] = pA[ao1[x] + b * 32]; pr[4 + b] = pA[ao2[x] + b * 32]; }
+  };
+  auto xform_row = [&](const int x) {
+    float r[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r[b] = fmaf(sg[x], pr[4 + b], pr[b]);
+    V[x][0] = r[0] - r[2];
+    V[x][1] = r[1] + r[2];
+    V[x][2] = r[2] - r[1];
+    V[x][3] = r[1] - r[3];
+    const float t0 = fmaf(c1[x], dq[1][0], c0[x] * dq[0][0]), t1 = fmaf(c1[x], dq[1][1], c0[x] * dq[0][1]);
+    M[x][0] = t0;
+    M[x][1] = t0 + t1;
+    M[x][2] = t0 - t1;
+    M[x][3] = -t1;
+  };
+
+  begin_tile(ks, true);
+  vv_static_for<0, NPA>([&](auto K) { stA.template load_piece<K.value>(sa, -1, tid); });
+  vv_static_for<0, NPB>([&](auto K) { stB.template load_piece<K.value>(sb, 0, tid); });
+  vv_static_for<0, NPA>([&](auto K) { stA.template commit_piece<K.value>(lds, tid); });
+  vv_static_for<0, NPB>([&](auto K) { stB.template commit_piece<K.value>(lds + ASZ, tid); });
+  __syncthreads();
+  int cur = 0;
+  for (int pt = ks; pt < NT; pt += KS) {
+    const float* tA = lds + cur * TSZ;
+    const float* tB = tA + ASZ;
+    float* nA = lds + (cur ^ 1) * TSZ;
+    float* nB = nA + ASZ;
+    const bool live = pt + KS < NT;
+    begin_tile(live ? pt + KS : ks, live);
+    // first step of the staged tile: row 0 directly, reads of row 1 (transformed under the first MFMA group)
+    step_addr(tA, tB, 0);
+    read_dy();
+    read_row(0);
+    xform_row(0);
+    read_row(1);
+    vv_static_for<0, NKS>([&](auto JJ) {
+      constexpr int j = JJ.value;
+      constexpr bool more = j + 1 < NKS;
+      vv_static_for<0, 8>([&](auto SS) {
+        constexpr int sl = SS.value, x = sl >> 2, nu = sl & 3, slot = j * 8 + sl;
+        acc[x][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[x][nu], M[x][nu], acc[x][nu], 0, 0, 0);
+        // under group 0: row 1 of this step is transformed (reads issued one group earlier), then the reads of row 0 of the
+        // next step; under group 1: row 0 of the next step is transformed, then the reads of its row 1
+        if constexpr (x == 0) {
+          if constexpr (nu == 0) xform_row(1);
+          if constexpr (nu == 1 && more) { step_addr(tA, tB, j + 1); read_row(0); }
+        } else if constexpr (more) {
+          if constexpr (nu == 0) { read_dy(); }
+          if constexpr (nu == 1) { xform_row(0); read_row(1); }
+        }
+        if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
+        else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
+        else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
+        else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    __syncthreads();                        // next buffer complete, current buffer no longer read
+    cur ^= 1;
+  }
+
+  // ---- epilogue.  dg = G^T dU G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]: each wave folds ITS xi half into 9 tap partials
+  // (linear), xi halves meet in LDS (one slab per K quarter), then the four slabs are summed in fixed order into the
+  // workgroup's global slab -- the layout vv_wgrad_reduce expects.
+  __syncthreads();
+  float* slab = lds + kq * 9 * 1024;
+  // G^T[a][xi] for this wave's rows xi = 2xh, 2xh+1:   xh = 0: (1, .5) (0, .5) (0, .5)      xh = 1: (.5, 0) (-.5, 0) (.5, 1)
+  const float ga[3][2] = {{xh ? 0.5f : 1.f, xh ? 0.f : 0.5f}, {xh ? -0.5f : 0.f, xh ? 0.f : 0.5f}, {xh ? 0.5f : 0.f, xh ? 1.f : 0.5f}};
+  for (int ph = 1; ph >= 0; --ph) {         // xi half 1 writes, barrier, xi half 0 adds
+    if (xh == ph) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+        float* q = slab + row * 32 + l31;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float c[4];
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu) c[nu] = ga[a][0] * acc[0][nu][i] + ga[a][1] * acc[1][nu][i];
+          const float h = 0.5f * (c[1] + c[2]);
+          const float t0 = c[0] + h, t1 = 0.5f * (c[1] - c[2]), t2 = c[3] + h;
+          if (ph) { q[(a * 3 + 0) * 1024] = t0; q[(a * 3 + 1) * 1024] = t1; q[(a * 3 + 2) * 1024] = t2; }
+          else { q[(a * 3 + 0) * 1024] += t0; q[(a * 3 + 1) * 1024] += t1; q[(a * 3 + 2) * 1024] += t2; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float4* out = reinterpret_cast<float4*>(p.partial + (int64_t)g * p.partial_gstride +
+                                          ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024));
+  const float4* l4 = reinterpret_cast<const float4*>(lds);
+  for (int e = tid; e < 9 * 256; e += NTH) {
+    const float4 s0 = l4[e], s1 = l4[9 * 256 + e], s2 = l4[2 * 9 * 256 + e], s3 = l4[3 * 9 * 256 + e];
+    float4 r;
+    r.x = (s0.x + s1.x) + (s2.x + s3.x); r.y = (s0.y + s1.y) + (s2.y + s3.y);
+    r.z = (s0.z + s1.z) + (s2.z + s3.z); r.w = (s0.w + s1.w) + (s2.w + s3.w);
+    out[e] = r;
+  }
+}
+
 __global__ void __launch_bounds__(VV_WG)
 wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO, const int nslab,
                     const float* __restrict__ partial, const int64_t partial_gstride, float* __restrict__ grad,
@@ -486,6 +679,17 @@ int launch_ww(const vv_wgrad_params* p, hipStream_t st) {
   return VV_OK;
 }
 
+template <int TH, int TW, int NI>
+int launch_ww8(const vv_wgrad_params* p, hipStream_t st) {
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  const int total = p->G * NCI * NCO * p->ksplit;
+  const int nper = (total + 7) / 8;
+  VV_LAUNCH((wgrad_wino8_kernel<TH, TW, NI>), dim3(nper * 8), dim3(512), 0, st, *p, NT, NCI, NCO, total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
 template <int TH, int TW, int NI, int KIND>
 int launch_w(const vv_wgrad_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
@@ -512,12 +716,23 @@ extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
   if (p->kind == VV_CONV3 && (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE))
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
+  if (p->kind == VV_CONV3 && (p->pad0 & 512)) {           // Winograd form, eight waves (two per SIMD)
+    switch (p->H) {
+      case 32: return launch_ww8<8, 32, 1>(p, st);
+      case 16: return launch_ww8<16, 16, 1>(p, st);
+      case 8: return launch_ww8<8, 8, 2>(p, st);
+      case 4: return launch_ww8<4, 4, 8>(p, st);
+    }
+    return VV_ERR_UNSUPPORTED;
+  }
   if (p->kind == VV_CONV3 && (p->pad0 & 256)) {           // Winograd F(2x2,3x3) form (same tiles, same slabs)
+    // measured per level at B = 256: four waves x 16 GEMMs win on the 32^2 / 16^2 levels (few, long staged tiles), eight
+    // waves x 8 GEMMs (two waves per SIMD) on the 8^2 / 4^2 levels (-10 %)
     switch (p->H) {
       case 32: return launch_ww<8, 32, 1>(p, st);
       case 16: return launch_ww<16, 16, 1>(p, st);
-      case 8: return launch_ww<8, 8, 2>(p, st);
-      case 4: return launch_ww<4, 4, 8>(p, st);
+      case 8: return launch_ww8<8, 8, 2>(p, st);
+      case 4: return launch_ww8<4, 4, 8>(p, st);
     }
     return VV_ERR_UNSUPPORTED;
   }
