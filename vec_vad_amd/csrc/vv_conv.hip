@@ -5,13 +5,15 @@
 //   A operand : input activations, staged global -> registers -> LDS as a halo tile [NI][HH][HW][CK+4] with the
 //               producer's BatchNorm+ReLU (+2x2 max-pool, +skip concat, +frame erasure) applied on the way in,
 //               read back as ds_read_b128: lane l gets 4 consecutive channels of pixel (l&31), channel group (l>>5).
-//   B operand : pre-packed weight panels [tap][Cin/8][2][Cout][4] read straight from global/L2 as one
-//               global_load_dwordx4 per lane (fully coalesced 512 B per half-wave), no LDS.
+//   B operand : pre-packed weight panels [tap][Cin/8][2][Cout][4]; the chunk's panel takes the same route
+//               global -> registers -> LDS one chunk ahead, so the MFMA loop reads nothing but LDS.
 //   One float4 of A and one of B feed 4 MFMAs (k-pairs (j, j+4) of an 8-channel group).
 //   Epilogue  : + bias, NHWC store (128 B contiguous per half-wave), per-channel sum / sum^2 partials for BatchNorm.
 //
 // Replaces: nn.Conv2d(k3,p1) forward (model/unet.py:10,13), its data gradient, nn.ConvTranspose2d(k3,s2,p1,op1)
-// forward (model/unet.py:54) and its data gradient; cuDNN calls in the reference.
+// forward (model/unet.py:54) and its data gradient; cuDNN calls in the reference.  By default the 3x3 / stride-1 layers run
+// through the Winograd kernel in vv_wino.hip (VV_WINOGRAD=0 brings them back here); the transposed convolution always
+// runs here -- forward with all four output-parity phases in one workgroup, data gradient as a stride-2 gather.
 #include "vv_common.h"
 
 namespace {
