@@ -458,7 +458,8 @@ wgrad_wino8_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
   const int cit = w % NCI;
   const int g = w / NCI;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: everything derived from it lives in SGPRs
   const int kq = wave >> 1, xh = wave & 1;
   const int H = p.H, W = p.W;
   const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
