@@ -172,9 +172,7 @@ def test_extraction_stage_and_full_scripts(tmp_path, monkeypatch):
     frames, flows, boxes = _synthetic_ped2_tree(rng)
     cfg = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config.cfg')).read()
     cfg = cfg.replace('epochs = 10', 'epochs = 1').replace('batch_size = 128', 'batch_size = 4')
-    import re
-    cfg = re.sub(r'(\[UCSDped2\][^\[]*?)h_block=1\nw_block=1', r'\1h_block=2\nw_block=2', cfg)
-    cfg = re.sub(r'(\[UCSDped2\][^\[]*?)train_block_mode = 1', r'\1train_block_mode = 9', cfg)
+    cfg = cfg.replace('[UCSDped2]\n', '[UCSDped2]\nh_block = 2\nw_block = 2\ntrain_block_mode = 9\n')      # dataset-level overrides
     open('config.cfg', 'w').write(cfg)
     c = T.read_config('config.cfg')
     assert c['h_block'] == 2 and c['cp'].getint('UCSDped2', 'train_block_mode') == 9 and c['batch_size'] == 4
