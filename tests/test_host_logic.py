@@ -224,3 +224,53 @@ def test_frame_indexers_on_a_synthetic_tree(tmp_path):
     assert [int(dss[i][1][0]) for i in range(5)] == [0, 1, 0, 0, 1]
     with pytest.raises(NotImplementedError):
         V.unified_dataset_interface('UCF', root3)
+
+
+def test_read_config_accepts_both_layouts(tmp_path):
+    """train.read_config on the shipped config.cfg (shared values in [DEFAULT]) and on a file written the way the reference
+    writes its own (every key repeated inside the dataset section, `key=value` without spaces): same effective values."""
+    import train as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = T.read_config(os.path.join(root, 'config.cfg'))
+    assert (c['dataset_name'], c['mode_fg'], c['modality'], c['method']) == ('UCSDped2', 'obj_det_with_motion', 'raw2flow', 'SelfComplete')
+    assert (c['h_block'], c['w_block'], c['tot_frame_num'], c['tot_of_num'], c['rawRange']) == (1, 1, 5, 5, None)
+    assert c['cp'].getint('ShanghaiTech', 'saveSegNum') == 40000 and c['cp'].getint('avenue', 'patch_size') == 32
+    flat = '''[shared_parameters]
+dataset_name = avenue
+raw_dataset_dir = raw_datasets
+foreground_extraction_mode = obj_det
+data_root_dir = data
+modality = raw2flow
+method = SelfComplete
+[avenue]
+patch_size=32
+h_block=2
+w_block=3
+train_bbox_saved = True
+train_foreground_saved = True
+test_bbox_saved = True
+test_foreground_saved = True
+scores_saved = False
+train_block_mode = 1
+test_block_mode = 1
+motionThr = 0
+[SelfComplete]
+border_mode = predict
+epochs = 3
+batch_size = 64
+nf = 32
+useFlow = True
+context_frame_num = 4
+context_of_num = 0
+rawRange = 3
+padding = True
+lambda_raw = 1.0
+lambda_of = 2.0
+w_raw =1
+w_of =0.5
+'''
+    p = tmp_path / 'flat.cfg'
+    p.write_text(flat)
+    c = T.read_config(str(p))
+    assert (c['dataset_name'], c['h_block'], c['w_block'], c['tot_of_num'], c['rawRange']) == ('avenue', 2, 3, 1, 3)
+    assert c['padding'] is True and c['lambda_of'] == 2.0 and c['w_of'] == 0.5 and c['shuffle_seed'] == 0 and c['score_batch'] == 512
