@@ -41,32 +41,29 @@ def frame_roc_auc(scores, labels):
 def save_roc_pr_curve_data(scores, labels, file_path, verbose=True):
     """Same outputs / file layout as the reference when scikit-learn is importable (utils.py:29-65); without it only the
     ROC-AUC (rank statistic) is computed and stored."""
-    scores = np.asarray(scores).flatten()
-    labels = np.asarray(labels).flatten()
-    scores_pos, scores_neg = scores[labels == 1], scores[labels != 1]
-    truth = np.concatenate((np.zeros_like(scores_neg), np.ones_like(scores_pos)))
-    preds = np.concatenate((scores_neg, scores_pos))
+    s = np.asarray(scores).ravel()
+    y = np.asarray(labels).ravel()
+    pos, neg = s[y == 1], s[y != 1]
+    out = {'preds': np.concatenate((neg, pos)),                       # negatives first, like the reference's file
+           'truth': np.concatenate((np.zeros_like(neg), np.ones_like(pos)))}
     try:
-        from sklearn.metrics import roc_curve, precision_recall_curve, auc
+        from sklearn import metrics
     except ImportError:
-        roc_auc = frame_roc_auc(preds, truth > 0)
+        out['roc_auc'] = frame_roc_auc(out['preds'], out['truth'] > 0)
         if verbose:
-            print('AUC@ROC is {}'.format(roc_auc))
-        np.savez_compressed(file_path, preds=preds, truth=truth, roc_auc=roc_auc)
-        return roc_auc
-    fpr, tpr, roc_thresholds = roc_curve(truth, preds)
-    roc_auc = auc(fpr, tpr)
-    fnr = 1 - tpr
-    k = np.nanargmin(np.absolute(fnr - fpr))
-    eer1, eer2 = fpr[k], fnr[k]
-    precision_norm, recall_norm, pr_thresholds_norm = precision_recall_curve(truth, preds)
-    pr_auc_norm = auc(recall_norm, precision_norm)
-    precision_anom, recall_anom, pr_thresholds_anom = precision_recall_curve(truth, -preds, pos_label=0)
-    pr_auc_anom = auc(recall_anom, precision_anom)
+            print('AUC@ROC is {}'.format(out['roc_auc']))
+        np.savez_compressed(file_path, **out)
+        return out['roc_auc']
+    out['fpr'], out['tpr'], out['roc_thresholds'] = metrics.roc_curve(out['truth'], out['preds'])
+    out['roc_auc'] = metrics.auc(out['fpr'], out['tpr'])
+    miss = 1 - out['tpr']
+    k = np.nanargmin(np.absolute(miss - out['fpr']))                  # equal-error point
+    # precision/recall with "normal" as the positive class, then with "anomaly" as the positive class
+    for tag, sc, kw in (('norm', out['preds'], {}), ('anom', -out['preds'], {'pos_label': 0})):
+        pr, rc, th = metrics.precision_recall_curve(out['truth'], sc, **kw)
+        out['precision_' + tag], out['recall_' + tag], out['pr_thresholds_' + tag] = pr, rc, th
+        out['pr_auc_' + tag] = metrics.auc(rc, pr)
     if verbose:
-        print('AUC@ROC is {}'.format(roc_auc), 'EER1 is {}'.format(eer1), 'EER2 is {}'.format(eer2))
-    np.savez_compressed(file_path, preds=preds, truth=truth, fpr=fpr, tpr=tpr, roc_thresholds=roc_thresholds,
-                        roc_auc=roc_auc, precision_norm=precision_norm, recall_norm=recall_norm,
-                        pr_thresholds_norm=pr_thresholds_norm, pr_auc_norm=pr_auc_norm, precision_anom=precision_anom,
-                        recall_anom=recall_anom, pr_thresholds_anom=pr_thresholds_anom, pr_auc_anom=pr_auc_anom)
-    return roc_auc
+        print('AUC@ROC is {}'.format(out['roc_auc']), 'EER1 is {}'.format(out['fpr'][k]), 'EER2 is {}'.format(miss[k]))
+    np.savez_compressed(file_path, **out)
+    return out['roc_auc']
