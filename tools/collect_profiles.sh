@@ -10,6 +10,8 @@ python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_mfma -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/make_pmc_mfma.py $O/pmc_mfma/*/*counter_collection.csv $O/pmc_mfma_busy.json
 python $R/tools/make_pmc_traffic.py $O/pmc_fetch/*/*counter_collection.csv $O/pmc_write/*/*counter_collection.csv $O/pmc_hbm_traffic.json
 python $R/tools/bench_flownet2.py > $O/flownet2_1024x448.json 2> /dev/null
 python $R/tools/bench_flownet2.py 384 512 > $O/flownet2_512x384.json 2> /dev/null
@@ -18,5 +20,5 @@ python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --model full --batch 
 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --batch 1024 > $O/bench_net4_b1024.json 2> /dev/null
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
 cp $O/fn2stats/*/*kernel_stats.csv $O/flownet2_kernel_stats.csv
-rm -rf $O/stats $O/fn2stats $O/pmc_fetch $O/pmc_write
+rm -rf $O/stats $O/fn2stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 tail -n 1 $O/bench.json
