@@ -1,5 +1,5 @@
 """micro-benchmark of vv_wgrad_mfma with bring-up switches (pad0 bits): which part of the kernel costs what."""
-import sys, os, time
+import sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vec_vad_amd import _lib as L

@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from model.unet import SelfCompleteNet4, SelfCompleteNetFull  # noqa: E402
-from vad_datasets import CubeStore, frame_size  # noqa: E402
+from vad_datasets import CubeStore  # noqa: E402
 from vec_vad_amd.trainer import FusedTrainer, shard_batch  # noqa: E402
 
 

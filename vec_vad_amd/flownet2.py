@@ -11,7 +11,6 @@ views, packing 12/11-channel network inputs) uses torch tensor ops.  No torch.nn
 ``with_bn`` must be False and ``fp16`` False (what VEC_VAD instantiates, flownet2.py:12-17).
 """
 import ctypes as C
-import os
 
 import torch
 import torch.nn as nn

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .bank import UNetBank, UnitSpec, BankLayout, conv_key_to_state_name, RAW_C, OF_C
+from .bank import UNetBank, UnitSpec, conv_key_to_state_name, RAW_C, OF_C
 
 _NO_STANDALONE = ('this block only carries parameters for the fused HIP UNet bank; call the enclosing '
                   'SelfCompleteNet* model (vec_vad_amd has no per-block PyTorch fallback)')
