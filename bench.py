@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 FWD_FLOP_NET4 = 1855520768      # per cube, SURVEY.md section 8(d)
 TRAIN_FLOP_NET4 = 5524094976
 FP32_MFMA_PEAK = 157.3e12       # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
+BF16_MFMA_PEAK = 2.5e15         # v_mfma_f32_32x32x16_bf16, dense
+HBM_PEAK = 8.0e12               # HBM3E, MI355X_MICROARCH.md
 
 
 def conv_flops(lay, B, G):
@@ -42,10 +44,22 @@ def conv_flops(lay, B, G):
     return fl
 
 
-def pmc_traffic():
+def conv_bytes(lay, B, G):
+    """algorithmic HBM bytes of the same launches: the input tensor read once + the output tensor written once, fp32
+    (every conv output round-trips HBM exactly once); weights (L2 resident) not counted."""
+    by = {}
+    for l in lay.convs:
+        cin = l.cinp if l.idx == 0 else l.cin                 # layer 0 reads the 16-channel frame-erased buffer
+        by['conv%d' % l.idx] = 4.0 * B * l.H * l.H * G * (cin + l.cout)
+        if l.idx > 0:
+            by['dgrad%d' % l.idx] = 4.0 * B * l.H * l.H * G * (l.cout + l.cin)
+    return by
+
+
+def pmc_traffic(name='r01_pmc_hbm_traffic.json'):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed."""
-    p = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    p = os.path.join(ROOT, 'profiles', name)
     try:
         d = json.load(open(p))
         return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected']
@@ -94,12 +108,16 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='cubes per GPU per step')
     ap.add_argument('--pool', type=int, default=4096, help='device-resident synthetic cubes per GPU')
     ap.add_argument('--model', default='net4', choices=['net4', 'full'])
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help="bf16 = BASELINE config 4's mixed precision (bf16 conv operands, fp32 accumulation / tensors / BatchNorm / "
+                         "Adam); the headline number is fp32, like the reference")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
     ap.add_argument('--overlap', nargs='?', const='free', default='none', choices=('none', 'free', 'paired'),
                     help="side stream for the weight-gradient kernels: 'free' = under everything that follows (conv launches "
                          "are then contended), 'paired' = only under the next layer's BatchNorm backward (conv launches run alone)")
     args = ap.parse_args()
+    os.environ['VV_PRECISION'] = args.precision
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -143,6 +161,7 @@ def main():
     torch.cuda.synchronize()
     ws = bank.workspace(B)
     fl = conv_flops(bank.lay, B, bank.Ga)
+    by = conv_bytes(bank.lay, B, bank.Ga)
     # HIP events around every MFMA 3x3-conv launch (forward conv + data-gradient) of the timed region
     ev = []
     trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
@@ -199,6 +218,7 @@ def main():
     conv_t = sum(sum(v) for k, v in per.items() if k in fl)
     conv_n = sum(len(v) for k, v in per.items() if k in fl)
     conv_f = sum(fl[k] * len(v) for k, v in per.items() if k in fl)
+    conv_b = sum(by[k] * len(v) for k, v in per.items() if k in fl)
     if args.breakdown and rank == 0:
         tot = sum(sum(v) for v in per.values())
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
@@ -219,7 +239,8 @@ def main():
     out = {
         'metric': 'spatio-temporal cubes/sec (train step)', 'value': value, 'unit': 'cubes/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16 operands, f32 accumulate',
+        'data': 'synthetic',
         'config': {'workload': 'UCSDped2-shaped 5raw+1of UNet bank (SelfCompleteNet4, nf=32, padding=False) train step: '
                                'cube gather + forward + backward + Adam(eps=1e-7)' if args.model == 'net4' else
                                '5raw+5of UNet bank (SelfCompleteNetFull) train step',
@@ -244,6 +265,22 @@ def main():
                      'side_stream_weight_grad': args.overlap,
                      'isolated_frac': (iso_f / iso_t / FP32_MFMA_PEAK) if iso_t > 0 else None},
     }
+    if args.precision == 'bf16':
+        # the bf16 matrix instruction needs 1/16 of the fp32 one's cycles: the same launches are bound by HBM (fp32 tensors)
+        mf = out['roofline']
+        out['roofline'] = {'bound': 'hbm',
+                           'kernel': 'conv_mfma_kernel<..., BF=true> (3x3 implicit GEMM, bf16 operands / fp32 accumulation, forward + '
+                                     'data-gradient launches): achieved = algorithmic bytes (input read once + output written once, '
+                                     'fp32) / time',
+                           'achieved': (conv_b / conv_t / 1e9) if conv_t > 0 else None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                           'frac': (conv_b / conv_t / HBM_PEAK) if conv_t > 0 else None,
+                           'traffic': pmc_traffic('r01_pmc_hbm_traffic_bf16.json'), 'launches_timed': conv_n,
+                           'avg_launch_us': mf['avg_launch_us'],
+                           'algorithmic_mbytes_per_launch': (conv_b / conv_n / 1e6) if conv_n else None,
+                           'algorithmic_gflop_per_launch': mf['algorithmic_gflop_per_launch'],
+                           'mfma_tflops': mf['achieved'], 'frac_of_bf16_mfma_peak': (mf['achieved'] * 1e12 / BF16_MFMA_PEAK)
+                           if mf['achieved'] else None, 'side_stream_weight_grad': args.overlap}
+        out['config']['precision'] = 'mixed bf16 (BASELINE config 4): conv / transposed-conv operands bf16, everything else fp32'
     if not args.no_cpu_baseline and world == 1:
         try:
             out['cpu_baseline'] = cpu_baseline()

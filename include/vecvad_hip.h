@@ -59,6 +59,10 @@ typedef struct vv_view {
  * Replaces nn.Conv2d(k3,p1) / nn.ConvTranspose2d(k3,s2,p1,op1) forward and their autograd data-gradients
  * (cuDNN in the reference: model/unet.py:10,13,54) with BatchNorm/ReLU/MaxPool/cat of the producer fused into
  * the load, bias + per-channel sum / sum-of-squares partials (BatchNorm batch statistics) fused into the store. */
+/* vv_conv_params.pad0 flag: round both operands to bf16 (nearest even) on their way into LDS and contract on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- torch.autocast(bfloat16) semantics for the convolution; tensors in
+ * HBM, bias, BatchNorm statistics and master weights stay fp32 (BASELINE config 4, "mixed bf16"). */
+#define VV_CONV_BF16 1
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */
@@ -74,7 +78,7 @@ typedef struct vv_conv_params {
   int64_t ab_gstride;
   vv_view src1;      /* VV_IN_CAT: second input (plain) */
   int32_t csplit;    /* VV_IN_CAT: channels [0,csplit) come from src0 */
-  int32_t pad0;
+  int32_t pad0;      /* flags: VV_CONV_BF16 (vv_conv_mfma only) */
   const int32_t* chmap; /* VV_IN_CUBE: [G][CinP] source channel or -1 (zero) */
   const float* w;    /* packed weights [9][CinP/8][2][Cout][4]  (see vv_pack_weights) */
   int64_t w_gstride;
@@ -112,6 +116,18 @@ typedef struct vv_wgrad_params {
 int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream);
 int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W);
 /* slabs written per (ci-tile, co-tile): ksplit (the 4 waves of a workgroup are summed in LDS first) */
+
+/* Weight gradient of the 3x3 convolution with bf16 operands / fp32 accumulation (mixed precision, BASELINE config 4;
+ * torch.autocast(bfloat16) semantics of the autograd weight gradient of nn.Conv2d, model/unet.py:10,13): act (after the
+ * deferred BatchNorm+ReLU) and dy are rounded to bf16 on their way into LDS, products accumulate in fp32 on
+ * v_mfma_f32_32x32x16_bf16.  Same parameter block as vv_wgrad_mfma (kind = VV_CONV3; pad0 ignored); H = W in {32, 16, 8}.
+ * One workgroup covers up to 64 ci x 64 co and every ksplit-th pixel tile:  slabs per (ci-tile, co-tile) = ksplit * kw.
+ * vv_wgrad_bf16_plan returns 0 when the geometry is not handled (use vv_wgrad_mfma), else 1 and
+ *   *ntiles  = pixel tiles (the upper bound of ksplit),
+ *   *nblocks = workgroups per group and k-split part,
+ *   *kw      = slabs per workgroup and (ci-tile, co-tile) (1 today): pass ksplit * kw to vv_wgrad_reduce. */
+int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream);
+int vv_wgrad_bf16_plan(int32_t B, int32_t H, int32_t W, int32_t CinP, int32_t Cout, int32_t* ntiles, int32_t* nblocks, int32_t* kw);
 
 /* Sum the slabs and scatter into PyTorch parameter layout:
  * CONV3 : grad[co][ci][ky][kx]   (nn.Conv2d.weight  [Cout,Cin,3,3])

@@ -199,12 +199,78 @@ def cubes_to_inputs(raw, flow):
 
 
 # ----------------------------------------------------------------------------------------------------
+# Mixed precision (BASELINE config 4, "mixed bf16").  The reference itself is fp32 only; config 4 asks for the
+# torch.autocast(bfloat16) treatment of the convolutions: operands rounded to bf16 (nearest even), products accumulated
+# in fp32.  MIXED = None is the reference arithmetic.  MIXED = {...} restates what the HIP path computes per operation,
+# so that the bf16 path can be checked operation by operation instead of only through AUROC:
+#   'fwd'      3x3 conv and transposed conv forward:  conv(bf16(x), bf16(w)) + b, fp32 result
+#   'dgrad'    3x3 conv data gradient:                conv_input_grad(bf16(dy), bf16(w))
+#   'dgradT'   transposed-conv data gradient          (fp32 operands while False)
+#   'wgrad'    3x3 conv weight gradient:              corr(bf16(x), bf16(dy)) for maps of at least 'wgrad_min_hw' pixels a side
+#              (the 4x4 level keeps the fp32 kernel), fp32 operands otherwise; 'wgradT' the same for the transposed conv
+# Tensors between operations, bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam stay fp32.
+# ----------------------------------------------------------------------------------------------------
+MIXED = None
+MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': False, 'wgrad': True, 'wgrad_min_hw': 8, 'wgradT': False}
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _MixedConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, transposed, cfg):
+        ctx.save_for_backward(x, w)
+        ctx.transposed, ctx.cfg = transposed, cfg
+        xr, wr = (_r(x), _r(w)) if cfg['fwd'] else (x, w)
+        if transposed:
+            return F.conv_transpose2d(xr, wr, b, stride=2, padding=1, output_padding=1)
+        return F.conv2d(xr, wr, b, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        cfg, tr = ctx.cfg, ctx.transposed
+        dx = dw = db = None
+        dq = cfg['dgradT'] if tr else cfg['dgrad']
+        dyd, wd = (_r(dy), _r(w)) if dq else (dy, w)
+        wq = cfg.get('wgradT', False) if tr else (cfg['wgrad'] and x.shape[-1] >= cfg.get('wgrad_min_hw', 0))
+        dyw, xw = (_r(dy), _r(x)) if wq else (dy, x)
+        if tr:
+            if ctx.needs_input_grad[0]:
+                dx = F.conv2d(dyd, wd, None, stride=2, padding=1)
+            if ctx.needs_input_grad[1]:
+                dw = torch.nn.grad.conv2d_weight(dyw, w.shape, xw, stride=2, padding=1)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = torch.nn.grad.conv2d_input(x.shape, wd, dyd, padding=1)
+            if ctx.needs_input_grad[1]:
+                dw = torch.nn.grad.conv2d_weight(xw, w.shape, dyw, padding=1)
+        if ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None
+
+
+def _conv3(x, w, b):
+    if MIXED is None:
+        return F.conv2d(x, w, b, padding=1)
+    return _MixedConv.apply(x, w, b, False, MIXED)
+
+
+def _convT(x, w, b):
+    if MIXED is None:
+        return F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    return _MixedConv.apply(x, w, b, True, MIXED)
+
+
+# ----------------------------------------------------------------------------------------------------
 # Functional network
 # ----------------------------------------------------------------------------------------------------
 def _double_conv(sd, prefix, x, train):
     # model/unet.py:9-16 : (conv3x3 p1 -> BN(eps 1e-5, momentum 0.1) -> ReLU) x 2
     for ci, bi in ((0, 1), (3, 4)):
-        x = F.conv2d(x, sd['%s.%d.weight' % (prefix, ci)], sd['%s.%d.bias' % (prefix, ci)], padding=1)
+        x = _conv3(x, sd['%s.%d.weight' % (prefix, ci)], sd['%s.%d.bias' % (prefix, ci)])
         rm, rv = sd['%s.%d.running_mean' % (prefix, bi)], sd['%s.%d.running_var' % (prefix, bi)]
         x = F.batch_norm(x, rm, rv, sd['%s.%d.weight' % (prefix, bi)], sd['%s.%d.bias' % (prefix, bi)],
                          training=train, momentum=0.1, eps=1e-5)
@@ -225,7 +291,7 @@ def unet_forward(sd, stems, x, train):
         skips.append(h)
     h = skips.pop()
     for u in stems['up']:
-        up = F.conv_transpose2d(h, sd[u + '.up.weight'], sd[u + '.up.bias'], stride=2, padding=1, output_padding=1)
+        up = _convT(h, sd[u + '.up.weight'], sd[u + '.up.bias'])
         h = _double_conv(sd, u + '.conv.conv', torch.cat([skips.pop(), up], dim=1), train)
     return F.conv2d(h, sd[stems['outc'] + '.conv.weight'], sd[stems['outc'] + '.conv.bias'])
 

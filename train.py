@@ -80,13 +80,15 @@ def read_config(path='config.cfg'):
              shuffle_seed=cp.getint('mi355x', 'shuffle_seed', fallback=0),
              score_batch=cp.getint('mi355x', 'score_batch', fallback=512),
              save_score_masks=cp.getboolean('mi355x', 'save_score_masks', fallback=True),
-             overlap_wgrad=cp.getboolean('mi355x', 'overlap_wgrad', fallback=False))
+             overlap_wgrad=cp.getboolean('mi355x', 'overlap_wgrad', fallback=False),
+             precision=cp.get('mi355x', 'precision', fallback='fp32').strip().lower())
     assert c['modality'] == 'raw2flow'
     return c
 
 
 def build_network(c):
     """train.py:261-268 / test.py:216-224."""
+    os.environ['VV_PRECISION'] = c.get('precision', 'fp32')       # read by the UNet bank when it is built ([mi355x] precision)
     kw = dict(features_root=c['nf'], tot_raw_num=c['tot_frame_num'], tot_of_num=c['tot_of_num'],
               border_mode=c['border_mode'], rawRange=c['rawRange'], useFlow=c['useFlow'], padding=c['padding'])
     if c['tot_of_num'] == 1:

@@ -17,6 +17,7 @@ c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 IN_PLAIN, IN_ACT, IN_POOL, IN_CAT, IN_CUBE = 0, 1, 2, 3, 4
 CONV3, CONVT_FWD, CONVT_DGRAD = 0, 1, 2
+CONV_BF16 = 1          # vv_conv_params.pad0 flag (include/vecvad_hip.h VV_CONV_BF16)
 
 
 class View(C.Structure):
@@ -82,6 +83,8 @@ _SIGS = {
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
     'vv_wgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    'vv_wgrad_bf16': (c_i32, [C.POINTER(WgradParams), c_vp]),
+    'vv_wgrad_bf16_plan': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
     'vv_wgrad_reduce': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'vv_pack_weights': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_bn_finalize': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp, c_i64,

@@ -210,8 +210,17 @@ class UNetBank:
         self.chmap, self.oc, self.tsrc, self.tcoff = chmap.to(d), oc.to(d), tsrc.to(d), tcoff.to(d)
         # VV_WINOGRAD=0 keeps the direct implicit-GEMM kernel for the 3x3 convolutions (A/B comparisons, bit-for-bit fmaf
         # chains); default: Winograd F(2x2,3x3) for forward and data-gradient (2.25x fewer MFMA cycles, a few ulp apart)
-        self.wino = os.environ.get('VV_WINOGRAD', '1') != '0'
-        self.wino_wgrad = self.wino and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
+        # VV_PRECISION=bf16 (config.cfg [mi355x] precision): mixed precision, BASELINE config 4 -- the convolutions / transposed
+        # convolutions round their operands to bf16 and contract on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (direct kernel;
+        # Winograd's transforms would amplify the bf16 rounding); tensors in HBM, BatchNorm, loss, master weights, Adam stay fp32
+        self.precision = os.environ.get('VV_PRECISION', 'fp32').lower()
+        if self.precision not in ('fp32', 'bf16'):
+            raise ValueError("VV_PRECISION / [mi355x] precision must be 'fp32' or 'bf16', got %r" % self.precision)
+        self.cflag = L.CONV_BF16 if self.precision == 'bf16' else 0
+        self.bf16_wgrad = os.environ.get('VV_BF16_WGRAD', '1') != '0'      # 0: keep the fp32 (Winograd) weight gradient in bf16 mode
+        wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
+        self.wino = wino_env and not self.cflag
+        self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
         self.wgrad_flag = int(os.environ.get('VV_WGRAD_FLAG', '256'))     # 256: Winograd (variant per level), 512: eight-wave form
         direct = [(k, v) for k, v in lay.pk.items() if not (self.wino and k[0] == 'c')]
         ents = (L.PackEntry * len(direct))()
@@ -339,7 +348,7 @@ class UNetBank:
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             y = ws.y[l.idx]
             panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
-            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, 0, chmap,
+            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, self.cflag, chmap,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
@@ -356,7 +365,7 @@ class UNetBank:
             sidx, H, ci, co = lay.convT[u]
             y, t = ws.y[sidx], ws.t[u]
             cp = L.ConvParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, L.view(y, ci, 0, y.stride(0)),
-                              self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, 0, None,
+                              self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, self.cflag, None,
                               kbase + 4 * lay.pk['t%d.f' % u][0], UP, pbase + 4 * lay.p['t%d.b' % u][0], U,
                               L.view(t, co, 0, t.stride(0)), None)
             P.keep.append(cp)
@@ -415,7 +424,13 @@ class UNetBank:
             nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
             ks = _pick_ksplit(Ga * nci * nco, nt)
             wplan['c%d' % l.idx] = (ks, nci * nco * ks)
-            wmax = max(wmax, nci * nco * ks)
+            if self.cflag and self.bf16_wgrad:
+                # bf16 weight gradient: HBM bound, one workgroup (up to 512 registers per lane) per CU
+                ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
+                if lib.vv_wgrad_bf16_plan(B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
+                    ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))      # one workgroup per CU, one round
+                    wplan['c%d' % l.idx] = (ks, nci * nco * ks * kw.value, kw.value)
+            wmax = max(wmax, wplan['c%d' % l.idx][1])
         for u, (_, H, ci, co) in enumerate(lay.convT):
             nci, nco = ci // 32, co // 32
             nt = lib.vv_wgrad_ntiles(L.CONVT_FWD, B, H, H)
@@ -478,7 +493,7 @@ class UNetBank:
             if i > 0:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
-                                  L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, 0, None,
+                                  L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, self.cflag, None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)), None)
                 P.keep.append(cp)
@@ -489,15 +504,16 @@ class UNetBank:
             # weight-gradient starts when it is done, sharing the chip with the HBM-bound BatchNorm backward of the
             # next layer only.
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
-            ks, nslab = wplan['c%d' % i]
+            wpl = wplan['c%d' % i]
+            ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)           # kw > 0: the bf16-operand kernel (mixed precision)
             # pad0 bit 8: Winograd F(2x2,3x3) form of the weight gradient (same tiles / slabs, 2.25x fewer MFMA cycles)
             wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit,
                                self.wgrad_flag if self.wino_wgrad else 0, chmap,
                                L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
-            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,), record='wdone%d' % i,
-                  pwait=('*main',))
-            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks, ws.wpart.data_ptr(), wpg,
+            P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,),
+                  record='wdone%d' % i, pwait=('*main',))
+            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * max(kw, 1), ws.wpart.data_ptr(), wpg,
                                         gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i, stream=1)
 
         def convT_bwd(u, m):

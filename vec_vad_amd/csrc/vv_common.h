@@ -58,6 +58,20 @@ __device__ __forceinline__ float4 vv_max4(float4 p, float4 q) {
   return p;
 }
 
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// 4 floats -> 4 bf16 (round to nearest even), packed in channel order
+__device__ __forceinline__ uint2 vv_pack_bf16x4(float4 v) {
+  const v2bf lo = __builtin_convertvector((v2f){v.x, v.y}, v2bf);
+  const v2bf hi = __builtin_convertvector((v2f){v.z, v.w}, v2bf);
+  uint2 o;
+  o.x = __builtin_bit_cast(unsigned, lo);
+  o.y = __builtin_bit_cast(unsigned, hi);
+  return o;
+}
+
 // Resolved (per group) description of how a convolution reads its input.
 struct VVSrc {
   const float* p0; int cs0, co0;
@@ -279,6 +293,21 @@ struct VVStagerB {
       float4 v = r[K];
       if (act && ((valid >> K) & 1u)) v = vv_act4(v, sa, sb);
       *reinterpret_cast<float4*>(lds + (it / Q) * S + (tid % Q) * 4) = v;
+    }
+  }
+
+  // bf16 operand path: the same items, rounded to nearest-even bf16 (v_cvt_pk_bf16_f32) after the deferred BatchNorm+ReLU and
+  // written as 8 B (4 channels) per item; S is still the pixel stride in floats (4 B units).
+  __device__ __forceinline__ void commit_bf16(float* lds, int tid) const {
+    const int q = tid % Q;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * NTH;
+      if (NITEMS % NTH == 0 || it < NITEMS) {
+        float4 v = r[k];
+        if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
+        *reinterpret_cast<uint2*>(lds + (it / Q) * S + q * 2) = vv_pack_bf16x4(v);
+      }
     }
   }
 

@@ -25,16 +25,24 @@ struct Geo {
   static constexpr int SP = KIND == VV_CONVT_DGRAD ? 2 : 1;  // lane pixel stride inside the halo tile
 };
 
-template <int TH, int TW, int NI, int NR, int KIND, int CK>
-__global__ void __launch_bounds__(VV_WG, ((NR == 1 && KIND != VV_CONVT_FWD) ? 3 : 2))
+// BF = true: mixed-precision variant (BASELINE config 4).  Same tiles, same fp32 tensors in HBM, same fp32 weight panels; the
+// operands are rounded to bf16 on their way into LDS (activations after the deferred BatchNorm+ReLU, weights from the fp32
+// panel) and the contraction runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: one ds_read_b128 per operand now
+// carries 8 channels of a 16-channel K step (lanes 0-31: k 0..7, lanes 32-63: k 8..15), 1/16 of the matrix-core time of the
+// fp32 instruction -- this variant is bound by HBM / staging, not by MFMA.
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF>
+__global__ void __launch_bounds__(VV_WG, ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
-  constexpr int S = CK + 4;             // LDS pixel stride (floats): S/4 odd -> conflict-free ds_read_b128
+  static_assert(!BF || CK % 16 == 0, "bf16 K step = 16 channels");
+  // LDS pixel stride (floats): S/4 odd -> conflict-free ds_read_b128.  bf16: CK/2 floats of data + 16 B pad
+  constexpr int S = BF ? CK / 2 + ((CK / 8) % 2 ? 8 : 4) : CK + 4;
   constexpr int S4 = S / 4;
+  static_assert(S4 % 2 == 1, "odd float4 stride");
   constexpr int MR = 2;                 // 2 x 32 pixels per wave
   constexpr int TN = NR * 32;
-  constexpr int KGC = CK / 8;           // 8-channel groups per chunk
+  constexpr int KGC = BF ? CK / 16 : CK / 8;   // K groups per chunk: 8 fp32 channels (4 MFMAs) or 16 bf16 channels (1 MFMA)
   constexpr int A4 = NI * HH * HW * S4; // float4 slots of the activation halo tile
   constexpr int BROWS = 9 * KGC * 2;    // weight panel rows of one chunk: [tap][kg][half]
   constexpr int B4 = BROWS * TN;
@@ -93,14 +101,16 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   VVStagerB<NI, HH, HW, S, CK> stA;
   stA.init(s, ox0, tid);            // every tile spans full rows (TW == W): the column origin is tile independent
   unsigned boff[NBT];
-  float4 rb[NBT];
+  float4 rb[NBT], rb2[BF ? NBT : 1];
 #pragma unroll
   for (int k = 0; k < NBT; ++k) {
     const int it = tid + k * VV_WG;
     const int col = it % TN, row = it / TN;            // row = (tap*KGC + kg)*2 + half
     const int hf = row & 1, tk = row >> 1;
     const int kg = tk % KGC, tap = tk / KGC;
-    boff[k] = (B4 % VV_WG == 0 || it < B4) ? (unsigned)(((tap * KQ + kg) * 2 + hf) * Cout + co0 + col) * 16u : 0x80000000u;
+    // bf16: LDS row (tap, kg, half) = channels 16 kg + 8 half + 0..7 = fp32 panel rows (tap, 2 kg + half, 0) and (.., 1)
+    const int prow = BF ? (tap * KQ + 2 * kg + hf) * 2 : (tap * KQ + kg) * 2 + hf;
+    boff[k] = (B4 % VV_WG == 0 || it < B4) ? (unsigned)(prow * Cout + co0 + col) * 16u : 0x80000000u;
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   auto issue = [&](const int c0) {
@@ -110,14 +120,25 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     for (int k = 0; k < NBT; ++k) {
       const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rsW, boff[k], so, 0);
       rb[k] = make_float4(v.x, v.y, v.z, v.w);
+      if constexpr (BF) {
+        const v4f u = __builtin_amdgcn_raw_buffer_load_b128(rsW, boff[k], so + Cout * 16, 0);
+        rb2[k] = make_float4(u.x, u.y, u.z, u.w);
+      }
     }
   };
   auto commit = [&]() {
-    stA.commit(lds, tid);
+    if constexpr (BF) stA.commit_bf16(lds, tid); else stA.commit(lds, tid);
 #pragma unroll
     for (int k = 0; k < NBT; ++k) {
       const int it = tid + k * VV_WG;
-      if (B4 % VV_WG == 0 || it < B4) lds4[A4 + it] = rb[k];
+      if (B4 % VV_WG == 0 || it < B4) {
+        if constexpr (BF) {
+          const uint2 lo = vv_pack_bf16x4(rb[k]), hi = vv_pack_bf16x4(rb2[k]);
+          *reinterpret_cast<uint4*>(&lds4[A4 + it]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+          lds4[A4 + it] = rb[k];
+        }
+      }
     }
   };
 
@@ -163,10 +184,15 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             const int an = KIND == VV_CONVT_FWD ? phc : n;
-            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[cur][n].x, acc[m][an], 0, 0, 0);
-            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[cur][n].y, acc[m][an], 0, 0, 0);
-            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][an], 0, 0, 0);
-            acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][an], 0, 0, 0);
+            if constexpr (BF) {
+              acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fa[cur][m]),
+                                                                   __builtin_bit_cast(v8bf, fb[cur][n]), acc[m][an], 0, 0, 0);
+            } else {
+              acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].x, fb[cur][n].x, acc[m][an], 0, 0, 0);
+              acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].y, fb[cur][n].y, acc[m][an], 0, 0, 0);
+              acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][an], 0, 0, 0);
+              acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][an], 0, 0, 0);
+            }
             if (it + 1 < NIT) {
               const int last = (m == MR - 1 && n == NR - 1);
               // spread MR+NR reads over MR*NR MFMA groups (the last group takes whatever is left)
@@ -254,19 +280,19 @@ inline bool tile_geo(int H, int W, TileGeo* t) {
   return false;
 }
 
-template <int TH, int TW, int NI, int NR, int KIND, int CK>
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false>
 int launch(const vv_conv_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NN = p->Cout / (NR * 32);
   const int total = p->G * NN * NT;
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
+  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK, BF>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
                      total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
 
-template <int KIND, int CK>
+template <int KIND, int CK, bool BF>
 int dispatch(const vv_conv_params* p, hipStream_t st) {
   TileGeo t;
   if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
@@ -274,20 +300,22 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   // (512 slots) a launch needs >= 2 full rounds of them, otherwise 32-wide tiles fill the machine better.
   const int nt = ((p->B + t.NI - 1) / t.NI) * (p->H / t.TH) * (p->W / t.TW);
   const bool wide = KIND != VV_CONVT_FWD && (p->Cout % 64) == 0 && (int64_t)p->G * nt * (p->Cout / 64) >= 1024;
-  constexpr int CKD = KIND == VV_CONVT_DGRAD ? 8 : 16;
+  // K chunk: 16 channels (fp32: 8 for the stride-2 gather and the 16-image 4x4 tiles, whose halo tiles are large)
+  constexpr int CKD = BF ? 16 : (KIND == VV_CONVT_DGRAD ? 8 : 16);
+  constexpr int CK4 = BF ? 16 : 8;
   if constexpr (KIND == VV_CONVT_FWD) {        // four phase accumulators: 32-wide N tiles only
     switch (p->H) {
-      case 32: return launch<8, 32, 1, 1, KIND, CKD>(p, st);
-      case 16: return launch<16, 16, 1, 1, KIND, CKD>(p, st);
-      case 8: return launch<8, 8, 4, 1, KIND, CKD>(p, st);
-      case 4: return launch<4, 4, 16, 1, KIND, 8>(p, st);
+      case 32: return launch<8, 32, 1, 1, KIND, CKD, BF>(p, st);
+      case 16: return launch<16, 16, 1, 1, KIND, CKD, BF>(p, st);
+      case 8: return launch<8, 8, 4, 1, KIND, CKD, BF>(p, st);
+      case 4: return launch<4, 4, 16, 1, KIND, CK4, BF>(p, st);
     }
   } else {
     switch (p->H) {
-      case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD>(p, st) : launch<8, 32, 1, 1, KIND, CKD>(p, st);
-      case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD>(p, st) : launch<16, 16, 1, 1, KIND, CKD>(p, st);
-      case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD>(p, st) : launch<8, 8, 4, 1, KIND, CKD>(p, st);
-      case 4: return wide ? launch<4, 4, 16, 2, KIND, 8>(p, st) : launch<4, 4, 16, 1, KIND, 8>(p, st);   // 16 images x 6x6 halo: small chunks
+      case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD, BF>(p, st) : launch<8, 32, 1, 1, KIND, CKD, BF>(p, st);
+      case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD, BF>(p, st) : launch<16, 16, 1, 1, KIND, CKD, BF>(p, st);
+      case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD, BF>(p, st) : launch<8, 8, 4, 1, KIND, CKD, BF>(p, st);
+      case 4: return wide ? launch<4, 4, 16, 2, KIND, CK4, BF>(p, st) : launch<4, 4, 16, 1, KIND, CK4, BF>(p, st);
     }
   }
   return VV_ERR_UNSUPPORTED;
@@ -306,16 +334,19 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   if (p->G <= 0 || p->B <= 0) return VV_ERR_BAD_ARG;
   if (p->Cout % 32) return VV_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  const bool bf = (p->pad0 & VV_CONV_BF16) != 0;
+  if (p->CinP % 8) return VV_ERR_BAD_ARG;
   switch (p->kind) {
     case VV_CONV3:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
-      return dispatch<VV_CONV3, 16>(p, st);
+      return bf ? dispatch<VV_CONV3, 16, true>(p, st) : dispatch<VV_CONV3, 16, false>(p, st);
     case VV_CONVT_FWD:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
-      return dispatch<VV_CONVT_FWD, 16>(p, st);
+      return bf ? dispatch<VV_CONVT_FWD, 16, true>(p, st) : dispatch<VV_CONVT_FWD, 16, false>(p, st);
     case VV_CONVT_DGRAD:
-      if (p->CinP % 8) return VV_ERR_BAD_ARG;
-      return dispatch<VV_CONVT_DGRAD, 8>(p, st);
+      // no bf16 variant yet: the stride-2 gather's halo tile is 4x the output tile, a 16-channel chunk of it does not fit
+      // the register-staged pipeline; the flag is ignored (fp32 operands) for this kind
+      return dispatch<VV_CONVT_DGRAD, 8, false>(p, st);
   }
   return VV_ERR_BAD_ARG;
 }
