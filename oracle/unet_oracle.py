@@ -211,7 +211,7 @@ def cubes_to_inputs(raw, flow):
 # Tensors between operations, bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam stay fp32.
 # ----------------------------------------------------------------------------------------------------
 MIXED = None
-MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': False, 'wgrad': True, 'wgrad_min_hw': 8, 'wgradT': False}
+MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 8, 'wgradT': True}
 
 
 def _r(t):

@@ -108,6 +108,32 @@ def test_bf16_transposed_conv_forward(H, Cin, Cout, B):
         assert (got - ref).abs().max().item() <= 2e-4 * scale
 
 
+@pytest.mark.parametrize('H,Cin,Cout,B', [(16, 64, 32, 3), (8, 128, 64, 5), (4, 256, 128, 17)])
+def test_bf16_transposed_conv_data_gradient(H, Cin, Cout, B):
+    """Data gradient of ConvTranspose2d(k3, s2, p1, op1) (a stride-2 gather over the 2H x 2W output gradient) with bf16 operands:
+    d(in)[ci] = conv2d(bf16(dy), bf16(Wt), stride 2, pad 1) in fp64."""
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H * 55 + Cin)
+    dy = torch.randn(G, B * 4 * H * H, Cout, generator=g).cuda()
+    wt = (torch.randn(G, Cin, Cout, 3, 3, generator=g) * 0.1).cuda()          # nn.ConvTranspose2d layout per group
+    st = torch.cuda.current_stream().cuda_stream
+    pk = _pack(lib, L, wt, G, 3, Cout, Cin, st)
+    out = torch.full((G, B * H * H, Cin), 3.0, device='cuda')
+    cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, G, B, H, H, Cout, Cout, Cin, L.view(dy, Cout, 0, dy.stride(0)), None, None, 0,
+                      L.NULL_VIEW, 0, L.CONV_BF16, None, pk.data_ptr(), pk.stride(0), None, 0, L.view(out, Cin, 0, out.stride(0)), None)
+    L.check(lib.vv_conv_mfma(C.byref(cp), st), 'dgradT')
+    for gi in range(G):
+        dyn = dy[gi].view(B, 2 * H, 2 * H, Cout).permute(0, 3, 1, 2)
+        ref = F.conv2d(_r(dyn).double(), _r(wt[gi]).double(), None, stride=2, padding=1)
+        ref32 = F.conv2d(dyn.double(), wt[gi].double(), None, stride=2, padding=1)
+        got = out[gi].view(B, H, H, Cin).permute(0, 3, 1, 2).double()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-4 * scale
+        assert (got - ref32).abs().max().item() > 2e-4 * scale
+
+
 @pytest.mark.parametrize('H,Cin,CinP,Cout,B,ks', [(32, 12, 16, 32, 2, 3), (32, 32, 32, 32, 3, 1), (32, 64, 64, 32, 2, 5), (32, 32, 32, 64, 1, 2),
                                                  (16, 64, 64, 64, 5, 4), (16, 128, 128, 64, 2, 1), (8, 128, 128, 128, 9, 2),
                                                  (8, 256, 256, 128, 3, 1)])
@@ -130,7 +156,7 @@ def test_bf16_weight_gradient_matches_rounded_operand_reference(H, Cin, CinP, Co
         b[:, Cin:] = 0
     st = torch.cuda.current_stream().cuda_stream
     nt, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
-    assert lib.vv_wgrad_bf16_plan(B, H, H, CinP, Cout, C.byref(nt), C.byref(nblk), C.byref(kw)) == 1
+    assert lib.vv_wgrad_bf16_plan(L.CONV3, B, H, H, CinP, Cout, C.byref(nt), C.byref(nblk), C.byref(kw)) == 1
     ks = min(ks, nt.value)
     nci, nco = (CinP + 31) // 32, Cout // 32
     outs = []
@@ -154,6 +180,42 @@ def test_bf16_weight_gradient_matches_rounded_operand_reference(H, Cin, CinP, Co
         err = (outs[0][gi].double() - ref).abs().max().item()
         assert err <= 2e-4 * scale, (gi, err, scale)
         assert (outs[0][gi].double() - ref32).abs().max().item() > 2e-4 * scale
+
+
+@pytest.mark.parametrize('H,Cin,Cout,B,ks', [(16, 64, 32, 3, 2), (8, 128, 64, 5, 1), (4, 256, 128, 17, 3), (8, 32, 32, 2, 1), (16, 32, 64, 1, 2)])
+def test_bf16_transposed_conv_weight_gradient(H, Cin, Cout, B, ks):
+    """vv_wgrad_bf16 with kind = VV_CONVT_FWD (weight gradient of ConvTranspose2d(k3,s2,p1,op1), H x W = its input): against the
+    float64 weight gradient of the bf16-rounded operands in the nn.ConvTranspose2d layout [Cin][Cout][3][3]."""
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H * 31 + Cin)
+    x = torch.randn(G, B * H * H, Cin, generator=g).cuda()
+    dy = torch.randn(G, B * 4 * H * H, Cout, generator=g).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    nt, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.vv_wgrad_bf16_plan(L.CONVT_FWD, B, H, H, Cin, Cout, C.byref(nt), C.byref(nblk), C.byref(kw)) == 1
+    ks = min(ks, nt.value)
+    nci, nco = Cin // 32, Cout // 32
+    part = torch.full((G, nci * nco * ks * kw.value * 9 * 1024), 7.0, device='cuda')
+    grad = torch.zeros(G, Cin * Cout * 9, device='cuda')
+    wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, G, B, H, H, Cin, Cin, Cout, ks, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(),
+                       Cin, L.NULL_VIEW, 0, 0, None, L.View(dy.data_ptr(), dy.stride(0), Cout, 0), part.data_ptr(), part.stride(0))
+    L.check(lib.vv_wgrad_bf16(C.byref(wp), st), 'wgradT_bf16')
+    L.check(lib.vv_wgrad_reduce(L.CONVT_FWD, G, Cin, Cin, Cout, ks * kw.value, part.data_ptr(), part.stride(0), grad.data_ptr(),
+                                grad.stride(0), st), 'reduce')
+    got = grad.view(G, Cin, Cout, 3, 3)
+    for gi in range(G):
+        act = torch.relu(torch.addcmul(b[gi].view(1, -1, 1, 1), x[gi].view(B, H, H, Cin).permute(0, 3, 1, 2), a[gi].view(1, -1, 1, 1)))
+        dyn = dy[gi].view(B, 2 * H, 2 * H, Cout).permute(0, 3, 1, 2)
+        # conv_transpose2d(x, Wt) == the data gradient of conv2d(., Wt, stride 2, pad 1): dWt = conv2d_weight(dy, Wt.shape, x)
+        ref = torch.nn.grad.conv2d_weight(_r(dyn).double(), (Cin, Cout, 3, 3), _r(act).double(), stride=2, padding=1)
+        ref32 = torch.nn.grad.conv2d_weight(dyn.double(), (Cin, Cout, 3, 3), act.double(), stride=2, padding=1)
+        scale = ref.abs().max().item()
+        assert (got[gi].double() - ref).abs().max().item() <= 2e-4 * scale
+        assert (got[gi].double() - ref32).abs().max().item() > 2e-4 * scale
 
 
 def _build_bf16(monkeypatch, kind='net4'):

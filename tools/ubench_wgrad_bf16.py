@@ -19,7 +19,7 @@ def run(H, Cin, Cout, ks=None, reps=10, dbg=0):
     b = torch.randn(G, Cin, device=dev) * 0.1
     nci, nco = (Cin + 31) // 32, Cout // 32
     nt, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
-    assert lib.vv_wgrad_bf16_plan(B, H, H, Cin, Cout, C.byref(nt), C.byref(nblk), C.byref(kw))
+    assert lib.vv_wgrad_bf16_plan(0, B, H, H, Cin, Cout, C.byref(nt), C.byref(nblk), C.byref(kw))
     if ks is None:
         ks = max(1, min(nt.value, 256 // (G * nblk.value)))
     part = torch.empty(G, nci * nco * ks * kw.value * 9 * 1024, device=dev)

@@ -84,7 +84,7 @@ _SIGS = {
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
     'vv_wgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     'vv_wgrad_bf16': (c_i32, [C.POINTER(WgradParams), c_vp]),
-    'vv_wgrad_bf16_plan': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
+    'vv_wgrad_bf16_plan': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
     'vv_wgrad_reduce': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'vv_pack_weights': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_bn_finalize': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp, c_i64,

@@ -427,7 +427,7 @@ class UNetBank:
             if self.cflag and self.bf16_wgrad:
                 # bf16 weight gradient: HBM bound, one workgroup (up to 512 registers per lane) per CU
                 ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
-                if lib.vv_wgrad_bf16_plan(B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
+                if lib.vv_wgrad_bf16_plan(L.CONV3, B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
                     ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))      # one workgroup per CU, one round
                     wplan['c%d' % l.idx] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['c%d' % l.idx][1])
@@ -436,7 +436,12 @@ class UNetBank:
             nt = lib.vv_wgrad_ntiles(L.CONVT_FWD, B, H, H)
             ks = _pick_ksplit(Ga * nci * nco, nt)
             wplan['t%d' % u] = (ks, nci * nco * ks)
-            wmax = max(wmax, nci * nco * ks)
+            if self.cflag and self.bf16_wgrad:
+                ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
+                if lib.vv_wgrad_bf16_plan(L.CONVT_FWD, B, H, H, ci, co, C.byref(ntb), C.byref(nblk), C.byref(kw)):
+                    ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))
+                    wplan['t%d' % u] = (ks, nci * nco * ks * kw.value, kw.value)
+            wmax = max(wmax, wplan['t%d' % u][1])
         ws.wpart = f(Ga, wmax * 9 * 1024)
         wpg = ws.wpart.stride(0)
 
@@ -523,7 +528,7 @@ class UNetBank:
             skipc = lay.convs[m.skip].cout
             dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
             DT = ws.DT[u]
-            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, 0, None,
+            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, self.cflag, None,
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
@@ -531,13 +536,14 @@ class UNetBank:
                                      ws.bscr.data_ptr(), gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u, stream=1,
                   wait=('D%d' % m.idx,), pwait=('*main',))
             y = ws.y[sidx]
-            ks, nslab = wplan['t%d' % u]
+            wpl = wplan['t%d' % u]
+            ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)
             wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
                                self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, 0, None, dy,
                                ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
-            P.add(lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1)
-            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks, ws.wpart.data_ptr(), wpg,
+            P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1)
+            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr(), wpg,
                                         gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
 
         for l in reversed(lay.convs):

@@ -31,7 +31,7 @@ struct Geo {
 // carries 8 channels of a 16-channel K step (lanes 0-31: k 0..7, lanes 32-63: k 8..15), 1/16 of the matrix-core time of the
 // fp32 instruction -- this variant is bound by HBM / staging, not by MFMA.
 template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF>
-__global__ void __launch_bounds__(VV_WG, ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2))
+__global__ void __launch_bounds__(VV_WG, (BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
@@ -299,6 +299,7 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   // 64-wide N tiles halve the activation re-staging but also halve the workgroup count; with 2 workgroups per CU
   // (512 slots) a launch needs >= 2 full rounds of them, otherwise 32-wide tiles fill the machine better.
   const int nt = ((p->B + t.NI - 1) / t.NI) * (p->H / t.TH) * (p->W / t.TW);
+  // (bf16 stride-2 gather: the 4x halo tile of a 16-channel chunk takes ~400 registers per lane -- one workgroup per CU)
   const bool wide = KIND != VV_CONVT_FWD && (p->Cout % 64) == 0 && (int64_t)p->G * nt * (p->Cout / 64) >= 1024;
   // K chunk: 16 channels (fp32: 8 for the stride-2 gather and the 16-image 4x4 tiles, whose halo tiles are large)
   constexpr int CKD = BF ? 16 : (KIND == VV_CONVT_DGRAD ? 8 : 16);
@@ -344,9 +345,8 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
       return bf ? dispatch<VV_CONVT_FWD, 16, true>(p, st) : dispatch<VV_CONVT_FWD, 16, false>(p, st);
     case VV_CONVT_DGRAD:
-      // no bf16 variant yet: the stride-2 gather's halo tile is 4x the output tile, a 16-channel chunk of it does not fit
-      // the register-staged pipeline; the flag is ignored (fp32 operands) for this kind
-      return dispatch<VV_CONVT_DGRAD, 8, false>(p, st);
+      if (bf && p->CinP % 16) return VV_ERR_BAD_ARG;
+      return bf ? dispatch<VV_CONVT_DGRAD, 8, true>(p, st) : dispatch<VV_CONVT_DGRAD, 8, false>(p, st);
   }
   return VV_ERR_BAD_ARG;
 }

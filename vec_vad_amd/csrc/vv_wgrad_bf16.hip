@@ -182,12 +182,172 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed convolution (k3, s2, p1, op1):  dW[tap][ci][co] = sum_pixels bf16(act[pixel][ci]) * bf16(dy[2*pixel - 1 + tap][co]).
+// Same scheme with the roles swapped: the un-shifted operand is the layer input (8 reads), the tap-shifted one is the output
+// gradient, gathered at stride 2 from a (2TH+1) x (2TW+1) halo tile -- the three column taps of a row share 17 reads (9 per
+// row on the 4x4 level, where a lane's 8 pixels are a 2x4 block).  Pixel tiles of 128 (8 K steps) keep the 4x halo tile of up to
+// 64 output channels in LDS.
+template <int TH, int TW, int NI, int CB, int OB>
+__global__ void __launch_bounds__(VV_WG, 1)
+wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+  constexpr int KW = 4 / (CB * OB);
+  constexpr int NKS = 8 / KW;                // K steps per wave and tile
+  constexpr int BHH = 2 * TH + 1, BHW = 2 * TW + 1;
+  constexpr int S = 18;
+  constexpr int APX = NI * TH * TW, BPX = NI * BHH * BHW;
+  constexpr int ASZ = APX * S, BSZ = BPX * S;
+  static_assert(APX == 128, "8 K steps per tile");
+  constexpr int TSZ = CB * ASZ + OB * BSZ;
+  constexpr int RSZ = KW > 1 ? CB * OB * 9 * 1024 : 0;
+  __shared__ float lds[TSZ > RSZ ? TSZ : RSZ];
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int KS = p.ksplit;
+  const int NCI2 = NCI / CB, NCO2 = NCO / OB;
+  const int ks = w % KS; w /= KS;
+  const int cot2 = w % NCO2; w /= NCO2;
+  const int cit2 = w % NCI2;
+  const int g = w / NCI2;
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W;
+  const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
+  const int blk = KW == 1 ? wave : (KW == 2 ? (wave & 1) : 0);
+  const int kq = KW == 1 ? 0 : (KW == 2 ? (wave >> 1) : wave);
+  const int cb = CB == 2 ? (OB == 2 ? (blk >> 1) : blk) : 0;
+  const int ob = OB == 2 ? (blk & 1) : 0;
+
+  const VVSrc sa = vv_make_src(p, g, H, W);
+  VVSrc sb;
+  sb.p0 = p.dy.ptr + (int64_t)g * p.dy.gstride; sb.cs0 = p.dy.cstride; sb.co0 = p.dy.coff;
+  sb.a = sb.b = nullptr; sb.p1 = nullptr; sb.cs1 = sb.co1 = 0; sb.chmap = nullptr; sb.csplit = 0;
+  sb.mode = VV_IN_PLAIN; sb.SH = 2 * H; sb.SW = 2 * W; sb.B = p.B;
+
+  v16f acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  VVStagerB<NI, TH, TW, S, 32> stA0, stA1;
+  VVStagerB<NI, BHH, BHW, S, 32> stB0, stB1;
+  stA0.init(sa, 0, tid);
+  if constexpr (CB == 2) stA1.init(sa, 0, tid);
+  stB0.init(sb, -1, tid);
+  if constexpr (OB == 2) stB1.init(sb, -1, tid);
+  auto issue = [&](const int pt) __attribute__((always_inline)) {
+    const int img0 = (pt / tpi) * NI;
+    const int trem = pt % tpi;
+    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+    stA0.prefetch(sa, img0, ty0, tx0, (cit2 * CB) * 32, tid, p.CinP);
+    if constexpr (CB == 2) stA1.prefetch(sa, img0, ty0, tx0, (cit2 * CB + 1) * 32, tid, p.CinP);
+    stB0.prefetch(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB) * 32, tid, p.Cout);
+    if constexpr (OB == 2) stB1.prefetch(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB + 1) * 32, tid, p.Cout);
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    stA0.commit_bf16(lds, tid);
+    if constexpr (CB == 2) stA1.commit_bf16(lds + ASZ, tid);
+    stB0.commit_bf16(lds + CB * ASZ, tid);
+    if constexpr (OB == 2) stB1.commit_bf16(lds + CB * ASZ + BSZ, tid);
+  };
+
+  const unsigned* ldsw = reinterpret_cast<const unsigned*>(lds);
+  const unsigned* xt = ldsw + cb * ASZ + (l31 >> 1);
+  const unsigned* yt = ldsw + CB * ASZ + ob * BSZ + (l31 >> 1);
+  const unsigned sel = (l31 & 1) ? 0x07060302u : 0x05040100u;
+  auto pk = [&](const unsigned a, const unsigned b) -> unsigned { return __builtin_amdgcn_perm(b, a, sel); };
+
+  issue(ks);
+  for (int pt = ks; pt < NT; pt += KS) {
+    if (pt != ks) __syncthreads();
+    commit();
+    __syncthreads();
+    if (pt + KS < NT) issue(pt + KS);
+
+    vv_static_for<0, NKS>([&](auto KK) {
+      const int k = kq * NKS + KK.value;          // K step of the tile: 16 pixels, 8 per half-wave
+      // this lane's 8 pixels: image im, rows r .. r+GR-1, columns c0 .. c0+GC-1 (GR x GC = 1x8, or 2x4 on the 4x4 level)
+      constexpr int GR = TW == 4 ? 2 : 1, GC = 8 / GR;
+      int im, r, c0;
+      if constexpr (TW == 16) { im = 0; r = k; c0 = 8 * half; }
+      else if constexpr (TW == 8) { im = half; r = k; c0 = 0; }
+      else { im = k; r = 2 * half; c0 = 0; }
+      const unsigned* xp = xt + ((im * TH + r) * TW + c0) * S;
+      const unsigned* yp = yt + ((im * BHH + 2 * r) * BHW + 2 * c0) * S;   // halo row 2r (image row 2r-1), halo column 2c0
+      unsigned xv[8];
+#pragma unroll
+      for (int i = 0; i < GR; ++i)
+#pragma unroll
+        for (int j = 0; j < GC; ++j) xv[i * GC + j] = xp[(i * TW + j) * S];
+      const v8bf aq = __builtin_bit_cast(v8bf, (v4u){pk(xv[0], xv[1]), pk(xv[2], xv[3]), pk(xv[4], xv[5]), pk(xv[6], xv[7])});
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        unsigned dv[GR][2 * GC + 1];
+#pragma unroll
+        for (int i = 0; i < GR; ++i)
+#pragma unroll
+          for (int j = 0; j < 2 * GC + 1; ++j) dv[i][j] = yp[((2 * i + ky) * BHW + j) * S];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          v4u bq;
+          if constexpr (GR == 1) {
+            bq = (v4u){pk(dv[0][kx], dv[0][kx + 2]), pk(dv[0][kx + 4], dv[0][kx + 6]), pk(dv[0][kx + 8], dv[0][kx + 10]),
+                       pk(dv[0][kx + 12], dv[0][kx + 14])};
+          } else {
+            bq = (v4u){pk(dv[0][kx], dv[0][kx + 2]), pk(dv[0][kx + 4], dv[0][kx + 6]), pk(dv[GR - 1][kx], dv[GR - 1][kx + 2]),
+                       pk(dv[GR - 1][kx + 4], dv[GR - 1][kx + 6])};
+          }
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, __builtin_bit_cast(v8bf, bq), acc[ky * 3 + kx], 0, 0, 0);
+        }
+      }
+    });
+  }
+
+  const int cit = cit2 * CB + cb, cot = cot2 * OB + ob;
+  float* out = p.partial + (int64_t)g * p.partial_gstride + ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024);
+  if constexpr (KW == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+        out[t * 1024 + row * 32 + l31] = acc[t][i];
+      }
+  } else {
+    float* red = lds + blk * (9 * 1024);
+    __syncthreads();
+    for (int wv = 0; wv < KW; ++wv) {
+      if (kq == wv) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+            float* q = red + t * 1024 + row * 32 + l31;
+            const float v = wv ? *q + acc[t][i] : acc[t][i];
+            if (wv == KW - 1) out[t * 1024 + row * 32 + l31] = v; else *q = v;
+          }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 struct BGeo { int TH, TW, NI; };
-inline bool bgeo(int H, int W, BGeo* t) {
+inline bool bgeo(int kind, int H, int W, BGeo* t) {
   if (H != W) return false;
-  if (H == 32) { *t = {8, 32, 1}; return true; }
-  if (H == 16) { *t = {16, 16, 1}; return true; }
-  if (H == 8) { *t = {8, 8, 4}; return true; }
+  if (kind == VV_CONV3) {
+    if (H == 32) { *t = {8, 32, 1}; return true; }
+    if (H == 16) { *t = {16, 16, 1}; return true; }
+    if (H == 8) { *t = {8, 8, 4}; return true; }
+    return false;
+  }
+  if (H == 16) { *t = {8, 16, 1}; return true; }      // transposed conv: H x W = its INPUT resolution
+  if (H == 8) { *t = {8, 8, 2}; return true; }
+  if (H == 4) { *t = {4, 4, 8}; return true; }
   return false;
 }
 
@@ -203,6 +363,28 @@ int launch_b(const vv_wgrad_params* p, hipStream_t st) {
   return VV_OK;
 }
 
+template <int TH, int TW, int NI, int CB, int OB>
+int launch_t(const vv_wgrad_params* p, hipStream_t st) {
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  if (p->ksplit > NT) return VV_ERR_BAD_ARG;
+  const int total = p->G * (NCI / CB) * (NCO / OB) * p->ksplit;
+  const int nper = (total + 7) / 8;
+  VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+template <int TH, int TW, int NI>
+int dispatch_t(const vv_wgrad_params* p, hipStream_t st) {
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  const bool c2 = NCI % 2 == 0, o2 = NCO % 2 == 0 && TW != 4;     // 4x4 level: two 4x halo tiles of 8 images spill registers
+  if (c2 && o2) return launch_t<TH, TW, NI, 2, 2>(p, st);
+  if (c2) return launch_t<TH, TW, NI, 2, 1>(p, st);
+  if (o2) return launch_t<TH, TW, NI, 1, 2>(p, st);
+  return launch_t<TH, TW, NI, 1, 1>(p, st);
+}
+
 template <int TH, int TW, int NI>
 int dispatch_b(const vv_wgrad_params* p, hipStream_t st) {
   const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
@@ -215,12 +397,12 @@ int dispatch_b(const vv_wgrad_params* p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int vv_wgrad_bf16_plan(int32_t B, int32_t H, int32_t W, int32_t CinP, int32_t Cout, int32_t* ntiles, int32_t* nblocks,
-                                  int32_t* kw) {
+extern "C" int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W, int32_t CinP, int32_t Cout, int32_t* ntiles,
+                                  int32_t* nblocks, int32_t* kw) {
   BGeo t;
-  if (!bgeo(H, W, &t) || Cout % 32 || CinP <= 0) return 0;
+  if (!bgeo(kind, H, W, &t) || Cout % 32 || CinP <= 0) return 0;
   const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
-  const int cbk = NCI % 2 == 0 ? 2 : 1, obk = NCO % 2 == 0 ? 2 : 1;
+  const int cbk = NCI % 2 == 0 ? 2 : 1, obk = (NCO % 2 == 0 && !(kind != VV_CONV3 && t.TW == 4)) ? 2 : 1;
   if (ntiles) *ntiles = ((B + t.NI - 1) / t.NI) * (H / t.TH) * (W / t.TW);
   if (nblocks) *nblocks = (NCI / cbk) * (NCO / obk);
   if (kw) *kw = 1;      // the waves of a workgroup are summed in LDS: one slab per (ci-tile, co-tile) and k-split part
@@ -230,9 +412,16 @@ extern "C" int vv_wgrad_bf16_plan(int32_t B, int32_t H, int32_t W, int32_t CinP,
 extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
   if (!p || !p->src0.ptr || !p->dy.ptr || !p->partial) return VV_ERR_BAD_ARG;
   if (p->Cout % 32 || p->ksplit < 1) return VV_ERR_BAD_ARG;
-  if (p->kind != VV_CONV3) return VV_ERR_UNSUPPORTED;
   if (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE) return VV_ERR_UNSUPPORTED;   // feed the materialised tensor
   hipStream_t st = (hipStream_t)stream;
+  if (p->kind != VV_CONV3) {                   // weight gradient of the transposed conv (H x W = its input resolution)
+    switch (p->H == p->W ? p->H : 0) {
+      case 16: return dispatch_t<8, 16, 1>(p, st);
+      case 8: return dispatch_t<8, 8, 2>(p, st);
+      case 4: return dispatch_t<4, 4, 8>(p, st);
+    }
+    return VV_ERR_UNSUPPORTED;
+  }
   switch (p->H == p->W ? p->H : 0) {
     case 32: return dispatch_b<8, 32, 1>(p, st);
     case 16: return dispatch_b<16, 16, 1>(p, st);
