@@ -120,7 +120,7 @@ int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W);
 /* Weight gradient of the 3x3 convolution with bf16 operands / fp32 accumulation (mixed precision, BASELINE config 4;
  * torch.autocast(bfloat16) semantics of the autograd weight gradient of nn.Conv2d, model/unet.py:10,13): act (after the
  * deferred BatchNorm+ReLU) and dy are rounded to bf16 on their way into LDS, products accumulate in fp32 on
- * v_mfma_f32_32x32x16_bf16.  Same parameter block as vv_wgrad_mfma (pad0 ignored); kind = VV_CONV3 with H = W in {32, 16, 8}, or
+ * v_mfma_f32_32x32x16_bf16.  Same parameter block as vv_wgrad_mfma (pad0 ignored); kind = VV_CONV3 with H = W in {32, 16, 8, 4}, or
  * VV_CONVT_FWD (weight gradient of nn.ConvTranspose2d(k3,s2,p1,op1), model/unet.py:54) with H = W in {16, 8, 4}.
  * One workgroup covers up to 64 ci x 64 co and every ksplit-th pixel tile:  slabs per (ci-tile, co-tile) = ksplit * kw.
  * vv_wgrad_bf16_plan returns 0 when the geometry is not handled (use vv_wgrad_mfma), else 1 and

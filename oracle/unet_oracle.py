@@ -206,12 +206,12 @@ def cubes_to_inputs(raw, flow):
 #   'fwd'      3x3 conv and transposed conv forward:  conv(bf16(x), bf16(w)) + b, fp32 result
 #   'dgrad'    3x3 conv data gradient:                conv_input_grad(bf16(dy), bf16(w))
 #   'dgradT'   transposed-conv data gradient          (fp32 operands while False)
-#   'wgrad'    3x3 conv weight gradient:              corr(bf16(x), bf16(dy)) for maps of at least 'wgrad_min_hw' pixels a side
-#              (the 4x4 level keeps the fp32 kernel), fp32 operands otherwise; 'wgradT' the same for the transposed conv
+#   'wgrad'    3x3 conv weight gradient:              corr(bf16(x), bf16(dy)) for maps of at least 'wgrad_min_hw' pixels a side,
+#              fp32 operands otherwise; 'wgradT' the same for the transposed conv
 # Tensors between operations, bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam stay fp32.
 # ----------------------------------------------------------------------------------------------------
 MIXED = None
-MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 8, 'wgradT': True}
+MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 0, 'wgradT': True}
 
 
 def _r(t):

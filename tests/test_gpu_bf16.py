@@ -136,7 +136,7 @@ def test_bf16_transposed_conv_data_gradient(H, Cin, Cout, B):
 
 @pytest.mark.parametrize('H,Cin,CinP,Cout,B,ks', [(32, 12, 16, 32, 2, 3), (32, 32, 32, 32, 3, 1), (32, 64, 64, 32, 2, 5), (32, 32, 32, 64, 1, 2),
                                                  (16, 64, 64, 64, 5, 4), (16, 128, 128, 64, 2, 1), (8, 128, 128, 128, 9, 2),
-                                                 (8, 256, 256, 128, 3, 1)])
+                                                 (8, 256, 256, 128, 3, 1), (4, 128, 128, 256, 33, 2), (4, 256, 256, 256, 16, 1), (4, 32, 32, 32, 5, 1)])
 def test_bf16_weight_gradient_matches_rounded_operand_reference(H, Cin, CinP, Cout, B, ks):
     """vv_wgrad_bf16 (+ vv_wgrad_reduce into the nn.Conv2d weight layout) against the float64 weight gradient of the
     bf16-rounded operands -- every (ci-blocks, co-blocks) workgroup shape (1x1, 2x1, 1x2, 2x2 blocks of 32 channels), ragged

@@ -110,6 +110,39 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     __syncthreads();
     if (pt + KS < NT) issue(pt + KS);
 
+    if constexpr (TW == 4) {
+      // 4x4 level: a lane's 8 pixels are a 2x4 block (rows 2*half, 2*half+1 of image im), a K step is one image.  The nine
+      // tap-shifted operands are cut from a 4 x 6 window of the halo tile: 24 reads, 24 packs, no window carried over.
+      constexpr int NKS = 16 / KW;
+      vv_static_for<0, NKS>([&](auto KK) {
+        const int im = kq * NKS + KK.value;
+        const int r = 2 * half;
+        const unsigned* xp = xt + ((im * AHH + r) * AHW) * S;      // halo row r (image row r-1), halo column 0 (column -1)
+        const unsigned* yp = yt + ((im * TH + r) * TW) * S;
+        unsigned P[4][3][2];
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+          unsigned v[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) v[j] = xp[(rho * AHW + j) * S];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) { P[rho][kx][0] = pk(v[kx], v[kx + 1]); P[rho][kx][1] = pk(v[kx + 2], v[kx + 3]); }
+        }
+        unsigned d[8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i * 4 + j] = yp[(i * TW + j) * S];
+        const v8bf bq = __builtin_bit_cast(v8bf, (v4u){pk(d[0], d[1]), pk(d[2], d[3]), pk(d[4], d[5]), pk(d[6], d[7])});
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const v4u aq = (v4u){P[ky][kx][0], P[ky][kx][1], P[ky + 1][kx][0], P[ky + 1][kx][1]};
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, aq), bq, acc[ky * 3 + kx], 0, 0, 0);
+          }
+      });
+    } else {
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) {
       const int strip = KW == 1 ? sg : (KW == 2 ? kq : (kq >> 1));
@@ -147,6 +180,7 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, win[(k + ky) % 3][kx]), bq,
                                                                        acc[ky * 3 + kx], 0, 0, 0);
       });
+    }
     }
   }
 
@@ -343,12 +377,21 @@ inline bool bgeo(int kind, int H, int W, BGeo* t) {
     if (H == 32) { *t = {8, 32, 1}; return true; }
     if (H == 16) { *t = {16, 16, 1}; return true; }
     if (H == 8) { *t = {8, 8, 4}; return true; }
+    if (H == 4) { *t = {4, 4, 16}; return true; }
     return false;
   }
   if (H == 16) { *t = {8, 16, 1}; return true; }      // transposed conv: H x W = its INPUT resolution
   if (H == 8) { *t = {8, 8, 2}; return true; }
   if (H == 4) { *t = {4, 4, 8}; return true; }
   return false;
+}
+
+// (ci blocks, co blocks) of 32 channels a workgroup covers: 2 x 2 when the layer has them; on the 4x4 levels the staged tiles of
+// 16 (8) images are large and two blocks are the most that stays in registers
+inline void block_shape(int kind, int TW, int NCI, int NCO, int* cbk, int* obk) {
+  int c = NCI % 2 == 0 ? 2 : 1, o = NCO % 2 == 0 ? 2 : 1;
+  if (TW == 4 && c * o == 4) { if (kind == VV_CONV3) c = 1; else o = 1; }
+  *cbk = c; *obk = o;
 }
 
 template <int TH, int TW, int NI, int CB, int OB>
@@ -378,20 +421,22 @@ int launch_t(const vv_wgrad_params* p, hipStream_t st) {
 template <int TH, int TW, int NI>
 int dispatch_t(const vv_wgrad_params* p, hipStream_t st) {
   const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
-  const bool c2 = NCI % 2 == 0, o2 = NCO % 2 == 0 && TW != 4;     // 4x4 level: two 4x halo tiles of 8 images spill registers
-  if (c2 && o2) return launch_t<TH, TW, NI, 2, 2>(p, st);
-  if (c2) return launch_t<TH, TW, NI, 2, 1>(p, st);
-  if (o2) return launch_t<TH, TW, NI, 1, 2>(p, st);
+  int c, o;
+  block_shape(p->kind, TW, NCI, NCO, &c, &o);
+  if (c == 2 && o == 2) { if constexpr (TW != 4) return launch_t<TH, TW, NI, 2, 2>(p, st); }
+  if (c == 2) return launch_t<TH, TW, NI, 2, 1>(p, st);
+  if (o == 2) return launch_t<TH, TW, NI, 1, 2>(p, st);
   return launch_t<TH, TW, NI, 1, 1>(p, st);
 }
 
 template <int TH, int TW, int NI>
 int dispatch_b(const vv_wgrad_params* p, hipStream_t st) {
   const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
-  const bool c2 = NCI % 2 == 0, o2 = NCO % 2 == 0;
-  if (c2 && o2) return launch_b<TH, TW, NI, 2, 2>(p, st);
-  if (c2) return launch_b<TH, TW, NI, 2, 1>(p, st);
-  if (o2) return launch_b<TH, TW, NI, 1, 2>(p, st);
+  int c, o;
+  block_shape(p->kind, TW, NCI, NCO, &c, &o);
+  if (c == 2 && o == 2) { if constexpr (TW != 4) return launch_b<TH, TW, NI, 2, 2>(p, st); }
+  if (c == 2) return launch_b<TH, TW, NI, 2, 1>(p, st);
+  if (o == 2) return launch_b<TH, TW, NI, 1, 2>(p, st);
   return launch_b<TH, TW, NI, 1, 1>(p, st);
 }
 
@@ -402,7 +447,8 @@ extern "C" int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W,
   BGeo t;
   if (!bgeo(kind, H, W, &t) || Cout % 32 || CinP <= 0) return 0;
   const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
-  const int cbk = NCI % 2 == 0 ? 2 : 1, obk = (NCO % 2 == 0 && !(kind != VV_CONV3 && t.TW == 4)) ? 2 : 1;
+  int cbk, obk;
+  block_shape(kind, t.TW, NCI, NCO, &cbk, &obk);
   if (ntiles) *ntiles = ((B + t.NI - 1) / t.NI) * (H / t.TH) * (W / t.TW);
   if (nblocks) *nblocks = (NCI / cbk) * (NCO / obk);
   if (kw) *kw = 1;      // the waves of a workgroup are summed in LDS: one slab per (ci-tile, co-tile) and k-split part
@@ -426,6 +472,7 @@ extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
     case 32: return dispatch_b<8, 32, 1>(p, st);
     case 16: return dispatch_b<16, 16, 1>(p, st);
     case 8: return dispatch_b<8, 8, 4>(p, st);
+    case 4: return dispatch_b<4, 4, 16>(p, st);
   }
   return VV_ERR_UNSUPPORTED;
 }
