@@ -280,6 +280,11 @@ def main():
                            'algorithmic_gflop_per_launch': mf['algorithmic_gflop_per_launch'],
                            'mfma_tflops': mf['achieved'], 'frac_of_bf16_mfma_peak': (mf['achieved'] * 1e12 / BF16_MFMA_PEAK)
                            if mf['achieved'] else None, 'side_stream_weight_grad': args.overlap}
+        cfgd = out['config']
+        for k_ in ('frac_of_fp32_mfma_peak_whole_step', 'forward_frac_of_fp32_mfma_peak'):      # wrong denominator in this mode
+            cfgd.pop(k_, None)
+        cfgd['frac_of_bf16_mfma_peak_whole_step'] = value / world * flop_per_cube / BF16_MFMA_PEAK
+        cfgd['forward_frac_of_bf16_mfma_peak'] = B * fwd_flop_per_cube / (fwd_ms * 1e-3) / BF16_MFMA_PEAK
         out['config']['precision'] = 'mixed bf16 (BASELINE config 4): conv / transposed-conv operands bf16, everything else fp32'
     if not args.no_cpu_baseline and world == 1:
         try:
