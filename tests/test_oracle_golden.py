@@ -105,3 +105,47 @@ def test_oracle_script_level():
     np.testing.assert_allclose(np.concatenate(cs), g['cube_scores'], rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(np.array(fs), g['frame_scores'], rtol=1e-2, atol=1e-2)
     assert abs(O.roc_auc(np.array(fs), g['labels']) - float(g['auc'])) < 1e-9
+
+
+def test_mixed_precision_switch_is_transparent_when_off_and_rounds_when_on():
+    """oracle/unet_oracle.py MIXED: (a) with every rounding off, the custom autograd function used for the mixed-precision
+    restatement returns what F.conv2d / F.conv_transpose2d and their autograd return, bit for bit (data gradients) or to fp32
+    round-off (weight / bias gradients: another summation order); (b) with MIXED_BF16 the forward equals the convolution of the
+    bf16-rounded operands; (c) MIXED = None (the default every other test runs under) bypasses it."""
+    import torch.nn.functional as F
+    from oracle import unet_oracle as O
+    assert O.MIXED is None
+    torch.manual_seed(3)
+    x = torch.randn(2, 8, 8, 8, requires_grad=True)
+    w = torch.randn(16, 8, 3, 3, requires_grad=True)
+    b = torch.randn(16, requires_grad=True)
+    wt = torch.randn(8, 4, 3, 3, requires_grad=True)
+    bt = torch.randn(4, requires_grad=True)
+    off = {'fwd': False, 'dgrad': False, 'dgradT': False, 'wgrad': False, 'wgradT': False}
+    rnd = lambda t: t.to(torch.bfloat16).float()
+    try:
+        for tr in (False, True):
+            ww, bb = (wt, bt) if tr else (w, b)
+            ref = F.conv_transpose2d(x, ww, bb, stride=2, padding=1, output_padding=1) if tr else F.conv2d(x, ww, bb, padding=1)
+            g = torch.randn_like(ref)
+            gref = torch.autograd.grad(ref, (x, ww, bb), g)
+            O.MIXED = off
+            out = (O._convT if tr else O._conv3)(x, ww, bb)
+            assert torch.equal(out, ref)
+            got = torch.autograd.grad(out, (x, ww, bb), g)
+            assert torch.equal(got[0], gref[0])
+            for a_, r_ in zip(got[1:], gref[1:]):
+                assert torch.allclose(a_, r_, rtol=1e-5, atol=1e-4)
+            O.MIXED = O.MIXED_BF16
+            out = (O._convT if tr else O._conv3)(x, ww, bb)
+            want = F.conv_transpose2d(rnd(x), rnd(ww), bb, stride=2, padding=1, output_padding=1) if tr else \
+                F.conv2d(rnd(x), rnd(ww), bb, padding=1)
+            assert torch.equal(out, want) and not torch.equal(out, ref)
+            gx, = torch.autograd.grad(out, (x,), g)
+            if tr:
+                want_gx = F.conv2d(rnd(g), rnd(ww), None, stride=2, padding=1)
+            else:
+                want_gx = torch.nn.grad.conv2d_input(x.shape, rnd(ww), rnd(g), padding=1)
+            assert torch.allclose(gx, want_gx.detach(), rtol=1e-5, atol=1e-5)
+    finally:
+        O.MIXED = None
