@@ -63,6 +63,10 @@ typedef struct vv_view {
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- torch.autocast(bfloat16) semantics for the convolution; tensors in
  * HBM, bias, BatchNorm statistics and master weights stay fp32 (BASELINE config 4, "mixed bf16"). */
 #define VV_CONV_BF16 1
+/* with VV_CONV_BF16 and in_mode = VV_IN_PLAIN: src0 holds bf16 elements (same [B,H,W,C] indexing, gstride still in floats) --
+ * the data gradient reading a dy that vv_bn_bwd_apply stored as bf16 (VV_BNBWD_DZ_BF16): same values as rounding on load, half
+ * the bytes */
+#define VV_CONV_SRC_BF16 2
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */
@@ -120,13 +124,14 @@ int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W);
 /* Weight gradient of the 3x3 convolution with bf16 operands / fp32 accumulation (mixed precision, BASELINE config 4;
  * torch.autocast(bfloat16) semantics of the autograd weight gradient of nn.Conv2d, model/unet.py:10,13): act (after the
  * deferred BatchNorm+ReLU) and dy are rounded to bf16 on their way into LDS, products accumulate in fp32 on
- * v_mfma_f32_32x32x16_bf16.  Same parameter block as vv_wgrad_mfma (pad0 ignored); kind = VV_CONV3 with H = W in {32, 16, 8, 4}, or
+ * v_mfma_f32_32x32x16_bf16.  Same parameter block as vv_wgrad_mfma (pad0: VV_WGRAD_DY_BF16 only); kind = VV_CONV3 with H = W in {32, 16, 8, 4}, or
  * VV_CONVT_FWD (weight gradient of nn.ConvTranspose2d(k3,s2,p1,op1), model/unet.py:54) with H = W in {16, 8, 4}.
  * One workgroup covers up to 64 ci x 64 co and every ksplit-th pixel tile:  slabs per (ci-tile, co-tile) = ksplit * kw.
  * vv_wgrad_bf16_plan returns 0 when the geometry is not handled (use vv_wgrad_mfma), else 1 and
  *   *ntiles  = pixel tiles (the upper bound of ksplit),
  *   *nblocks = workgroups per group and k-split part,
  *   *kw      = slabs per workgroup and (ci-tile, co-tile) (1 today): pass ksplit * kw to vv_wgrad_reduce. */
+#define VV_WGRAD_DY_BF16 1   /* vv_wgrad_bf16, pad0: dy holds bf16 elements (written by vv_bn_bwd_apply with VV_BNBWD_DZ_BF16) */
 int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream);
 int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W, int32_t CinP, int32_t Cout, int32_t* ntiles, int32_t* nblocks,
                        int32_t* kw);
@@ -174,8 +179,13 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
 
 /* BatchNorm + ReLU (+ MaxPool, + skip fan-in) backward, phase 1:
  * dz = (dA0 [+ route(dPool)]) * [a*y+b > 0]; writes per-block partial sums of dz and dz*xhat (not dz). */
+/* vv_bnbwd_params.flags: vv_bn_bwd_apply writes dy as bf16 (nearest even; [B,H,W,C] with 2-byte elements at the same base,
+ * dz_gstride still in floats) for consumers that round it to bf16 anyway (vv_conv_mfma + VV_CONV_SRC_BF16, vv_wgrad_bf16 +
+ * VV_WGRAD_DY_BF16) */
+#define VV_BNBWD_DZ_BF16 1
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
+  int32_t flags;
   const float* y; int64_t y_gstride;             /* pre-BN conv output [B,H,W,C] */
   const float* a; const float* b; const float* mean; const float* invstd; int64_t ab_gstride;
   vv_view dA;                                    /* gradient wrt the post-ReLU activation (same resolution) */

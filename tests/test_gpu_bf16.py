@@ -296,6 +296,30 @@ def test_bf16_train_steps_match_mixed_oracle(monkeypatch):
     np.testing.assert_allclose(np.array(losses), ref_losses, rtol=2e-3)
 
 
+def test_bf16_dy_storage_is_bitwise_neutral(monkeypatch):
+    """In the mixed mode BatchNorm backward stores dy as bf16 because both of its consumers (data gradient, weight gradient)
+    round it to bf16 on load anyway: the gradients of a whole backward pass must be bit-identical with and without that
+    (VV_BF16_DZ=0 keeps the fp32 tensor), Full bank, ragged batch."""
+    from oracle import unet_oracle as O
+    from test_gpu_unet import _build
+    raw, flow = O.seeded_cubes(37, 5, 9, smooth=False)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    grads = []
+    monkeypatch.setenv('VV_PRECISION', 'bf16')
+    for dz in ('1', '0'):
+        monkeypatch.setenv('VV_BF16_DZ', dz)
+        net, sd, _ = _build('full', False)
+        net.train()
+        bank = net.bank()
+        assert bank.dz16 == (dz == '1')
+        ws = bank.set_input_cubes(rawd, flowd, None, 37)
+        bank.forward(ws, True)
+        bank.backward(ws)
+        grads.append(bank.grads.clone())
+    assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_bf16_scores_and_auc_close_to_fp32(monkeypatch):
     """Config 4's bar: the bf16 path is judged on AUROC.  Same weights, same cubes, eval mode: per-cube
     scores of the two precisions within 10 % of each other after 40 training steps each (observed: 1 cube of 96 beyond 5 %), and the AUROC of a labelled cube set

@@ -18,6 +18,9 @@ c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 IN_PLAIN, IN_ACT, IN_POOL, IN_CAT, IN_CUBE = 0, 1, 2, 3, 4
 CONV3, CONVT_FWD, CONVT_DGRAD = 0, 1, 2
 CONV_BF16 = 1          # vv_conv_params.pad0 flag (include/vecvad_hip.h VV_CONV_BF16)
+CONV_SRC_BF16 = 2      # VV_CONV_SRC_BF16
+BNBWD_DZ_BF16 = 1      # vv_bnbwd_params.flags
+WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 
 
 class View(C.Structure):
@@ -46,7 +49,7 @@ class PackEntry(C.Structure):
 
 
 class BnBwdParams(C.Structure):
-    _fields_ = [('G', c_i32), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32),
+    _fields_ = [('G', c_i32), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('flags', c_i32),
                 ('y', c_vp), ('y_gstride', c_i64),
                 ('a', c_vp), ('b', c_vp), ('mean', c_vp), ('invstd', c_vp), ('ab_gstride', c_i64),
                 ('dA', View), ('dpool', c_vp), ('dpool_gstride', c_i64),

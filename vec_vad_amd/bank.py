@@ -218,6 +218,8 @@ class UNetBank:
             raise ValueError("VV_PRECISION / [mi355x] precision must be 'fp32' or 'bf16', got %r" % self.precision)
         self.cflag = L.CONV_BF16 if self.precision == 'bf16' else 0
         self.bf16_wgrad = os.environ.get('VV_BF16_WGRAD', '1') != '0'      # 0: keep the fp32 (Winograd) weight gradient in bf16 mode
+        # BatchNorm backward stores dy as bf16 when both of its consumers round it to bf16 anyway (bit-identical results)
+        self.dz16 = bool(self.cflag) and self.bf16_wgrad and os.environ.get('VV_BF16_DZ', '1') != '0'
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
@@ -481,12 +483,16 @@ class UNetBank:
         def conv_bwd(l):
             i = l.idx
             y = ws.y[i]
+            # mixed precision: both consumers of dy (data gradient, weight gradient) round it to bf16 -- let BatchNorm backward
+            # store it that way (same values, half the bytes written once and read twice)
+            wpl = wplan['c%d' % i]
+            dz16 = bool(self.dz16 and len(wpl) > 2)
             pos = order.index(i)
             dzb = ws.dz2[pos % 2]
             # the layer visited two steps earlier used the same dy buffer: its weight-grad (side stream) must be done
             reuse_wait = ('wdone%d' % order[pos - 2],) if pos >= 2 else ()
             dA, dpool, dpg = dA_for(l)
-            bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout, y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
+            bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout, L.BNBWD_DZ_BF16 if dz16 else 0, y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
@@ -498,7 +504,8 @@ class UNetBank:
             if i > 0:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
-                                  L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0, self.cflag, None,
+                                  L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
+                                  self.cflag | (L.CONV_SRC_BF16 if dz16 else 0), None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)), None)
                 P.keep.append(cp)
@@ -509,11 +516,11 @@ class UNetBank:
             # weight-gradient starts when it is done, sharing the chip with the HBM-bound BatchNorm backward of the
             # next layer only.
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
-            wpl = wplan['c%d' % i]
             ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)           # kw > 0: the bf16-operand kernel (mixed precision)
             # pad0 bit 8: Winograd F(2x2,3x3) form of the weight gradient (same tiles / slabs, 2.25x fewer MFMA cycles)
+            wflag = (L.WGRAD_DY_BF16 if dz16 else 0) if kw else (self.wgrad_flag if self.wino_wgrad else 0)
             wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit,
-                               self.wgrad_flag if self.wino_wgrad else 0, chmap,
+                               wflag, chmap,
                                L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,),

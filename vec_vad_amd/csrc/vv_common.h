@@ -296,6 +296,33 @@ struct VVStagerB {
     }
   }
 
+  // bf16 SOURCE (plain tensors only: a dy that BatchNorm backward stored as bf16): the same items are 8 B = 4 channels
+  // each, loaded into r[k].x / r[k].y as bit patterns and copied to LDS as they are.  Compile-time choice of the caller.
+  __device__ __forceinline__ void prefetch16(const VVSrc& s, int img0, int y0, int x0, int c0, int tid, int cmax = 1 << 30) {
+    const int q = tid % Q;
+    const int c = c0 + q * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0 + (s.co0 >> 1)), 0, 0x7FFFFFFF, 0x00020000);
+    const int tile = (img0 * s.SH + y0) * s.SW + x0;
+    const bool cok = c < cmax;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int y = y0 + hy[k];
+      const bool ok = cok && (unsigned)y < (unsigned)s.SH && (img0 + im[k]) < s.B && pix[k] >= 0;
+      const unsigned off = ok ? (unsigned)((tile + pix[k]) * s.cs0 + c) * 2u : OOB;
+      const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+      r[k] = make_float4(v.x, v.y, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void commit_raw16(float* lds, int tid) const {
+    const int q = tid % Q;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * NTH;
+      if (NITEMS % NTH == 0 || it < NITEMS)
+        *reinterpret_cast<uint2*>(lds + (it / Q) * S + q * 2) = make_uint2(__builtin_bit_cast(unsigned, r[k].x), __builtin_bit_cast(unsigned, r[k].y));
+    }
+  }
+
   // bf16 operand path: the same items, rounded to nearest-even bf16 (v_cvt_pk_bf16_f32) after the deferred BatchNorm+ReLU and
   // written as 8 B (4 channels) per item; S is still the pixel stride in floats (4 B units).
   __device__ __forceinline__ void commit_bf16(float* lds, int tid) const {

@@ -30,7 +30,8 @@ struct Geo {
 // panel) and the contraction runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: one ds_read_b128 per operand now
 // carries 8 channels of a 16-channel K step (lanes 0-31: k 0..7, lanes 32-63: k 8..15), 1/16 of the matrix-core time of the
 // fp32 instruction -- this variant is bound by HBM / staging, not by MFMA.
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF>
+// S16 (with BF, plain input): src0 holds bf16 elements -- a dy that BatchNorm backward stored as bf16; copied, not converted.
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, bool S16>
 __global__ void __launch_bounds__(VV_WG, (BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
@@ -114,7 +115,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   auto issue = [&](const int c0) {
-    stA.prefetch(s, img0, oy0, ox0, c0, tid);
+    if constexpr (S16) stA.prefetch16(s, img0, oy0, ox0, c0, tid); else stA.prefetch(s, img0, oy0, ox0, c0, tid);
     const int so = (c0 >> 3) * 2 * Cout * 16;
 #pragma unroll
     for (int k = 0; k < NBT; ++k) {
@@ -127,7 +128,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
   };
   auto commit = [&]() {
-    if constexpr (BF) stA.commit_bf16(lds, tid); else stA.commit(lds, tid);
+    if constexpr (S16) stA.commit_raw16(lds, tid); else if constexpr (BF) stA.commit_bf16(lds, tid); else stA.commit(lds, tid);
 #pragma unroll
     for (int k = 0; k < NBT; ++k) {
       const int it = tid + k * VV_WG;
@@ -280,19 +281,19 @@ inline bool tile_geo(int H, int W, TileGeo* t) {
   return false;
 }
 
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false>
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false, bool S16 = false>
 int launch(const vv_conv_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NN = p->Cout / (NR * 32);
   const int total = p->G * NN * NT;
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK, BF>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
+  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK, BF, S16>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
                      total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
 
-template <int KIND, int CK, bool BF>
+template <int KIND, int CK, bool BF, bool S16 = false>
 int dispatch(const vv_conv_params* p, hipStream_t st) {
   TileGeo t;
   if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
@@ -306,17 +307,17 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   constexpr int CK4 = BF ? 16 : 8;
   if constexpr (KIND == VV_CONVT_FWD) {        // four phase accumulators: 32-wide N tiles only
     switch (p->H) {
-      case 32: return launch<8, 32, 1, 1, KIND, CKD, BF>(p, st);
-      case 16: return launch<16, 16, 1, 1, KIND, CKD, BF>(p, st);
-      case 8: return launch<8, 8, 4, 1, KIND, CKD, BF>(p, st);
-      case 4: return launch<4, 4, 16, 1, KIND, CK4, BF>(p, st);
+      case 32: return launch<8, 32, 1, 1, KIND, CKD, BF, S16>(p, st);
+      case 16: return launch<16, 16, 1, 1, KIND, CKD, BF, S16>(p, st);
+      case 8: return launch<8, 8, 4, 1, KIND, CKD, BF, S16>(p, st);
+      case 4: return launch<4, 4, 16, 1, KIND, CK4, BF, S16>(p, st);
     }
   } else {
     switch (p->H) {
-      case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD, BF>(p, st) : launch<8, 32, 1, 1, KIND, CKD, BF>(p, st);
-      case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD, BF>(p, st) : launch<16, 16, 1, 1, KIND, CKD, BF>(p, st);
-      case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD, BF>(p, st) : launch<8, 8, 4, 1, KIND, CKD, BF>(p, st);
-      case 4: return wide ? launch<4, 4, 16, 2, KIND, CK4, BF>(p, st) : launch<4, 4, 16, 1, KIND, CK4, BF>(p, st);
+      case 32: return wide ? launch<8, 32, 1, 2, KIND, CKD, BF, S16>(p, st) : launch<8, 32, 1, 1, KIND, CKD, BF, S16>(p, st);
+      case 16: return wide ? launch<16, 16, 1, 2, KIND, CKD, BF, S16>(p, st) : launch<16, 16, 1, 1, KIND, CKD, BF, S16>(p, st);
+      case 8: return wide ? launch<8, 8, 4, 2, KIND, CKD, BF, S16>(p, st) : launch<8, 8, 4, 1, KIND, CKD, BF, S16>(p, st);
+      case 4: return wide ? launch<4, 4, 16, 2, KIND, CK4, BF, S16>(p, st) : launch<4, 4, 16, 1, KIND, CK4, BF, S16>(p, st);
     }
   }
   return VV_ERR_UNSUPPORTED;
@@ -336,10 +337,12 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   if (p->Cout % 32) return VV_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const bool bf = (p->pad0 & VV_CONV_BF16) != 0;
+  if ((p->pad0 & VV_CONV_SRC_BF16) && !(bf && p->in_mode == VV_IN_PLAIN && p->kind == VV_CONV3 && p->src0.coff % 2 == 0)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
   switch (p->kind) {
     case VV_CONV3:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
+      if (bf && (p->pad0 & VV_CONV_SRC_BF16)) return dispatch<VV_CONV3, 16, true, true>(p, st);
       return bf ? dispatch<VV_CONV3, 16, true>(p, st) : dispatch<VV_CONV3, 16, false>(p, st);
     case VV_CONVT_FWD:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;

@@ -157,7 +157,8 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
     } else {
       d.x = gk.x * (d.x - c1.x - xh.x * c2.x); d.y = gk.y * (d.y - c1.y - xh.y * c2.y);
       d.z = gk.z * (d.z - c1.z - xh.z * c2.z); d.w = gk.w * (d.w - c1.w - xh.w * c2.w);
-      *reinterpret_cast<float4*>(dz + pix * C + c) = d;
+      if (p.flags & VV_BNBWD_DZ_BF16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dz) + pix * C + c) = vv_pack_bf16x4(d);
+      else *reinterpret_cast<float4*>(dz + pix * C + c) = d;
     }
   };
 
