@@ -231,6 +231,12 @@ int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* parti
 /* bias gradient of the transposed conv: db[co] = sum_pixels dy[p][co] (two-stage, deterministic) */
 int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, int64_t dy_gstride, int32_t cstride,
                  int32_t coff, float* scratch, float* db, int64_t grad_gstride, vv_stream stream);
+/* The same bias gradient without a pass over the tensor: when dy is the output of a vv_conv_mfma / vv_conv_wino launch that was
+ * given a `stats` array ([G][ntiles][2][C]: per-tile column sums in slot 0), db[g][j] = sum_tiles stats[g][tile][0][coff + j]
+ * (fixed order, fp64).  Used for the transposed conv's bias: its output gradient is a channel slice of the concat layer's data
+ * gradient (autograd of nn.ConvTranspose2d bias, model/unet.py:54). */
+int vv_bias_from_partials(int32_t G, int32_t C, int32_t ntiles, int32_t coff, int32_t n, const float* partial,
+                          int64_t partial_gstride, float* db, int64_t grad_gstride, vv_stream stream);
 
 /* ---- fused Adam over one flat buffer (torch.optim.Adam(eps=1e-7), train.py:376,400-402) ---- */
 int vv_adam(int64_t n, float* param, const float* grad, float* m, float* v, float lr, float beta1, float beta2,

@@ -418,6 +418,8 @@ class UNetBank:
         ws.bnscr = f(Ga, 2 * lay.cmax)
         ws.ocpart = f(Ga, B, 132)
         ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
+        ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles(B, l.H, l.H), lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin
+                              for l in lay.convs if l.mode == L.IN_CAT))
         # wgrad split-K choice: ~1024 workgroups per launch
         wplan = {}
         wmax = 0
@@ -507,7 +509,9 @@ class UNetBank:
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
                                   self.cflag | (L.CONV_SRC_BF16 if dz16 else 0), None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
-                                  L.view(Dl, l.cin, 0, Dl.stride(0)), None)
+                                  L.view(Dl, l.cin, 0, Dl.stride(0)),
+                                  # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
+                                  ws.dstats.data_ptr() if l.mode == L.IN_CAT else None)
                 P.keep.append(cp)
                 # paired schedule: the MFMA data-gradient runs alone (the side stream has drained) ...
                 P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i,
@@ -539,9 +543,9 @@ class UNetBank:
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
-            P.add(lib.vv_bias_grad, (Ga, B * (2 * H) * (2 * H), co, dcat.data_ptr(), dcat.stride(0), m.cin, skipc,
-                                     ws.bscr.data_ptr(), gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u, stream=1,
-                  wait=('D%d' % m.idx,), pwait=('*main',))
+            ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles(B, m.H, m.H)
+            P.add(lib.vv_bias_from_partials, (Ga, m.cin, ntd, skipc, co, ws.dstats.data_ptr(), ntd * 2 * m.cin,
+                                              gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u)
             y = ws.y[sidx]
             wpl = wplan['t%d' % u]
             ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)

@@ -429,6 +429,27 @@ bias_grad_stage2(const int C, const int nblk, const float* __restrict__ scratch,
   }
 }
 
+// Bias gradient of the transposed conv from the per-tile column sums the data-gradient kernel of the consuming (concat) layer
+// leaves in its `stats` partials: db[j] = sum over pixels of d(cat)[pixel][coff + j] = sum over tiles of partial[tile][0][coff + j].
+// Same fixed-order fp64 reduction as the BatchNorm partials.
+__global__ void __launch_bounds__(VV_WG)
+bias_from_partials_kernel(const int C, const int ntiles, const int coff, const int n, const float* __restrict__ partial,
+                          const int64_t partial_gstride, float* __restrict__ db, const int64_t grad_gstride) {
+  __shared__ double sh[8][32];
+  const int g = blockIdx.y;
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (j < n) vv_sum_partials(partial + (int64_t)g * partial_gstride + coff + j, ntiles, C, part, s1, s2);
+  sh[part][cl] = s1;
+  __syncthreads();
+  if (part != 0 || j >= n) return;
+  s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s1 += sh[k][cl];
+  db[(int64_t)g * grad_gstride + j] = (float)s1;
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ void __launch_bounds__(VV_WG)
 adam_kernel(const int64_t n4, float4* __restrict__ p, const float4* __restrict__ gr, float4* __restrict__ m,
@@ -661,6 +682,15 @@ extern "C" int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, in
                      coff, scratch, nblk);
   VV_CHECK_LAUNCH();
   VV_LAUNCH(bias_grad_stage2, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, scratch, db, grad_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_bias_from_partials(int32_t G, int32_t C, int32_t ntiles, int32_t coff, int32_t n, const float* partial,
+                                     int64_t partial_gstride, float* db, int64_t grad_gstride, vv_stream stream) {
+  if (!partial || !db || n <= 0 || coff < 0 || coff + n > C || ntiles <= 0) return VV_ERR_BAD_ARG;
+  VV_LAUNCH(bias_from_partials_kernel, dim3((n + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, ntiles, coff, n, partial,
+            partial_gstride, db, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
