@@ -44,15 +44,16 @@ def conv_flops(lay, B, G):
     return fl
 
 
-def conv_bytes(lay, B, G):
+def conv_bytes(lay, B, G, dy_bytes=4):
     """algorithmic HBM bytes of the same launches: the input tensor read once + the output tensor written once, fp32
-    (every conv output round-trips HBM exactly once); weights (L2 resident) not counted."""
+    (every conv output round-trips HBM exactly once); weights (L2 resident) not counted.
+    dy_bytes = 2 when BatchNorm backward stores the data-gradient's input as bf16 (mixed precision)."""
     by = {}
     for l in lay.convs:
         cin = l.cinp if l.idx == 0 else l.cin                 # layer 0 reads the 16-channel frame-erased buffer
         by['conv%d' % l.idx] = 4.0 * B * l.H * l.H * G * (cin + l.cout)
         if l.idx > 0:
-            by['dgrad%d' % l.idx] = 4.0 * B * l.H * l.H * G * (l.cout + l.cin)
+            by['dgrad%d' % l.idx] = 1.0 * B * l.H * l.H * G * (dy_bytes * l.cout + 4 * l.cin)
     return by
 
 
@@ -161,7 +162,7 @@ def main():
     torch.cuda.synchronize()
     ws = bank.workspace(B)
     fl = conv_flops(bank.lay, B, bank.Ga)
-    by = conv_bytes(bank.lay, B, bank.Ga)
+    by = conv_bytes(bank.lay, B, bank.Ga, 2 if getattr(bank, 'dz16', False) else 4)
     # HIP events around every MFMA 3x3-conv launch (forward conv + data-gradient) of the timed region
     ev = []
     trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
@@ -270,8 +271,8 @@ def main():
         mf = out['roofline']
         out['roofline'] = {'bound': 'hbm',
                            'kernel': 'conv_mfma_kernel<..., BF=true> (3x3 implicit GEMM, bf16 operands / fp32 accumulation, forward + '
-                                     'data-gradient launches): achieved = algorithmic bytes (input read once + output written once, '
-                                     'fp32) / time',
+                                     'data-gradient launches): achieved = algorithmic bytes (input read once + output written once; fp32 '
+                                     'tensors, except the data gradient\'s input which BatchNorm backward stores as bf16) / time',
                            'achieved': (conv_b / conv_t / 1e9) if conv_t > 0 else None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                            'frac': (conv_b / conv_t / HBM_PEAK) if conv_t > 0 else None,
                            'traffic': pmc_traffic('r01_pmc_hbm_traffic_bf16.json'), 'launches_timed': conv_n,
