@@ -61,7 +61,8 @@ typedef struct vv_view {
  * the load, bias + per-channel sum / sum-of-squares partials (BatchNorm batch statistics) fused into the store. */
 /* vv_conv_params.pad0 flag: round both operands to bf16 (nearest even) on their way into LDS and contract on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- torch.autocast(bfloat16) semantics for the convolution; tensors in
- * HBM, bias, BatchNorm statistics and master weights stay fp32 (BASELINE config 4, "mixed bf16"). */
+ * HBM, bias, BatchNorm statistics and master weights stay fp32 (BASELINE config 4, "mixed bf16").  `w` must then be a bf16
+ * panel (vv_pack_weights with mode | VV_PACK_BF16; CinP % 16 == 0). */
 #define VV_CONV_BF16 1
 /* with VV_CONV_BF16 and in_mode = VV_IN_PLAIN: src0 holds bf16 elements (same [B,H,W,C] indexing, gstride still in floats) --
  * the data gradient reading a dy that vv_bn_bwd_apply stored as bf16 (VV_BNBWD_DZ_BF16): same values as rounding on load, half
@@ -148,7 +149,10 @@ int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t CinP, int32_t 
  * mode 1: conv data-grad    Wp[t=(2-ky)*3+(2-kx)][k=co][n=ci] = W[co][ci][ky][kx]
  * mode 2: convT forward     Wp[t=ky*3+kx][k=ci][n=co] = Wt[ci][co][ky][kx]
  * mode 3: convT data-grad   Wp[t=ky*3+kx][k=co][n=ci] = Wt[ci][co][ky][kx]
- * packed element (t,k,n) lives at (((t*KP/8 + k/8)*2 + (k%8)/4)*N + n)*4 + k%4 ; rows k >= K are zero. */
+ * packed element (t,k,n) lives at (((t*KP/8 + k/8)*2 + (k%8)/4)*N + n)*4 + k%4 ; rows k >= K are zero.
+ * mode | 4 (VV_PACK_BF16): the same panel as bf16 for VV_CONV_BF16 launches (KP % 16 == 0):
+ * element (t,k,n) is the bf16 at index (((t*KP/16 + k/16)*2 + (k%16)/8)*N + n)*8 + k%8 from the same dst_off. */
+#define VV_PACK_BF16 4
 typedef struct vv_pack_entry {
   int64_t src_off;   /* floats from the group's parameter base */
   int64_t dst_off;   /* floats from the group's packed base */

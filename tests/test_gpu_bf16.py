@@ -21,7 +21,7 @@ def _r(t):
 
 
 def _pack(lib, L, w, G, mode, K, N, st):
-    ent = (L.PackEntry * 1)(L.PackEntry(0, 0, mode, K, K, N))
+    ent = (L.PackEntry * 1)(L.PackEntry(0, 0, mode | L.PACK_BF16, K, K, N))
     tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()
     out = torch.zeros(G, 9 * K * N, device='cuda')
     L.check(lib.vv_pack_weights(tab.data_ptr(), 1, G, w.data_ptr(), w[0].numel(), out.data_ptr(), out.stride(0), 9 * K * N, st), 'pack')

@@ -19,6 +19,7 @@ IN_PLAIN, IN_ACT, IN_POOL, IN_CAT, IN_CUBE = 0, 1, 2, 3, 4
 CONV3, CONVT_FWD, CONVT_DGRAD = 0, 1, 2
 CONV_BF16 = 1          # vv_conv_params.pad0 flag (include/vecvad_hip.h VV_CONV_BF16)
 CONV_SRC_BF16 = 2      # VV_CONV_SRC_BF16
+PACK_BF16 = 4          # vv_pack_entry.mode flag: bf16 panel for VV_CONV_BF16 launches
 BNBWD_DZ_BF16 = 1      # vv_bnbwd_params.flags
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 

@@ -228,7 +228,8 @@ class UNetBank:
         ents = (L.PackEntry * len(direct))()
         mx = 0
         for i, (k, (off, mode, K, KP, N, src)) in enumerate(direct):
-            ents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
+            # mixed precision: the bf16-operand kernels read bf16 panels (same offsets, half the bytes)
+            ents[i] = L.PackEntry(lay.p[src][0], off, mode | (L.PACK_BF16 if self.cflag else 0), K, KP, N)
             mx = max(mx, 9 * KP * N)
         self.pack_table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(d)
         self.pack_n, self.pack_max = len(direct), mx

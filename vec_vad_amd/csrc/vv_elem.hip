@@ -16,18 +16,30 @@ pack_weights_kernel(const vv_pack_entry* __restrict__ table, const float* __rest
   const float* src = params + (int64_t)g * params_gstride + e.src_off;
   float* dst = packed + (int64_t)g * packed_gstride + e.dst_off;
   const int KQ = e.KP >> 3;
+  const bool b16 = (e.mode & 4) != 0;        // bf16 panel [tap][KP/16][2][N][8] for the bf16-operand kernels (K step = 16 channels)
   for (int d = blockIdx.x * VV_WG + threadIdx.x; d < total; d += gridDim.x * VV_WG) {
-    const int j = d & 3;
-    int t = d >> 2;
-    const int n = t % e.N; t /= e.N;
-    const int half = t & 1; t >>= 1;
-    const int kq = t % KQ;
-    const int tap = t / KQ;
-    const int k = kq * 8 + half * 4 + j;
+    int n, tap, k;
+    if (b16) {
+      const int e8 = d & 7;
+      int t = d >> 3;
+      n = t % e.N; t /= e.N;
+      const int half = t & 1; t >>= 1;
+      const int ks = t % (e.KP >> 4);
+      tap = t / (e.KP >> 4);
+      k = ks * 16 + half * 8 + e8;
+    } else {
+      const int j = d & 3;
+      int t = d >> 2;
+      n = t % e.N; t /= e.N;
+      const int half = t & 1; t >>= 1;
+      const int kq = t % KQ;
+      tap = t / KQ;
+      k = kq * 8 + half * 4 + j;
+    }
     float v = 0.f;
     if (k < e.K) {
       int64_t si;
-      switch (e.mode) {
+      switch (e.mode & 3) {
         case 0: si = ((int64_t)n * e.K + k) * 9 + tap; break;          // W[co=n][ci=k][tap]
         case 1: si = ((int64_t)k * e.N + n) * 9 + (8 - tap); break;    // W[co=k][ci=n][flipped tap]
         case 2: si = ((int64_t)k * e.N + n) * 9 + tap; break;          // Wt[ci=k][co=n][tap]
@@ -35,7 +47,8 @@ pack_weights_kernel(const vv_pack_entry* __restrict__ table, const float* __rest
       }
       v = src[si];
     }
-    dst[d] = v;
+    if (b16) reinterpret_cast<__bf16*>(dst)[d] = (__bf16)v;
+    else dst[d] = v;
   }
 }
 
