@@ -96,6 +96,8 @@ typedef struct vv_conv_params {
 int vv_conv_mfma(const vv_conv_params* p, vv_stream stream);
 /* number of pixel tiles the kernel uses for this (B,H,W): rows of the `stats` partial array */
 int vv_conv_ntiles(int32_t B, int32_t H, int32_t W);
+/* the same for a launch with these `kind` / pad0 `flags` (the bf16 3x3 kernels use 128-pixel tiles on the 8x8 / 4x4 levels) */
+int vv_conv_ntiles2(int32_t B, int32_t H, int32_t W, int32_t kind, int32_t flags);
 
 /* Weight-gradient (autograd of nn.Conv2d / nn.ConvTranspose2d wrt weight; cuDNN in the reference).
  * dW[tap][ci][co] = sum_pixels act[pixel+tap][ci] * dy[pixel][co]  (CONV3)

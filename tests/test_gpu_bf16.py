@@ -51,7 +51,7 @@ def test_bf16_conv3x3_matches_rounded_operand_reference(H, Cin, Cout, B):
             continue
         src = torch.randn(G, B * H * H, K, generator=g).cuda() if dgrad else x
         pk = _pack(lib, L, w, G, 1 if dgrad else 0, K, N, st)
-        nt = lib.vv_conv_ntiles(B, H, H)
+        nt = lib.vv_conv_ntiles2(B, H, H, L.CONV3, L.CONV_BF16)
         y = torch.full((G, B * H * H, N), 3.0, device='cuda')
         s_ = torch.zeros(G, nt, 2, N, device='cuda')
         cp = L.ConvParams(L.CONV3, L.IN_PLAIN if dgrad else L.IN_ACT, G, B, H, H, K, K, N, L.view(src, K, 0, src.stride(0)),

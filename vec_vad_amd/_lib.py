@@ -85,6 +85,7 @@ _SIGS = {
     'vv_wino_ntiles': (c_i32, [c_i32, c_i32]),
     'vv_pack_wino': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
+    'vv_conv_ntiles2': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
     'vv_wgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     'vv_wgrad_bf16': (c_i32, [C.POINTER(WgradParams), c_vp]),

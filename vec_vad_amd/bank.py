@@ -297,7 +297,7 @@ class UNetBank:
         ws.t = [f(Ga, B * (2 * H) * (2 * H), co) for (_, H, ci, co) in lay.convT]
         ws.pooled = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.mode == L.IN_POOL}
         ws.erased = f(Ga, B * HWp, lay.convs[0].cinp)
-        nt = [max(lib.vv_conv_ntiles(B, l.H, l.H), lib.vv_wino_ntiles(B, l.H)) for l in lay.convs]
+        nt = [max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_wino_ntiles(B, l.H)) for l in lay.convs]
         ws.stats = f(Ga, max(n * 2 * l.cout for n, l in zip(nt, lay.convs)))
         ws.ab = torch.zeros(4, len(lay.convs), Ga, lay.cmax, device=d)
         ws.out4 = f(Ga, B * HWp, 4)
@@ -356,7 +356,7 @@ class UNetBank:
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
             P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
-            nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles(B, l.H, l.H)
+            nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag)
             P.add(lib.vv_bn_finalize,
                   (Ga, l.cout, nt, B * l.H * l.H, 1 if train else 0, 0.1, 1e-5, ws.stats.data_ptr(), nt * 2 * l.cout,
                    pbase + 4 * lay.p['c%d.g' % l.idx][0], pbase + 4 * lay.p['c%d.beta' % l.idx][0], U,
@@ -419,7 +419,7 @@ class UNetBank:
         ws.bnscr = f(Ga, 2 * lay.cmax)
         ws.ocpart = f(Ga, B, 132)
         ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
-        ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles(B, l.H, l.H), lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin
+        ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin
                               for l in lay.convs if l.mode == L.IN_CAT))
         # wgrad split-K choice: ~1024 workgroups per launch
         wplan = {}
@@ -544,7 +544,7 @@ class UNetBank:
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
-            ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles(B, m.H, m.H)
+            ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles2(B, m.H, m.H, L.CONV3, self.cflag)
             P.add(lib.vv_bias_from_partials, (Ga, m.cin, ntd, skipc, co, ws.dstats.data_ptr(), ntd * 2 * m.cin,
                                               gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u)
             y = ws.y[sidx]

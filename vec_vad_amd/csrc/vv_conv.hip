@@ -30,8 +30,10 @@ struct Geo {
 // carries 8 channels of a 16-channel K step (lanes 0-31: k 0..7, lanes 32-63: k 8..15), 1/16 of the matrix-core time of the
 // fp32 instruction -- this variant is bound by HBM / staging, not by MFMA.
 // S16 (with BF, plain input): src0 holds bf16 elements -- a dy that BatchNorm backward stored as bf16; copied, not converted.
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, bool S16>
-__global__ void __launch_bounds__(VV_WG, (BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2))
+// MR: 32-pixel row blocks per wave (2 = 256-pixel tiles; 1 = 128-pixel tiles, four workgroups per CU: the bf16 kernels on the 8x8 / 4x4
+// levels, where a launch has few, long workgroups and is bound by the chunk round trips)
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, bool S16, int MR>
+__global__ void __launch_bounds__(VV_WG, MR == 1 ? 4 : ((BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2)))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
@@ -40,7 +42,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr int S = BF ? CK / 2 + ((CK / 8) % 2 ? 8 : 4) : CK + 4;
   constexpr int S4 = S / 4;
   static_assert(S4 % 2 == 1, "odd float4 stride");
-  constexpr int MR = 2;                 // 2 x 32 pixels per wave
+  static_assert(TH * TW * NI == 128 * MR, "tile pixels");
   constexpr int TN = NR * 32;
   constexpr int KGC = BF ? CK / 16 : CK / 8;   // K groups per chunk: 8 fp32 channels (4 MFMAs) or 16 bf16 channels (1 MFMA)
   constexpr int A4 = NI * HH * HW * S4; // float4 slots of the activation halo tile
@@ -79,7 +81,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   int abase[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
-    const int pp = wave * 64 + m * 32 + l31;
+    const int pp = wave * (32 * MR) + m * 32 + l31;
     const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
     abase[m] = ((im * HH + r * SP) * HW + c * SP) * S4 + half;
   }
@@ -213,7 +215,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-      const int pp = wave * 64 + m * 32 + row;
+      const int pp = wave * (32 * MR) + m * 32 + row;
       const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
       const int img = img0 + im;
       if (img < p.B) {
@@ -270,13 +272,13 @@ inline bool tile_geo(int H, int W, TileGeo* t) {
   return false;
 }
 
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false, bool S16 = false>
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false, bool S16 = false, int MR = 2>
 int launch(const vv_conv_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NN = p->Cout / (NR * 32);
   const int total = p->G * NN * NT;
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK, BF, S16>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
+  VV_LAUNCH((conv_mfma_kernel<TH, TW, NI, NR, KIND, CK, BF, S16, MR>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NN,
                      total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -286,6 +288,10 @@ template <int KIND, int CK, bool BF, bool S16 = false>
 int dispatch(const vv_conv_params* p, hipStream_t st) {
   TileGeo t;
   if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
+  if constexpr (BF && KIND == VV_CONV3) {      // 128-pixel tiles on the 8x8 / 4x4 levels (vv_conv_ntiles2)
+    if (p->H == 8) return (p->Cout % 64) == 0 ? launch<8, 8, 2, 2, KIND, 16, BF, S16, 1>(p, st) : launch<8, 8, 2, 1, KIND, 16, BF, S16, 1>(p, st);
+    if (p->H == 4) return (p->Cout % 64) == 0 ? launch<4, 4, 8, 2, KIND, 16, BF, S16, 1>(p, st) : launch<4, 4, 8, 1, KIND, 16, BF, S16, 1>(p, st);
+  }
   // 64-wide N tiles halve the activation re-staging but also halve the workgroup count; with 2 workgroups per CU
   // (512 slots) a launch needs >= 2 full rounds of them, otherwise 32-wide tiles fill the machine better.
   const int nt = ((p->B + t.NI - 1) / t.NI) * (p->H / t.TH) * (p->W / t.TW);
@@ -318,6 +324,11 @@ extern "C" int vv_conv_ntiles(int32_t B, int32_t H, int32_t W) {
   TileGeo t;
   if (!tile_geo(H, W, &t)) return -1;
   return ((B + t.NI - 1) / t.NI) * (H / t.TH) * (W / t.TW);
+}
+
+extern "C" int vv_conv_ntiles2(int32_t B, int32_t H, int32_t W, int32_t kind, int32_t flags) {
+  if ((flags & VV_CONV_BF16) && kind == VV_CONV3 && H == W && (H == 8 || H == 4)) return (B + (H == 8 ? 1 : 7)) / (H == 8 ? 2 : 8);
+  return vv_conv_ntiles(B, H, W);
 }
 
 extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
