@@ -289,6 +289,7 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   TileGeo t;
   if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
   if constexpr (BF && KIND == VV_CONV3) {      // 128-pixel tiles on the 8x8 / 4x4 levels (vv_conv_ntiles2)
+    if (p->H == 16) return (p->Cout % 64) == 0 ? launch<8, 16, 1, 2, KIND, 16, BF, S16, 1>(p, st) : launch<8, 16, 1, 1, KIND, 16, BF, S16, 1>(p, st);
     if (p->H == 8) return (p->Cout % 64) == 0 ? launch<8, 8, 2, 2, KIND, 16, BF, S16, 1>(p, st) : launch<8, 8, 2, 1, KIND, 16, BF, S16, 1>(p, st);
     if (p->H == 4) return (p->Cout % 64) == 0 ? launch<4, 4, 8, 2, KIND, 16, BF, S16, 1>(p, st) : launch<4, 4, 8, 1, KIND, 16, BF, S16, 1>(p, st);
   }
@@ -327,6 +328,7 @@ extern "C" int vv_conv_ntiles(int32_t B, int32_t H, int32_t W) {
 }
 
 extern "C" int vv_conv_ntiles2(int32_t B, int32_t H, int32_t W, int32_t kind, int32_t flags) {
+  if ((flags & VV_CONV_BF16) && kind == VV_CONV3 && H == W && H == 16) return B * 2;
   if ((flags & VV_CONV_BF16) && kind == VV_CONV3 && H == W && (H == 8 || H == 4)) return (B + (H == 8 ? 1 : 7)) / (H == 8 ? 2 : 8);
   return vv_conv_ntiles(B, H, W);
 }
