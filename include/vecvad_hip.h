@@ -189,6 +189,7 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
  * dz_gstride still in floats) for consumers that round it to bf16 anyway (vv_conv_mfma + VV_CONV_SRC_BF16, vv_wgrad_bf16 +
  * VV_WGRAD_DY_BF16) */
 #define VV_BNBWD_DZ_BF16 1
+#define VV_BNBWD_PARTIALS_PER_CUBE 2   /* vv_bn_bwd_apply: `partial` holds [G][B][2][C] written by vv_outconv_bwd */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
   int32_t flags;
@@ -227,9 +228,13 @@ int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream);
 
 /* backward of the 1x1 conv: dA[p][c] = sum_co dout[p][co] W[co][c]; dW[co][c] = sum_p dout[p][co] act[p][c];
  * db[co] = sum_p dout[p][co].  partial: [G][nblk][132]; reduced by vv_outconv_bwd_reduce. */
+/* bnpart != NULL: also writes the BatchNorm-backward partial sums of the layer in front of the output conv, [G][B][2][C]
+ * (per cube: sum of g = dA * [act > 0], sum of g * xhat; mean / invstd: [G][ab_gstride] like a, b) -- vv_bn_bwd_apply with
+ * VV_BNBWD_PARTIALS_PER_CUBE then needs no vv_bn_bwd_reduce pass for that layer. */
 int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
                    int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
-                   int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial, vv_stream stream);
+                   int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial, const float* mean,
+                   const float* invstd, float* bnpart, vv_stream stream);
 int vv_outconv_bwd_nblk(int32_t B, int32_t HW);
 int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
                           float* dW, float* db, int64_t grad_gstride, vv_stream stream);

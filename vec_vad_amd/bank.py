@@ -454,7 +454,9 @@ class UNetBank:
         y = ws.y[last.idx]
         P.add(lib.vv_outconv_bwd, (Ga, B, HWp, nf, ws.dout4.data_ptr(), y.data_ptr(), y.stride(0), self._p(ws.ab[0, last.idx]),
                                    self._p(ws.ab[1, last.idx]), abg, pbase + 4 * lay.p['o.w'][0], U, ws.gA_last.data_ptr(),
-                                   ws.gA_last.stride(0), ws.ocpart.data_ptr()), 'outconv_bwd')
+                                   ws.gA_last.stride(0), ws.ocpart.data_ptr(),
+                                   # ... and the BatchNorm-backward partial sums of the last conv layer (no reduction pass for it)
+                                   self._p(ws.ab[2, last.idx]), self._p(ws.ab[3, last.idx]), ws.bnpart.data_ptr()), 'outconv_bwd')
         P.add(lib.vv_outconv_bwd_reduce, (Ga, nf, B, ws.ocpart.data_ptr(), self._p(self.oc, g0), gbase + 4 * lay.p['o.w'][0],
                                           gbase + 4 * lay.p['o.b'][0], U), 'outconv_bwd_reduce')
 
@@ -495,14 +497,17 @@ class UNetBank:
             # the layer visited two steps earlier used the same dy buffer: its weight-grad (side stream) must be done
             reuse_wait = ('wdone%d' % order[pos - 2],) if pos >= 2 else ()
             dA, dpool, dpg = dA_for(l)
-            bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout, L.BNBWD_DZ_BF16 if dz16 else 0, y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
+            from_outconv = i == last.idx           # its partial sums were written by vv_outconv_bwd
+            bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
+                               (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
-            P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i, wait=reuse_wait)
+            if not from_outconv:
+                P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i, wait=reuse_wait)
             P.add(lib.vv_bn_bwd_apply, (C.byref(bp), pbase + 4 * lay.p['c%d.g' % i][0], U, gbase + 4 * lay.p['c%d.g' % i][0],
                                         gbase + 4 * lay.p['c%d.beta' % i][0], U, ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
-                  record='dy%d' % i)
+                  record='dy%d' % i, wait=reuse_wait if from_outconv else ())
             # data gradient
             if i > 0:
                 Dl = ws.D[i]

@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(VV_WG)
 outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restrict__ dout4, const float* __restrict__ y,
                    const int64_t y_gstride, const float* __restrict__ a, const float* __restrict__ b,
                    const int64_t ab_gstride, const float* __restrict__ w, const int64_t param_gstride,
-                   float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial) {
+                   float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial,
+                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ bnpart) {
   __shared__ float sh[32][8 * 16 + 4];
   const int g = blockIdx.y, cube = blockIdx.x;
   const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
@@ -353,10 +354,15 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
   float db[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int co = 0; co < 4; ++co) dw[co] = make_float4(0, 0, 0, 0);
+  // bnpart: this block also leaves the BatchNorm-backward partial sums of the layer in front of the output conv (sum of
+  // g = dA * [act > 0] and of g * xhat per channel), so that layer needs no reduction pass over dA and y
+  float4 m4 = make_float4(0, 0, 0, 0), i4 = m4, s1 = m4, s2 = m4;
+  if (bnpart) { m4 = *reinterpret_cast<const float4*>(mean + abo); i4 = *reinterpret_cast<const float4*>(invstd + abo); }
   for (int i = pg; i < HW; i += 32) {
     const int64_t pix = (int64_t)cube * HW + i;
     const float4 d = *reinterpret_cast<const float4*>(dout4 + ((int64_t)g * MB + pix) * 4);
-    const float4 v = vv_act4(*reinterpret_cast<const float4*>(yg + pix * C + c), a4, b4);
+    const float4 yv = *reinterpret_cast<const float4*>(yg + pix * C + c);
+    const float4 v = vv_act4(yv, a4, b4);
     const float dd[4] = {d.x, d.y, d.z, d.w};
     float4 o = make_float4(0, 0, 0, 0);
 #pragma unroll
@@ -368,6 +374,12 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
       db[co] += dd[co];
     }
     *reinterpret_cast<float4*>(dAg + pix * C + c) = o;
+    if (bnpart) {
+      const float4 gq = make_float4(v.x > 0.f ? o.x : 0.f, v.y > 0.f ? o.y : 0.f, v.z > 0.f ? o.z : 0.f, v.w > 0.f ? o.w : 0.f);
+      s1.x += gq.x; s1.y += gq.y; s1.z += gq.z; s1.w += gq.w;
+      s2.x = fmaf(gq.x, (yv.x - m4.x) * i4.x, s2.x); s2.y = fmaf(gq.y, (yv.y - m4.y) * i4.y, s2.y);
+      s2.z = fmaf(gq.z, (yv.z - m4.z) * i4.z, s2.z); s2.w = fmaf(gq.w, (yv.w - m4.w) * i4.w, s2.w);
+    }
   }
 #pragma unroll
   for (int co = 0; co < 4; ++co) *reinterpret_cast<float4*>(&sh[pg][sub * 16 + co * 4]) = dw[co];
@@ -386,6 +398,17 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
     float s = 0.f;
     for (int k = 0; k < 32; ++k) s += sh[k][128 + (tid - 128)];
     out[tid] = s;
+  }
+  if (!bnpart) return;
+  __syncthreads();
+  *reinterpret_cast<float4*>(&sh[pg][sub * 8]) = s1;
+  *reinterpret_cast<float4*>(&sh[pg][sub * 8 + 4]) = s2;
+  __syncthreads();
+  if (tid < 2 * C) {                       // C = 32: threads 0..31 -> sum g, 32..63 -> sum g*xhat; fixed order over the 32 pixel lanes
+    const int which = tid >> 5, cc = tid & 31;
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += sh[k][(cc >> 2) * 8 + which * 4 + (cc & 3)];
+    bnpart[((int64_t)(g * B + cube) * 2 + which) * C + cc] = s;
   }
 }
 
@@ -640,15 +663,17 @@ extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
 extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int64_t param_gstride, float* dgamma,
                                float* dbeta, int64_t grad_gstride, float* scratch, vv_stream stream) {
   if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial || !gamma || !dgamma || !dbeta || !scratch) return VV_ERR_BAD_ARG;
-  const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  // VV_BNBWD_PARTIALS_PER_CUBE: the partials were left by vv_outconv_bwd (one block per cube), not by vv_bn_bwd_reduce
+  const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B : vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  const int nblk_apply = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   const int64_t M = (int64_t)p->B * p->H * p->W;
   VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(VV_WG), 0, (hipStream_t)stream, p->C, nblk, (double)M,
             p->partial, dgamma, dbeta, grad_gstride, scratch);
   VV_CHECK_LAUNCH();
   if (p->dpool)
-    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, gamma, param_gstride, scratch);
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
   else
-    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, gamma, param_gstride, scratch);
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -668,11 +693,12 @@ extern "C" int vv_outconv_bwd_nblk(int32_t B, int32_t HW) { (void)HW; return B; 
 extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
                               int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
                               int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial,
-                              vv_stream stream) {
+                              const float* mean, const float* invstd, float* bnpart, vv_stream stream) {
   if (!dout4 || !y || !a || !b || !w || !dA || !partial) return VV_ERR_BAD_ARG;
+  if (bnpart && (!mean || !invstd)) return VV_ERR_BAD_ARG;
   if (C != 32) return VV_ERR_UNSUPPORTED;
   VV_LAUNCH(outconv_bwd_kernel, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
-                     a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial);
+                     a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
