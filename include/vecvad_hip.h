@@ -68,6 +68,10 @@ typedef struct vv_view {
  * the data gradient reading a dy that vv_bn_bwd_apply stored as bf16 (VV_BNBWD_DZ_BF16): same values as rounding on load, half
  * the bytes */
 #define VV_CONV_SRC_BF16 2
+/* with VV_CONV_BF16, VV_CONV3 / VV_CONVT_DGRAD: `out` is stored as bf16 (nearest even; same element indexing, gstride in
+ * floats) and `stats` sums the stored values -- activation gradients in bf16, torch.autocast's dtype for them; read back by
+ * vv_bn_bwd_* (VV_BNBWD_DA_BF16), by the transposed conv's data / weight gradient (VV_CONV_SRC_BF16 / VV_WGRAD_DY_BF16) */
+#define VV_CONV_OUT_BF16 8
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */
@@ -190,6 +194,7 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
  * VV_WGRAD_DY_BF16) */
 #define VV_BNBWD_DZ_BF16 1
 #define VV_BNBWD_PARTIALS_PER_CUBE 2   /* vv_bn_bwd_apply: `partial` holds [G][B][2][C] written by vv_outconv_bwd */
+#define VV_BNBWD_DA_BF16 4             /* dA (and dpool) hold bf16 elements (VV_CONV_OUT_BF16 / vv_outconv_bwd dA_bf16) */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
   int32_t flags;
@@ -234,7 +239,8 @@ int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream);
 int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
                    int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
                    int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial, const float* mean,
-                   const float* invstd, float* bnpart, vv_stream stream);
+                   const float* invstd, float* bnpart, int32_t dA_bf16 /* store dA as bf16 (VV_BNBWD_DA_BF16 consumer) */,
+                   vv_stream stream);
 int vv_outconv_bwd_nblk(int32_t B, int32_t HW);
 int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
                           float* dW, float* db, int64_t grad_gstride, vv_stream stream);

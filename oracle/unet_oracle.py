@@ -213,10 +213,12 @@ def cubes_to_inputs(raw, flow):
 #   'dgradT'   transposed-conv data gradient          (fp32 operands while False)
 #   'wgrad'    3x3 conv weight gradient:              corr(bf16(x), bf16(dy)) for maps of at least 'wgrad_min_hw' pixels a side,
 #              fp32 operands otherwise; 'wgradT' the same for the transposed conv
-# Tensors between operations, bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam stay fp32.
+#   'dx16'     activation gradients are STORED as bf16: the data gradients returned by the 3x3 conv / transposed conv and the
+#              gradient the 1x1 output conv hands to the last double_conv are rounded (torch.autocast's dtype for them)
+# Other tensors between operations, bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam stay fp32.
 # ----------------------------------------------------------------------------------------------------
 MIXED = None
-MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 0, 'wgradT': True}
+MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 0, 'wgradT': True, 'dx16': True}
 
 
 def _r(t):
@@ -254,7 +256,20 @@ class _MixedConv(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw, w.shape, dyw, padding=1)
         if ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
+        if dx is not None and cfg.get('dx16', False):
+            dx = _r(dx)
         return dx, dw, db, None, None
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity whose gradient is rounded to bf16 (the activation gradient the output conv hands back, 'dx16')"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
 
 
 def _conv3(x, w, b):
@@ -298,6 +313,8 @@ def unet_forward(sd, stems, x, train):
     for u in stems['up']:
         up = _convT(h, sd[u + '.up.weight'], sd[u + '.up.bias'])
         h = _double_conv(sd, u + '.conv.conv', torch.cat([skips.pop(), up], dim=1), train)
+    if MIXED is not None and MIXED.get('dx16', False):
+        h = _RoundGrad.apply(h)
     return F.conv2d(h, sd[stems['outc'] + '.conv.weight'], sd[stems['outc'] + '.conv.bias'])
 
 

@@ -218,6 +218,71 @@ def test_bf16_transposed_conv_weight_gradient(H, Cin, Cout, B, ks):
         assert (got[gi].double() - ref32).abs().max().item() > 2e-4 * scale
 
 
+def _as_bf16_storage(t):
+    """the tensor's values rounded to bf16 and stored as bf16 at the start of an fp32-sized buffer (what the kernels write / read
+    with their *_BF16 storage flags: same element indexing, group stride still counted in floats)"""
+    buf = torch.zeros_like(t)
+    flat = buf.view(t.shape[0], -1).view(torch.bfloat16)
+    flat[:, :t[0].numel()] = t.reshape(t.shape[0], -1).to(torch.bfloat16)
+    return buf
+
+
+@pytest.mark.parametrize('H,Cin,Cout,B', [(32, 32, 64, 2), (8, 128, 128, 5), (4, 256, 128, 9)])
+def test_bf16_stored_activation_gradients(H, Cin, Cout, B):
+    """VV_CONV_OUT_BF16 / VV_BNBWD_DA_BF16: (a) a data-gradient launch that stores its output as bf16 writes exactly the
+    rounded values of the fp32 launch, and its per-tile column sums are those of the stored values; (b) BatchNorm backward reading
+    bf16 dA / dpool gives bit-identical dy, dgamma, dbeta to reading an fp32 tensor that holds the same (rounded) values."""
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H + Cin)
+    st = torch.cuda.current_stream().cuda_stream
+    # (a)
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    dy = torch.randn(G, B * H * H, Cout, generator=g).cuda()
+    pk = _pack(lib, L, w, G, 1, Cout, Cin, st)
+    nt = lib.vv_conv_ntiles2(B, H, H, L.CONV3, L.CONV_BF16)
+    outs, stats = [], []
+    for flag in (L.CONV_BF16, L.CONV_BF16 | L.CONV_OUT_BF16):
+        o = torch.zeros(G, B * H * H, Cin, device='cuda')
+        s_ = torch.zeros(G, nt, 2, Cin, device='cuda')
+        cp = L.ConvParams(L.CONV3, L.IN_PLAIN, G, B, H, H, Cout, Cout, Cin, L.view(dy, Cout, 0, dy.stride(0)), None, None, 0, L.NULL_VIEW,
+                          0, flag, None, pk.data_ptr(), pk.stride(0), None, 0, L.view(o, Cin, 0, o.stride(0)), s_.data_ptr())
+        L.check(lib.vv_conv_mfma(C.byref(cp), st), 'dgrad')
+        outs.append(o)
+        stats.append(s_.sum(1)[:, 0])
+    stored = outs[1].view(G, -1).view(torch.bfloat16)[:, :B * H * H * Cin].float().view(G, B * H * H, Cin)
+    assert torch.equal(stored, _r(outs[0]))
+    torch.testing.assert_close(stats[1], stored.double().sum(1).float(), rtol=1e-4, atol=1e-3)
+    # (b)
+    Cc = Cin
+    y = torch.randn(G, B * H * H, Cc, generator=g).cuda()
+    dA = _r(torch.randn(G, B * H * H, Cc, generator=g)).cuda()
+    dP = _r(torch.randn(G, B * (H // 2) * (H // 2), Cc, generator=g)).cuda()
+    a = (torch.rand(G, Cc, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cc, generator=g) * 0.2).cuda()
+    mean = torch.randn(G, Cc, generator=g).cuda() * 0.1
+    invstd = (torch.rand(G, Cc, generator=g) + 0.5).cuda()
+    gamma = (torch.rand(G, Cc, generator=g) + 0.5).cuda()
+    nblk = lib.vv_bn_bwd_nblk(B, H, H, Cc)
+    for pool in (False, True):
+        res = []
+        for da16 in (False, True):
+            dAx, dPx = (_as_bf16_storage(dA), _as_bf16_storage(dP)) if da16 else (dA, dP)
+            dz = torch.zeros(G, B * H * H, Cc, device='cuda')
+            part = torch.zeros(G, nblk * 2 * Cc, device='cuda')
+            dgm, dbt, scr = torch.zeros(G, Cc, device='cuda'), torch.zeros(G, Cc, device='cuda'), torch.zeros(G, 2 * Cc, device='cuda')
+            bp = L.BnBwdParams(G, B, H, H, Cc, L.BNBWD_DA_BF16 if da16 else 0, y.data_ptr(), y.stride(0), a.data_ptr(), b.data_ptr(),
+                               mean.data_ptr(), invstd.data_ptr(), Cc, L.view(dAx, Cc, 0, dAx.stride(0)),
+                               dPx.data_ptr() if pool else None, dPx.stride(0) if pool else 0, dz.data_ptr(), dz.stride(0), part.data_ptr())
+            L.check(lib.vv_bn_bwd_reduce(C.byref(bp), st), 'reduce')
+            L.check(lib.vv_bn_bwd_apply(C.byref(bp), gamma.data_ptr(), Cc, dgm.data_ptr(), dbt.data_ptr(), Cc, scr.data_ptr(), st), 'apply')
+            res.append((dz, dgm, dbt))
+        for x, z in zip(res[0], res[1]):
+            assert torch.equal(x, z)
+        assert res[0][0].abs().max() > 0
+
+
 def _build_bf16(monkeypatch, kind='net4'):
     monkeypatch.setenv('VV_PRECISION', 'bf16')
     from test_gpu_unet import _build

@@ -22,6 +22,8 @@ CONV_SRC_BF16 = 2      # VV_CONV_SRC_BF16
 PACK_BF16 = 4          # vv_pack_entry.mode flag: bf16 panel for VV_CONV_BF16 launches
 BNBWD_DZ_BF16 = 1      # vv_bnbwd_params.flags
 BNBWD_PARTIALS_PER_CUBE = 2
+BNBWD_DA_BF16 = 4
+CONV_OUT_BF16 = 8       # VV_CONV_OUT_BF16
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 
 
@@ -100,7 +102,7 @@ _SIGS = {
     'vv_bn_bwd_apply': (c_i32, [C.POINTER(BnBwdParams), c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'vv_outconv_fwd': (c_i32, [C.POINTER(OutconvParams), c_vp]),
     'vv_outconv_bwd': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
-                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'vv_outconv_bwd_nblk': (c_i32, [c_i32, c_i32]),
     'vv_outconv_bwd_reduce': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'vv_bias_grad': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),

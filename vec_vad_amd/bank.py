@@ -220,6 +220,9 @@ class UNetBank:
         self.bf16_wgrad = os.environ.get('VV_BF16_WGRAD', '1') != '0'      # 0: keep the fp32 (Winograd) weight gradient in bf16 mode
         # BatchNorm backward stores dy as bf16 when both of its consumers round it to bf16 anyway (bit-identical results)
         self.dz16 = bool(self.cflag) and self.bf16_wgrad and os.environ.get('VV_BF16_DZ', '1') != '0'
+        # activation gradients (outputs of the data-gradient kernels and of the output-conv backward) stored as bf16 -- NOT
+        # neutral: it is torch.autocast's dtype for them; BatchNorm backward and the transposed conv's gradients read them back
+        self.da16 = bool(self.cflag) and self.bf16_wgrad and os.environ.get('VV_BF16_DA', '1') != '0'
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
@@ -456,7 +459,8 @@ class UNetBank:
                                    self._p(ws.ab[1, last.idx]), abg, pbase + 4 * lay.p['o.w'][0], U, ws.gA_last.data_ptr(),
                                    ws.gA_last.stride(0), ws.ocpart.data_ptr(),
                                    # ... and the BatchNorm-backward partial sums of the last conv layer (no reduction pass for it)
-                                   self._p(ws.ab[2, last.idx]), self._p(ws.ab[3, last.idx]), ws.bnpart.data_ptr()), 'outconv_bwd')
+                                   self._p(ws.ab[2, last.idx]), self._p(ws.ab[3, last.idx]), ws.bnpart.data_ptr(),
+                                   1 if self.da16 else 0), 'outconv_bwd')
         P.add(lib.vv_outconv_bwd_reduce, (Ga, nf, B, ws.ocpart.data_ptr(), self._p(self.oc, g0), gbase + 4 * lay.p['o.w'][0],
                                           gbase + 4 * lay.p['o.b'][0], U), 'outconv_bwd_reduce')
 
@@ -499,7 +503,8 @@ class UNetBank:
             dA, dpool, dpg = dA_for(l)
             from_outconv = i == last.idx           # its partial sums were written by vv_outconv_bwd
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
-                               (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
+                               (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0) |
+                               (L.BNBWD_DA_BF16 if self.da16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
@@ -513,7 +518,7 @@ class UNetBank:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
-                                  self.cflag | (L.CONV_SRC_BF16 if dz16 else 0), None,
+                                  self.cflag | (L.CONV_SRC_BF16 if dz16 else 0) | (L.CONV_OUT_BF16 if self.da16 else 0), None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
@@ -545,7 +550,8 @@ class UNetBank:
             skipc = lay.convs[m.skip].cout
             dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
             DT = ws.DT[u]
-            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0, self.cflag, None,
+            cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0,
+                              self.cflag | ((L.CONV_SRC_BF16 | L.CONV_OUT_BF16) if self.da16 else 0), None,
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
@@ -556,8 +562,8 @@ class UNetBank:
             wpl = wplan['t%d' % u]
             ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)
             wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
-                               self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, 0, None, dy,
-                               ws.wpart.data_ptr(), wpg)
+                               self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0,
+                               L.WGRAD_DY_BF16 if (kw and self.da16) else 0, None, dy, ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1)
             P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr(), wpg,

@@ -72,6 +72,11 @@ __device__ __forceinline__ uint2 vv_pack_bf16x4(float4 v) {
   return o;
 }
 
+__device__ __forceinline__ float4 vv_unpack_bf16x4(uint2 u) {
+  return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xFFFF0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xFFFF0000u));
+}
+
 // Resolved (per group) description of how a convolution reads its input.
 struct VVSrc {
   const float* p0; int cs0, co0;

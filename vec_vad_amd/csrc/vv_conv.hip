@@ -204,6 +204,10 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   const int OH = KIND == VV_CONVT_FWD ? 2 * H : H, OW = KIND == VV_CONVT_FWD ? 2 * W : W;
   float* __restrict__ outg = p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff;
   const int ocs = p.out.cstride;
+  // VV_CONV_OUT_BF16 (bf16 kernels, data gradients): the output is stored as bf16 (same element indexing, gstride in floats)
+  // and the per-tile column sums are those of the stored (rounded) values
+  const bool o16 = BF && KIND != VV_CONVT_FWD && (p.pad0 & VV_CONV_OUT_BF16);
+  __bf16* __restrict__ outh = reinterpret_cast<__bf16*>(p.out.ptr + (int64_t)g * p.out.gstride) + p.out.coff;
   float bias[NR], s1[NR], s2[NR];
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
@@ -224,11 +228,17 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int ph = 0; ph < 4; ++ph) o[((ph >> 1) * OW + (ph & 1)) * ocs] = acc[m][ph][i] + bias[0];
         } else {
-          float* o = outg + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs + co0 + l31;
+          const int64_t e = ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs + co0 + l31;
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
-            const float v = acc[m][n][i] + bias[n];
-            o[n * 32] = v;
+            float v = acc[m][n][i] + bias[n];
+            if (o16) {
+              const __bf16 hv = (__bf16)v;
+              outh[e + n * 32] = hv;
+              v = (float)hv;
+            } else {
+              outg[e + n * 32] = v;
+            }
             s1[n] += v; s2[n] = fmaf(v, v, s2[n]);
           }
         }
@@ -340,7 +350,8 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool bf = (p->pad0 & VV_CONV_BF16) != 0;
   if (bf && p->CinP % 16) return VV_ERR_BAD_ARG;
-  if ((p->pad0 & VV_CONV_SRC_BF16) && !(bf && p->in_mode == VV_IN_PLAIN && p->kind == VV_CONV3 && p->src0.coff % 2 == 0)) return VV_ERR_BAD_ARG;
+  if ((p->pad0 & VV_CONV_SRC_BF16) && !(bf && p->in_mode == VV_IN_PLAIN && p->kind != VV_CONVT_FWD && p->src0.coff % 2 == 0)) return VV_ERR_BAD_ARG;
+  if ((p->pad0 & VV_CONV_OUT_BF16) && !(bf && p->kind != VV_CONVT_FWD)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
   switch (p->kind) {
     case VV_CONV3:
@@ -354,6 +365,7 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
       return bf ? dispatch<VV_CONVT_FWD, 16, true>(p, st) : dispatch<VV_CONVT_FWD, 16, false>(p, st);
     case VV_CONVT_DGRAD:
       if (bf && p->CinP % 16) return VV_ERR_BAD_ARG;
+      if (bf && (p->pad0 & VV_CONV_SRC_BF16)) return dispatch<VV_CONVT_DGRAD, 8, true, true>(p, st);
       return bf ? dispatch<VV_CONVT_DGRAD, 8, true>(p, st) : dispatch<VV_CONVT_DGRAD, 8, false>(p, st);
   }
   return VV_ERR_BAD_ARG;

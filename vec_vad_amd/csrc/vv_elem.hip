@@ -146,6 +146,13 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
   float* __restrict__ dz = p.dz + (int64_t)g * p.dz_gstride;
   const float* __restrict__ dA = p.dA.ptr + (int64_t)g * p.dA.gstride + p.dA.coff;
   const int dcs = p.dA.cstride;
+  // VV_BNBWD_DA_BF16: dA / dpool hold bf16 elements (activation gradients stored by the bf16 kernels)
+  const bool da16 = (p.flags & VV_BNBWD_DA_BF16) != 0;
+  const unsigned short* __restrict__ dAh = reinterpret_cast<const unsigned short*>(p.dA.ptr + (int64_t)g * p.dA.gstride) + p.dA.coff;
+  auto ldA = [&](const int64_t pix) -> float4 {
+    if (da16) return vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(dAh + pix * dcs + c));
+    return *reinterpret_cast<const float4*>(dA + pix * dcs + c);
+  };
   const int64_t abo = (int64_t)g * p.ab_gstride + c;
   const float4 a4 = *reinterpret_cast<const float4*>(p.a + abo), b4 = *reinterpret_cast<const float4*>(p.b + abo);
   const float4 m4 = *reinterpret_cast<const float4*>(p.mean + abo), i4 = *reinterpret_cast<const float4*>(p.invstd + abo);
@@ -178,7 +185,7 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
   if constexpr (!POOL) {
     for (int i = pl; i < 256; i += PL) {
       const int64_t pix = (int64_t)blk * 256 + i;
-      if (pix < M) one(pix, *reinterpret_cast<const float4*>(dA + pix * dcs + c));
+      if (pix < M) one(pix, ldA(pix));
     }
   } else {
     // unit of work = one 2x2 pooling window (first maximum wins ties, like at::max_pool2d)
@@ -210,10 +217,11 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
         if (zz[k].z > bz) { bz = zz[k].z; iz = k; }
         if (zz[k].w > bw) { bw = zz[k].w; iw = k; }
       }
-      const float4 dp = *reinterpret_cast<const float4*>(dP + wi * C + c);
+      const float4 dp = da16 ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dP) + wi * C + c))
+                             : *reinterpret_cast<const float4*>(dP + wi * C + c);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float4 d = *reinterpret_cast<const float4*>(dA + px[k] * dcs + c);
+        float4 d = ldA(px[k]);
         d.x += ix == k ? dp.x : 0.f; d.y += iy == k ? dp.y : 0.f; d.z += iz == k ? dp.z : 0.f; d.w += iw == k ? dp.w : 0.f;
         one(px[k], d);
       }
@@ -336,7 +344,8 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
                    const int64_t y_gstride, const float* __restrict__ a, const float* __restrict__ b,
                    const int64_t ab_gstride, const float* __restrict__ w, const int64_t param_gstride,
                    float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial,
-                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ bnpart) {
+                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ bnpart,
+                   const int dA_bf16) {
   __shared__ float sh[32][8 * 16 + 4];
   const int g = blockIdx.y, cube = blockIdx.x;
   const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
@@ -373,7 +382,13 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
       dw[co].z = fmaf(dd[co], v.z, dw[co].z); dw[co].w = fmaf(dd[co], v.w, dw[co].w);
       db[co] += dd[co];
     }
-    *reinterpret_cast<float4*>(dAg + pix * C + c) = o;
+    if (dA_bf16) {                         // stored as bf16 (mixed precision): the sums below are those of the stored values
+      const uint2 h = vv_pack_bf16x4(o);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dAg) + pix * C + c) = h;
+      o = vv_unpack_bf16x4(h);
+    } else {
+      *reinterpret_cast<float4*>(dAg + pix * C + c) = o;
+    }
     if (bnpart) {
       const float4 gq = make_float4(v.x > 0.f ? o.x : 0.f, v.y > 0.f ? o.y : 0.f, v.z > 0.f ? o.z : 0.f, v.w > 0.f ? o.w : 0.f);
       s1.x += gq.x; s1.y += gq.y; s1.z += gq.z; s1.w += gq.w;
@@ -693,12 +708,12 @@ extern "C" int vv_outconv_bwd_nblk(int32_t B, int32_t HW) { (void)HW; return B; 
 extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
                               int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
                               int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial,
-                              const float* mean, const float* invstd, float* bnpart, vv_stream stream) {
+                              const float* mean, const float* invstd, float* bnpart, int32_t dA_bf16, vv_stream stream) {
   if (!dout4 || !y || !a || !b || !w || !dA || !partial) return VV_ERR_BAD_ARG;
   if (bnpart && (!mean || !invstd)) return VV_ERR_BAD_ARG;
   if (C != 32) return VV_ERR_UNSUPPORTED;
   VV_LAUNCH(outconv_bwd_kernel, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
-                     a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart);
+                     a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart, dA_bf16);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }

@@ -232,7 +232,7 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
 // gradient, gathered at stride 2 from a (2TH+1) x (2TW+1) halo tile -- the three column taps of a row share 17 reads (9 per
 // row on the 4x4 level, where a lane's 8 pixels are a 2x4 block).  Pixel tiles of 128 (8 K steps) keep the 4x halo tile of up to
 // 64 output channels in LDS.
-template <int TH, int TW, int NI, int CB, int OB>
+template <int TH, int TW, int NI, int CB, int OB, bool DY16>
 __global__ void __launch_bounds__(VV_WG, 1)
 wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
   constexpr int KW = 4 / (CB * OB);
@@ -288,14 +288,24 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
     const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
     stA0.prefetch(sa, img0, ty0, tx0, (cit2 * CB) * 32, tid, p.CinP);
     if constexpr (CB == 2) stA1.prefetch(sa, img0, ty0, tx0, (cit2 * CB + 1) * 32, tid, p.CinP);
-    stB0.prefetch(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB) * 32, tid, p.Cout);
-    if constexpr (OB == 2) stB1.prefetch(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB + 1) * 32, tid, p.Cout);
+    if constexpr (DY16) {
+      stB0.prefetch16(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB) * 32, tid, p.Cout);
+      if constexpr (OB == 2) stB1.prefetch16(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB + 1) * 32, tid, p.Cout);
+    } else {
+      stB0.prefetch(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB) * 32, tid, p.Cout);
+      if constexpr (OB == 2) stB1.prefetch(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB + 1) * 32, tid, p.Cout);
+    }
   };
   auto commit = [&]() __attribute__((always_inline)) {
     stA0.commit_bf16(lds, tid);
     if constexpr (CB == 2) stA1.commit_bf16(lds + ASZ, tid);
-    stB0.commit_bf16(lds + CB * ASZ, tid);
-    if constexpr (OB == 2) stB1.commit_bf16(lds + CB * ASZ + BSZ, tid);
+    if constexpr (DY16) {
+      stB0.commit_raw16(lds + CB * ASZ, tid);
+      if constexpr (OB == 2) stB1.commit_raw16(lds + CB * ASZ + BSZ, tid);
+    } else {
+      stB0.commit_bf16(lds + CB * ASZ, tid);
+      if constexpr (OB == 2) stB1.commit_bf16(lds + CB * ASZ + BSZ, tid);
+    }
   };
 
   const unsigned* ldsw = reinterpret_cast<const unsigned*>(lds);
@@ -426,7 +436,10 @@ int launch_t(const vv_wgrad_params* p, hipStream_t st) {
   if (p->ksplit > NT) return VV_ERR_BAD_ARG;
   const int total = p->G * (NCI / CB) * (NCO / OB) * p->ksplit;
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  if (p->pad0 & VV_WGRAD_DY_BF16)
+    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, true>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  else
+    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -473,7 +486,7 @@ extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
   if (p->Cout % 32 || p->ksplit < 1) return VV_ERR_BAD_ARG;
   if (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE) return VV_ERR_UNSUPPORTED;   // feed the materialised tensor
   hipStream_t st = (hipStream_t)stream;
-  if ((p->pad0 & VV_WGRAD_DY_BF16) && (p->kind != VV_CONV3 || p->dy.coff % 2)) return VV_ERR_BAD_ARG;
+  if ((p->pad0 & VV_WGRAD_DY_BF16) && p->dy.coff % 2) return VV_ERR_BAD_ARG;
   if (p->kind != VV_CONV3) {                   // weight gradient of the transposed conv (H x W = its input resolution)
     switch (p->H == p->W ? p->H : 0) {
       case 16: return dispatch_t<8, 16, 1>(p, st);
