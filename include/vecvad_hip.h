@@ -72,6 +72,11 @@ typedef struct vv_view {
  * floats) and `stats` sums the stored values -- activation gradients in bf16, torch.autocast's dtype for them; read back by
  * vv_bn_bwd_* (VV_BNBWD_DA_BF16), by the transposed conv's data / weight gradient (VV_CONV_SRC_BF16 / VV_WGRAD_DY_BF16) */
 #define VV_CONV_OUT_BF16 8
+/* with VV_CONV_BF16 (any kind; modes PLAIN / ACT / CAT): EVERY source tensor of the launch holds bf16 elements -- pre-BN conv
+ * outputs written with VV_CONV_OUT_BF16 (then also allowed on forward and VV_CONVT_FWD launches: torch.autocast's output dtype),
+ * pooled / frame-erased inputs written by vv_pool_act / vv_cube_erase with their bf16 switch.  coff / cstride / csplit stay in
+ * elements, gstride in floats. */
+#define VV_CONV_ALLSRC_BF16 16
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */
@@ -138,6 +143,7 @@ int vv_wgrad_ntiles(int32_t kind, int32_t B, int32_t H, int32_t W);
  *   *ntiles  = pixel tiles (the upper bound of ksplit),
  *   *nblocks = workgroups per group and k-split part,
  *   *kw      = slabs per workgroup and (ci-tile, co-tile) (1 today): pass ksplit * kw to vv_wgrad_reduce. */
+#define VV_WGRAD_X_BF16 2    /* vv_wgrad_bf16, pad0: the layer input (src0 / src1) holds bf16 elements; needs VV_WGRAD_DY_BF16 too */
 #define VV_WGRAD_DY_BF16 1   /* vv_wgrad_bf16, pad0: dy holds bf16 elements (written by vv_bn_bwd_apply with VV_BNBWD_DZ_BF16) */
 int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream);
 int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W, int32_t CinP, int32_t Cout, int32_t* ntiles, int32_t* nblocks,
@@ -194,6 +200,7 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
  * VV_WGRAD_DY_BF16) */
 #define VV_BNBWD_DZ_BF16 1
 #define VV_BNBWD_PARTIALS_PER_CUBE 2   /* vv_bn_bwd_apply: `partial` holds [G][B][2][C] written by vv_outconv_bwd */
+#define VV_BNBWD_Y_BF16 8              /* y holds bf16 elements (VV_CONV_OUT_BF16 on the forward launch) */
 #define VV_BNBWD_DA_BF16 4             /* dA (and dpool) hold bf16 elements (VV_CONV_OUT_BF16 / vv_outconv_bwd dA_bf16) */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
@@ -220,7 +227,7 @@ typedef struct vv_outconv_params {
   const float* y; int64_t y_gstride; const float* a; const float* b; int64_t ab_gstride;
   const float* w; const float* bias; int64_t param_gstride;   /* W [oc][C], bias [oc] inside the parameter block */
   const int32_t* oc;             /* [G] output channels (3 raw / 2 flow) */
-  const float* tgt0; int32_t tgt0_cstride; int32_t pad0;   /* cube NHWC [B,HW,15] */
+  const float* tgt0; int32_t tgt0_cstride; int32_t pad0;   /* cube NHWC [B,HW,15]; pad0 bit 0: y holds bf16 elements */
   const float* tgt1; int32_t tgt1_cstride; int32_t pad1;   /* flow NHWC [B,HW,2*T_of] */
   const int32_t* tgt_src;        /* [G] 0: tgt0, 1: tgt1 */
   const int32_t* tgt_coff;       /* [G] first target channel */
@@ -239,7 +246,7 @@ int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream);
 int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dout4, const float* y,
                    int64_t y_gstride, const float* a, const float* b, int64_t ab_gstride, const float* w,
                    int64_t param_gstride, float* dA, int64_t dA_gstride, float* partial, const float* mean,
-                   const float* invstd, float* bnpart, int32_t dA_bf16 /* store dA as bf16 (VV_BNBWD_DA_BF16 consumer) */,
+                   const float* invstd, float* bnpart, int32_t flags /* bit 0: store dA as bf16 (VV_BNBWD_DA_BF16 consumer); bit 1: y holds bf16 elements */,
                    vv_stream stream);
 int vv_outconv_bwd_nblk(int32_t B, int32_t HW);
 int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
@@ -271,9 +278,10 @@ int vv_cube_gather(int32_t B, int32_t T, int32_t Tf, int32_t HW, const int64_t* 
  *  vv_cube_erase: out[g][pixel][k] = cube[pixel][chmap[g][k]] (or 0): the frame-erased input of UNet g, Cin padded to CP
  *                 (model/unet.py:178-183). */
 int vv_pool_act(int32_t G, int32_t B, int32_t H2, int32_t W2, int32_t C, const float* y, int64_t y_gstride, const float* a,
-                const float* b, int64_t ab_gstride, float* out, int64_t out_gstride, vv_stream stream);
+                const float* b, int64_t ab_gstride, float* out, int64_t out_gstride, int32_t io_bf16 /* y and out hold bf16 */,
+                vv_stream stream);
 int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, const float* cube, const int32_t* chmap, float* out,
-                  int64_t out_gstride, vv_stream stream);
+                  int64_t out_gstride, int32_t out_bf16, vv_stream stream);
 
 /* NCHW <-> NHWC for the module surface (forward(x, x_of) takes NCHW like the reference) */
 int vv_nchw_to_nhwc(int32_t B, int32_t C, int32_t HW, const float* src, float* dst, vv_stream stream);

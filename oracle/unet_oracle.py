@@ -215,10 +215,12 @@ def cubes_to_inputs(raw, flow):
 #              fp32 operands otherwise; 'wgradT' the same for the transposed conv
 #   'dx16'     activation gradients are STORED as bf16: the data gradients returned by the 3x3 conv / transposed conv and the
 #              gradient the 1x1 output conv hands to the last double_conv are rounded (torch.autocast's dtype for them)
-# Other tensors between operations, bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam stay fp32.
+#   'y16'      the outputs of the 3x3 conv / transposed conv (bias added) are STORED as bf16 (torch.autocast's output dtype);
+#              BatchNorm statistics are those of the stored tensor
+# Bias, BatchNorm, max-pool, the 1x1 output conv, the loss and Adam compute in fp32.
 # ----------------------------------------------------------------------------------------------------
 MIXED = None
-MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 0, 'wgradT': True, 'dx16': True}
+MIXED_BF16 = {'fwd': True, 'dgrad': True, 'dgradT': True, 'wgrad': True, 'wgrad_min_hw': 0, 'wgradT': True, 'dx16': True, 'y16': True}
 
 
 def _r(t):
@@ -232,8 +234,10 @@ class _MixedConv(torch.autograd.Function):
         ctx.transposed, ctx.cfg = transposed, cfg
         xr, wr = (_r(x), _r(w)) if cfg['fwd'] else (x, w)
         if transposed:
-            return F.conv_transpose2d(xr, wr, b, stride=2, padding=1, output_padding=1)
-        return F.conv2d(xr, wr, b, padding=1)
+            out = F.conv_transpose2d(xr, wr, b, stride=2, padding=1, output_padding=1)
+        else:
+            out = F.conv2d(xr, wr, b, padding=1)
+        return _r(out) if cfg.get('y16', False) else out
 
     @staticmethod
     def backward(ctx, dy):

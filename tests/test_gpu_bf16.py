@@ -371,6 +371,8 @@ def test_bf16_dy_storage_is_bitwise_neutral(monkeypatch):
     rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
     grads = []
     monkeypatch.setenv('VV_PRECISION', 'bf16')
+    monkeypatch.setenv('VV_BF16_DA', '0')          # the other (non-neutral) storage choices off: this test isolates dy
+    monkeypatch.setenv('VV_BF16_Y', '0')
     for dz in ('1', '0'):
         monkeypatch.setenv('VV_BF16_DZ', dz)
         net, sd, _ = _build('full', False)

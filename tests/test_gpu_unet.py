@@ -185,6 +185,29 @@ def test_side_stream_weight_grad_is_bitwise_identical():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_two_stream_schedules_have_every_dependency(monkeypatch, precision):
+    """The two-stream schedules again, with one stream stalled before each of its launches (FusedTrainer.debug_delay): the other
+    stream runs far ahead, so a cross-stream dependency that is only satisfied by luck (e.g. a side-stream weight gradient reading
+    a data gradient the main stream has not written yet) changes the result.  Both directions, both schedules."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    monkeypatch.setenv('VV_PRECISION', precision)
+    raw, flow = O.seeded_cubes(24, 1, 4)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    outs = []
+    for overlap, delay in ((False, None), (True, (0, 200000)), (True, (1, 200000)), ('paired', (0, 200000)), ('paired', (1, 200000))):
+        net, _, _ = _build('net4', False)
+        net.train()
+        tr = FusedTrainer(net, overlap=overlap)
+        tr.debug_delay = delay
+        for s in range(2):
+            tr.step_cubes(rawd, flowd, torch.arange(24, device='cuda'))
+        outs.append(tr.bank.params.clone())
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
 def test_odd_batch_sizes_train():
     """ragged batches (last partial batch is kept, train.py:373 drop_last=False): B = 1, 2, 7, 17."""
     from oracle import unet_oracle as O

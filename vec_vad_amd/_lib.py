@@ -24,6 +24,9 @@ BNBWD_DZ_BF16 = 1      # vv_bnbwd_params.flags
 BNBWD_PARTIALS_PER_CUBE = 2
 BNBWD_DA_BF16 = 4
 CONV_OUT_BF16 = 8       # VV_CONV_OUT_BF16
+CONV_ALLSRC_BF16 = 16   # VV_CONV_ALLSRC_BF16
+BNBWD_Y_BF16 = 8
+WGRAD_X_BF16 = 2
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 
 
@@ -109,8 +112,8 @@ _SIGS = {
     'vv_bias_from_partials': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'vv_adam': (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     'vv_cube_gather': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'vv_pool_act': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
-    'vv_cube_erase': (c_i32, [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'vv_pool_act': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
+    'vv_cube_erase': (c_i32, [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     'vv_nchw_to_nhwc': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'vv_out4_to_nchw': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     'vv_nchw_to_out4': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),

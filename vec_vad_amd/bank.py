@@ -223,6 +223,10 @@ class UNetBank:
         # activation gradients (outputs of the data-gradient kernels and of the output-conv backward) stored as bf16 -- NOT
         # neutral: it is torch.autocast's dtype for them; BatchNorm backward and the transposed conv's gradients read them back
         self.da16 = bool(self.cflag) and self.bf16_wgrad and os.environ.get('VV_BF16_DA', '1') != '0'
+        # ... and so are the conv / transposed-conv OUTPUTS (pre-BatchNorm tensors; torch.autocast's output dtype, oracle 'y16') and
+        # with them the pooled / frame-erased inputs: every tensor a bf16 kernel stages is then bf16 (VV_CONV_ALLSRC_BF16)
+        self.y16 = self.dz16 and self.da16 and os.environ.get('VV_BF16_Y', '1') != '0'
+        self.fflag = self.cflag | ((L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16) if self.y16 else 0)      # forward launches
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
@@ -354,7 +358,7 @@ class UNetBank:
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             y = ws.y[l.idx]
             panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
-            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, self.cflag, chmap,
+            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, self.fflag, chmap,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
@@ -371,14 +375,15 @@ class UNetBank:
             sidx, H, ci, co = lay.convT[u]
             y, t = ws.y[sidx], ws.t[u]
             cp = L.ConvParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, L.view(y, ci, 0, y.stride(0)),
-                              self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, self.cflag, None,
+                              self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0, self.fflag, None,
                               kbase + 4 * lay.pk['t%d.f' % u][0], UP, pbase + 4 * lay.p['t%d.b' % u][0], U,
                               L.view(t, co, 0, t.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'convT%d' % u)
 
         P.add(lib.vv_cube_erase, (Ga, B * HW0 * HW0, ws.cube.shape[2], lay.convs[0].cinp, ws.cube.data_ptr(),
-                                  self._p(self.chmap, g0 * lay.convs[0].cinp), ws.erased.data_ptr(), ws.erased.stride(0)), 'cube_erase')
+                                  self._p(self.chmap, g0 * lay.convs[0].cinp), ws.erased.data_ptr(), ws.erased.stride(0),
+                                  1 if self.y16 else 0), 'cube_erase')
         for l in lay.convs:
             if l.mode == L.IN_CAT:
                 convT(l.up)
@@ -386,13 +391,13 @@ class UNetBank:
                 s = lay.convs[l.src]
                 ys, pb = ws.y[s.idx], ws.pooled[l.idx]
                 P.add(lib.vv_pool_act, (Ga, B, l.H, l.H, s.cout, ys.data_ptr(), ys.stride(0), self._p(ws.ab[0, s.idx]),
-                                        self._p(ws.ab[1, s.idx]), abg, pb.data_ptr(), pb.stride(0)), 'pool%d' % l.idx)
+                                        self._p(ws.ab[1, s.idx]), abg, pb.data_ptr(), pb.stride(0), 1 if self.y16 else 0), 'pool%d' % l.idx)
             conv(l)
         last = lay.convs[-1]
         y = ws.y[last.idx]
         op = L.OutconvParams(Ga, B, HW0 * HW0, self.nf, y.data_ptr(), y.stride(0), self._p(ws.ab[0, last.idx]),
                              self._p(ws.ab[1, last.idx]), abg, pbase + 4 * lay.p['o.w'][0], pbase + 4 * lay.p['o.b'][0], U,
-                             self._p(self.oc, g0), ws.cube.data_ptr(), ws.cube.shape[2], 0, ws.flow.data_ptr(),
+                             self._p(self.oc, g0), ws.cube.data_ptr(), ws.cube.shape[2], 1 if self.y16 else 0, ws.flow.data_ptr(),
                              ws.flow.shape[2], 0, self._p(self.tsrc, g0), self._p(self.tcoff, g0), ws.out4.data_ptr(),
                              ws.score.data_ptr(), ws.gscale.data_ptr() if train else None,
                              ws.dout4.data_ptr() if train else None)
@@ -460,7 +465,7 @@ class UNetBank:
                                    ws.gA_last.stride(0), ws.ocpart.data_ptr(),
                                    # ... and the BatchNorm-backward partial sums of the last conv layer (no reduction pass for it)
                                    self._p(ws.ab[2, last.idx]), self._p(ws.ab[3, last.idx]), ws.bnpart.data_ptr(),
-                                   1 if self.da16 else 0), 'outconv_bwd')
+                                   (1 if self.da16 else 0) | (2 if self.y16 else 0)), 'outconv_bwd')
         P.add(lib.vv_outconv_bwd_reduce, (Ga, nf, B, ws.ocpart.data_ptr(), self._p(self.oc, g0), gbase + 4 * lay.p['o.w'][0],
                                           gbase + 4 * lay.p['o.b'][0], U), 'outconv_bwd_reduce')
 
@@ -504,7 +509,7 @@ class UNetBank:
             from_outconv = i == last.idx           # its partial sums were written by vv_outconv_bwd
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
                                (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0) |
-                               (L.BNBWD_DA_BF16 if self.da16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
+                               (L.BNBWD_DA_BF16 if self.da16 else 0) | (L.BNBWD_Y_BF16 if self.y16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
@@ -518,7 +523,8 @@ class UNetBank:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
-                                  self.cflag | (L.CONV_SRC_BF16 if dz16 else 0) | (L.CONV_OUT_BF16 if self.da16 else 0), None,
+                                  self.cflag | ((L.CONV_ALLSRC_BF16 if self.y16 else L.CONV_SRC_BF16) if dz16 else 0) |
+                                  (L.CONV_OUT_BF16 if self.da16 else 0), None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
@@ -533,7 +539,8 @@ class UNetBank:
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)           # kw > 0: the bf16-operand kernel (mixed precision)
             # pad0 bit 8: Winograd F(2x2,3x3) form of the weight gradient (same tiles / slabs, 2.25x fewer MFMA cycles)
-            wflag = (L.WGRAD_DY_BF16 if dz16 else 0) if kw else (self.wgrad_flag if self.wino_wgrad else 0)
+            wflag = ((L.WGRAD_DY_BF16 if dz16 else 0) | (L.WGRAD_X_BF16 if (dz16 and self.y16) else 0)) if kw else \
+                (self.wgrad_flag if self.wino_wgrad else 0)
             wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit,
                                wflag, chmap,
                                L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
@@ -551,7 +558,7 @@ class UNetBank:
             dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
             DT = ws.DT[u]
             cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0,
-                              self.cflag | ((L.CONV_SRC_BF16 | L.CONV_OUT_BF16) if self.da16 else 0), None,
+                              self.cflag | (((L.CONV_ALLSRC_BF16 if self.y16 else L.CONV_SRC_BF16) | L.CONV_OUT_BF16) if self.da16 else 0), None,
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
@@ -563,9 +570,12 @@ class UNetBank:
             ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)
             wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
                                self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0,
-                               L.WGRAD_DY_BF16 if (kw and self.da16) else 0, None, dy, ws.wpart.data_ptr(), wpg)
+                               ((L.WGRAD_DY_BF16 | (L.WGRAD_X_BF16 if self.y16 else 0)) if (kw and self.da16) else 0), None, dy,
+                               ws.wpart.data_ptr(), wpg)
             P.keep.append(wp)
-            P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1)
+            # side stream: its dy is the concat layer's data gradient (main stream) -- wait for it
+            P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1,
+                  wait=('D%d' % m.idx,), pwait=('*main',))
             P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr(), wpg,
                                         gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
 

@@ -32,7 +32,7 @@ struct Geo {
 // S16 (with BF, plain input): src0 holds bf16 elements -- a dy that BatchNorm backward stored as bf16; copied, not converted.
 // MR: 32-pixel row blocks per wave (2 = 256-pixel tiles; 1 = 128-pixel tiles, four workgroups per CU: the bf16 kernels on the 8x8 / 4x4
 // levels, where a launch has few, long workgroups and is bound by the chunk round trips)
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, bool S16, int MR>
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, int S16, int MR>      // S16: 0 fp32 sources, 1 plain bf16 src0, 2 ALL sources bf16
 __global__ void __launch_bounds__(VV_WG, MR == 1 ? 4 : ((BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2)))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
@@ -117,7 +117,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   auto issue = [&](const int c0) {
-    if constexpr (S16) stA.prefetch16(s, img0, oy0, ox0, c0, tid); else stA.prefetch(s, img0, oy0, ox0, c0, tid);
+    if constexpr (S16 == 2) stA.prefetch16x(s, img0, oy0, ox0, c0, tid);
+    else if constexpr (S16 == 1) stA.prefetch16(s, img0, oy0, ox0, c0, tid);
+    else stA.prefetch(s, img0, oy0, ox0, c0, tid);
     const int so = (BF ? (c0 >> 4) : (c0 >> 3)) * 2 * Cout * 16;
 #pragma unroll
     for (int k = 0; k < NBT; ++k) {
@@ -126,7 +128,10 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
   };
   auto commit = [&]() {
-    if constexpr (S16) stA.commit_raw16(lds, tid); else if constexpr (BF) stA.commit_bf16(lds, tid); else stA.commit(lds, tid);
+    if constexpr (S16 == 2) stA.commit16(lds, tid);
+    else if constexpr (S16 == 1) stA.commit_raw16(lds, tid);
+    else if constexpr (BF) stA.commit_bf16(lds, tid);
+    else stA.commit(lds, tid);
 #pragma unroll
     for (int k = 0; k < NBT; ++k) {
       const int it = tid + k * VV_WG;
@@ -206,7 +211,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   const int ocs = p.out.cstride;
   // VV_CONV_OUT_BF16 (bf16 kernels, data gradients): the output is stored as bf16 (same element indexing, gstride in floats)
   // and the per-tile column sums are those of the stored (rounded) values
-  const bool o16 = BF && KIND != VV_CONVT_FWD && (p.pad0 & VV_CONV_OUT_BF16);
+  const bool o16 = BF && (p.pad0 & VV_CONV_OUT_BF16);
   __bf16* __restrict__ outh = reinterpret_cast<__bf16*>(p.out.ptr + (int64_t)g * p.out.gstride) + p.out.coff;
   float bias[NR], s1[NR], s2[NR];
 #pragma unroll
@@ -224,9 +229,13 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const int img = img0 + im;
       if (img < p.B) {
         if constexpr (KIND == VV_CONVT_FWD) {
-          float* o = outg + ((int64_t)(img * OH + 2 * (ty0 + r)) * OW + 2 * (tx0 + c)) * ocs + co0 + l31;
+          const int64_t e = ((int64_t)(img * OH + 2 * (ty0 + r)) * OW + 2 * (tx0 + c)) * ocs + co0 + l31;
 #pragma unroll
-          for (int ph = 0; ph < 4; ++ph) o[((ph >> 1) * OW + (ph & 1)) * ocs] = acc[m][ph][i] + bias[0];
+          for (int ph = 0; ph < 4; ++ph) {
+            const float v = acc[m][ph][i] + bias[0];
+            if (o16) outh[e + ((ph >> 1) * OW + (ph & 1)) * ocs] = (__bf16)v;
+            else outg[e + ((ph >> 1) * OW + (ph & 1)) * ocs] = v;
+          }
         } else {
           const int64_t e = ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs + co0 + l31;
 #pragma unroll
@@ -282,7 +291,7 @@ inline bool tile_geo(int H, int W, TileGeo* t) {
   return false;
 }
 
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false, bool S16 = false, int MR = 2>
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF = false, int S16 = 0, int MR = 2>
 int launch(const vv_conv_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NN = p->Cout / (NR * 32);
@@ -294,7 +303,7 @@ int launch(const vv_conv_params* p, hipStream_t st) {
   return VV_OK;
 }
 
-template <int KIND, int CK, bool BF, bool S16 = false>
+template <int KIND, int CK, bool BF, int S16 = 0>
 int dispatch(const vv_conv_params* p, hipStream_t st) {
   TileGeo t;
   if (!tile_geo(p->H, p->W, &t)) return VV_ERR_UNSUPPORTED;
@@ -351,21 +360,26 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   const bool bf = (p->pad0 & VV_CONV_BF16) != 0;
   if (bf && p->CinP % 16) return VV_ERR_BAD_ARG;
   if ((p->pad0 & VV_CONV_SRC_BF16) && !(bf && p->in_mode == VV_IN_PLAIN && p->kind != VV_CONVT_FWD && p->src0.coff % 2 == 0)) return VV_ERR_BAD_ARG;
-  if ((p->pad0 & VV_CONV_OUT_BF16) && !(bf && p->kind != VV_CONVT_FWD)) return VV_ERR_BAD_ARG;
+  if ((p->pad0 & VV_CONV_OUT_BF16) && !bf) return VV_ERR_BAD_ARG;
+  if ((p->pad0 & VV_CONV_ALLSRC_BF16) && (!bf || p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
+  const int sm = !bf ? 0 : ((p->pad0 & VV_CONV_ALLSRC_BF16) ? 2 : ((p->pad0 & VV_CONV_SRC_BF16) ? 1 : 0));
   switch (p->kind) {
     case VV_CONV3:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
       // (32-channel chunks for the bf16 kernels: measured -25 % with fp32 input on the 32x32 layers (spills), +-0 end to end with
       // bf16 input -- not kept)
-      if (bf && (p->pad0 & VV_CONV_SRC_BF16)) return dispatch<VV_CONV3, 16, true, true>(p, st);
+      if (sm == 2) return dispatch<VV_CONV3, 16, true, 2>(p, st);
+      if (sm == 1) return dispatch<VV_CONV3, 16, true, 1>(p, st);
       return bf ? dispatch<VV_CONV3, 16, true>(p, st) : dispatch<VV_CONV3, 16, false>(p, st);
     case VV_CONVT_FWD:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
+      if (sm == 2) return dispatch<VV_CONVT_FWD, 16, true, 2>(p, st);
       return bf ? dispatch<VV_CONVT_FWD, 16, true>(p, st) : dispatch<VV_CONVT_FWD, 16, false>(p, st);
     case VV_CONVT_DGRAD:
       if (bf && p->CinP % 16) return VV_ERR_BAD_ARG;
-      if (bf && (p->pad0 & VV_CONV_SRC_BF16)) return dispatch<VV_CONVT_DGRAD, 8, true, true>(p, st);
+      if (sm == 2) return dispatch<VV_CONVT_DGRAD, 8, true, 2>(p, st);
+      if (sm == 1) return dispatch<VV_CONVT_DGRAD, 8, true, 1>(p, st);
       return bf ? dispatch<VV_CONVT_DGRAD, 8, true>(p, st) : dispatch<VV_CONVT_DGRAD, 8, false>(p, st);
   }
   return VV_ERR_BAD_ARG;

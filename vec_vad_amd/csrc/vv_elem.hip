@@ -165,8 +165,13 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
     c2 = *reinterpret_cast<const float4*>(scratch + (int64_t)g * 2 * C + C + c);
   }
 
+  const bool y16 = (p.flags & VV_BNBWD_Y_BF16) != 0;
+  auto ldY = [&](const int64_t pix) -> float4 {
+    if (y16) return vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c));
+    return *reinterpret_cast<const float4*>(y + pix * C + c);
+  };
   auto one = [&](const int64_t pix, float4 d) {
-    const float4 yv = *reinterpret_cast<const float4*>(y + pix * C + c);
+    const float4 yv = ldY(pix);
     float4 z;
     z.x = fmaf(a4.x, yv.x, b4.x); z.y = fmaf(a4.y, yv.y, b4.y); z.z = fmaf(a4.z, yv.z, b4.z); z.w = fmaf(a4.w, yv.w, b4.w);
     d.x = z.x > 0.f ? d.x : 0.f; d.y = z.y > 0.f ? d.y : 0.f; d.z = z.z > 0.f ? d.z : 0.f; d.w = z.w > 0.f ? d.w : 0.f;
@@ -204,7 +209,7 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
       float4 zz[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float4 yv = *reinterpret_cast<const float4*>(y + px[k] * C + c);
+        const float4 yv = ldY(px[k]);
         zz[k].x = fmaxf(fmaf(a4.x, yv.x, b4.x), 0.f); zz[k].y = fmaxf(fmaf(a4.y, yv.y, b4.y), 0.f);
         zz[k].z = fmaxf(fmaf(a4.z, yv.z, b4.z), 0.f); zz[k].w = fmaxf(fmaf(a4.w, yv.w, b4.w), 0.f);
       }
@@ -302,7 +307,9 @@ outconv_fwd_kernel(const vv_outconv_params p) {
   float sse = 0.f;
   for (int i = pg; i < p.HW; i += 32) {
     const int64_t pix = (int64_t)cube * p.HW + i;
-    const float4 v = vv_act4(*reinterpret_cast<const float4*>(y + pix * C + c), a4, b4);
+    const float4 yq = (p.pad0 & 1) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c))
+                                   : *reinterpret_cast<const float4*>(y + pix * C + c);      // pad0 bit 0: y holds bf16 elements
+    const float4 v = vv_act4(yq, a4, b4);
     float o[4];
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
@@ -345,7 +352,7 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
                    const int64_t ab_gstride, const float* __restrict__ w, const int64_t param_gstride,
                    float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial,
                    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ bnpart,
-                   const int dA_bf16) {
+                   const int dA_bf16) {      // flags: bit 0 = dA stored as bf16, bit 1 = y holds bf16 elements
   __shared__ float sh[32][8 * 16 + 4];
   const int g = blockIdx.y, cube = blockIdx.x;
   const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
@@ -370,7 +377,8 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
   for (int i = pg; i < HW; i += 32) {
     const int64_t pix = (int64_t)cube * HW + i;
     const float4 d = *reinterpret_cast<const float4*>(dout4 + ((int64_t)g * MB + pix) * 4);
-    const float4 yv = *reinterpret_cast<const float4*>(yg + pix * C + c);
+    const float4 yv = (dA_bf16 & 2) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(yg) + pix * C + c))
+                                    : *reinterpret_cast<const float4*>(yg + pix * C + c);
     const float4 v = vv_act4(yv, a4, b4);
     const float dd[4] = {d.x, d.y, d.z, d.w};
     float4 o = make_float4(0, 0, 0, 0);
@@ -382,7 +390,7 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
       dw[co].z = fmaf(dd[co], v.z, dw[co].z); dw[co].w = fmaf(dd[co], v.w, dw[co].w);
       db[co] += dd[co];
     }
-    if (dA_bf16) {                         // stored as bf16 (mixed precision): the sums below are those of the stored values
+    if (dA_bf16 & 1) {                     // stored as bf16 (mixed precision): the sums below are those of the stored values
       const uint2 h = vv_pack_bf16x4(o);
       *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dAg) + pix * C + c) = h;
       o = vv_unpack_bf16x4(h);
@@ -583,7 +591,7 @@ nchw_to_out4_kernel(const int B, const int HW, const int oc, const float* __rest
 __global__ void __launch_bounds__(VV_WG)
 pool_act_kernel(const int64_t n4, const int C, const int H2, const int W2, const float* __restrict__ y, const int64_t y_gstride,
                 const float* __restrict__ a, const float* __restrict__ b, const int64_t ab_gstride, float* __restrict__ out,
-                const int64_t out_gstride) {
+                const int64_t out_gstride, const int io16) {     // io16: y and out hold bf16 elements (mixed precision)
   const int g = blockIdx.y;
   const int Q4 = C >> 2;
   const float* yg = y + (int64_t)g * y_gstride;
@@ -599,6 +607,15 @@ pool_act_kernel(const int64_t n4, const int C, const int H2, const int W2, const
     const float* q = yg + (((img * 2 * H2 + 2 * y2) * W + 2 * x2) * (int64_t)C + c);
     const float4 a4 = *reinterpret_cast<const float4*>(a + (int64_t)g * ab_gstride + c);
     const float4 b4 = *reinterpret_cast<const float4*>(b + (int64_t)g * ab_gstride + c);
+    if (io16) {
+      const unsigned short* qh = reinterpret_cast<const unsigned short*>(yg) + (((img * 2 * H2 + 2 * y2) * W + 2 * x2) * (int64_t)C + c);
+      const float4 w00 = vv_act4(vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(qh)), a4, b4);
+      const float4 w01 = vv_act4(vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(qh + C)), a4, b4);
+      const float4 w10 = vv_act4(vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(qh + (int64_t)W * C)), a4, b4);
+      const float4 w11 = vv_act4(vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(qh + (int64_t)(W + 1) * C)), a4, b4);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(og) + e * 4) = vv_pack_bf16x4(vv_max4(vv_max4(w00, w01), vv_max4(w10, w11)));
+      continue;
+    }
     const float4 v00 = vv_act4(*reinterpret_cast<const float4*>(q), a4, b4);
     const float4 v01 = vv_act4(*reinterpret_cast<const float4*>(q + C), a4, b4);
     const float4 v10 = vv_act4(*reinterpret_cast<const float4*>(q + (int64_t)W * C), a4, b4);
@@ -610,7 +627,7 @@ pool_act_kernel(const int64_t n4, const int C, const int H2, const int W2, const
 // frame erasure: out[g][pixel][k] = chmap[g][k] >= 0 ? cube[pixel][chmap[g][k]] : 0   (model/unet.py:178-183)
 __global__ void __launch_bounds__(VV_WG)
 cube_erase_kernel(const int64_t npix, const int Cc, const int CP, const float* __restrict__ cube, const int* __restrict__ chmap,
-                  float* __restrict__ out, const int64_t out_gstride) {
+                  float* __restrict__ out, const int64_t out_gstride, const int out16) {
   const int g = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
   if (e >= npix) return;
@@ -621,7 +638,8 @@ cube_erase_kernel(const int64_t npix, const int Cc, const int CP, const float* _
     float4 v;
     const int m0 = m[k], m1 = m[k + 1], m2 = m[k + 2], m3 = m[k + 3];
     v.x = m0 >= 0 ? q[m0] : 0.f; v.y = m1 >= 0 ? q[m1] : 0.f; v.z = m2 >= 0 ? q[m2] : 0.f; v.w = m3 >= 0 ? q[m3] : 0.f;
-    *reinterpret_cast<float4*>(o + k) = v;
+    if (out16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out + (int64_t)g * out_gstride) + e * CP + k) = vv_pack_bf16x4(v);
+    else *reinterpret_cast<float4*>(o + k) = v;
   }
 }
 
@@ -796,20 +814,20 @@ extern "C" int vv_nchw_to_out4(int32_t B, int32_t HW, int32_t oc, const float* s
 
 extern "C" int vv_pool_act(int32_t G, int32_t B, int32_t H2, int32_t W2, int32_t C, const float* y, int64_t y_gstride,
                            const float* a, const float* b, int64_t ab_gstride, float* out, int64_t out_gstride,
-                           vv_stream stream) {
+                           int32_t io_bf16, vv_stream stream) {
   if (!y || !a || !b || !out || C % 4) return VV_ERR_BAD_ARG;
   const int64_t n4 = (int64_t)B * H2 * W2 * C / 4;
   VV_LAUNCH(pool_act_kernel, dim3(nblocks(n4, 4096), G), dim3(VV_WG), 0, (hipStream_t)stream, n4, C, H2, W2, y, y_gstride, a,
-            b, ab_gstride, out, out_gstride);
+            b, ab_gstride, out, out_gstride, io_bf16);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
 
 extern "C" int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, const float* cube, const int32_t* chmap,
-                             float* out, int64_t out_gstride, vv_stream stream) {
+                             float* out, int64_t out_gstride, int32_t out_bf16, vv_stream stream) {
   if (!cube || !chmap || !out || CP % 4) return VV_ERR_BAD_ARG;
   VV_LAUNCH(cube_erase_kernel, dim3(nblocks(npix), G), dim3(VV_WG), 0, (hipStream_t)stream, npix, Cc, CP, cube, chmap, out,
-            out_gstride);
+            out_gstride, out_bf16);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }

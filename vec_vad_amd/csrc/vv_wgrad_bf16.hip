@@ -22,7 +22,7 @@ namespace {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int TH, int TW, int NI, int CB, int OB, bool DY16>      // DY16: dy holds bf16 elements (VV_WGRAD_DY_BF16)
+template <int TH, int TW, int NI, int CB, int OB, bool DY16, bool A16>      // DY16 / A16: dy / the layer input hold bf16 elements
 __global__ void __launch_bounds__(VV_WG, 1)
 wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
   constexpr int KW = 4 / (CB * OB);          // waves sharing one (ci-block, co-block) pair: they split the pixels
@@ -81,8 +81,13 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     const int img0 = (pt / tpi) * NI;
     const int trem = pt % tpi;
     const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
-    stA0.prefetch(sa, img0, ty0 - 1, tx0 - 1, (cit2 * CB) * 32, tid, p.CinP);
-    if constexpr (CB == 2) stA1.prefetch(sa, img0, ty0 - 1, tx0 - 1, (cit2 * CB + 1) * 32, tid, p.CinP);
+    if constexpr (A16) {
+      stA0.prefetch16x(sa, img0, ty0 - 1, tx0 - 1, (cit2 * CB) * 32, tid, p.CinP);
+      if constexpr (CB == 2) stA1.prefetch16x(sa, img0, ty0 - 1, tx0 - 1, (cit2 * CB + 1) * 32, tid, p.CinP);
+    } else {
+      stA0.prefetch(sa, img0, ty0 - 1, tx0 - 1, (cit2 * CB) * 32, tid, p.CinP);
+      if constexpr (CB == 2) stA1.prefetch(sa, img0, ty0 - 1, tx0 - 1, (cit2 * CB + 1) * 32, tid, p.CinP);
+    }
     if constexpr (DY16) {
       stB0.prefetch16(sb, img0, ty0, tx0, (cot2 * OB) * 32, tid, p.Cout);
       if constexpr (OB == 2) stB1.prefetch16(sb, img0, ty0, tx0, (cot2 * OB + 1) * 32, tid, p.Cout);
@@ -92,8 +97,13 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     }
   };
   auto commit = [&]() __attribute__((always_inline)) {
-    stA0.commit_bf16(lds, tid);
-    if constexpr (CB == 2) stA1.commit_bf16(lds + ASZ, tid);
+    if constexpr (A16) {
+      stA0.commit16(lds, tid);
+      if constexpr (CB == 2) stA1.commit16(lds + ASZ, tid);
+    } else {
+      stA0.commit_bf16(lds, tid);
+      if constexpr (CB == 2) stA1.commit_bf16(lds + ASZ, tid);
+    }
     if constexpr (DY16) {
       stB0.commit_raw16(lds + CB * ASZ, tid);
       if constexpr (OB == 2) stB1.commit_raw16(lds + CB * ASZ + BSZ, tid);
@@ -232,7 +242,7 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
 // gradient, gathered at stride 2 from a (2TH+1) x (2TW+1) halo tile -- the three column taps of a row share 17 reads (9 per
 // row on the 4x4 level, where a lane's 8 pixels are a 2x4 block).  Pixel tiles of 128 (8 K steps) keep the 4x halo tile of up to
 // 64 output channels in LDS.
-template <int TH, int TW, int NI, int CB, int OB, bool DY16>
+template <int TH, int TW, int NI, int CB, int OB, bool DY16, bool A16>
 __global__ void __launch_bounds__(VV_WG, 1)
 wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
   constexpr int KW = 4 / (CB * OB);
@@ -286,8 +296,13 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
     const int img0 = (pt / tpi) * NI;
     const int trem = pt % tpi;
     const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
-    stA0.prefetch(sa, img0, ty0, tx0, (cit2 * CB) * 32, tid, p.CinP);
-    if constexpr (CB == 2) stA1.prefetch(sa, img0, ty0, tx0, (cit2 * CB + 1) * 32, tid, p.CinP);
+    if constexpr (A16) {
+      stA0.prefetch16x(sa, img0, ty0, tx0, (cit2 * CB) * 32, tid, p.CinP);
+      if constexpr (CB == 2) stA1.prefetch16x(sa, img0, ty0, tx0, (cit2 * CB + 1) * 32, tid, p.CinP);
+    } else {
+      stA0.prefetch(sa, img0, ty0, tx0, (cit2 * CB) * 32, tid, p.CinP);
+      if constexpr (CB == 2) stA1.prefetch(sa, img0, ty0, tx0, (cit2 * CB + 1) * 32, tid, p.CinP);
+    }
     if constexpr (DY16) {
       stB0.prefetch16(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB) * 32, tid, p.Cout);
       if constexpr (OB == 2) stB1.prefetch16(sb, img0, 2 * ty0 - 1, 2 * tx0 - 1, (cot2 * OB + 1) * 32, tid, p.Cout);
@@ -297,8 +312,13 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
     }
   };
   auto commit = [&]() __attribute__((always_inline)) {
-    stA0.commit_bf16(lds, tid);
-    if constexpr (CB == 2) stA1.commit_bf16(lds + ASZ, tid);
+    if constexpr (A16) {
+      stA0.commit16(lds, tid);
+      if constexpr (CB == 2) stA1.commit16(lds + ASZ, tid);
+    } else {
+      stA0.commit_bf16(lds, tid);
+      if constexpr (CB == 2) stA1.commit_bf16(lds + ASZ, tid);
+    }
     if constexpr (DY16) {
       stB0.commit_raw16(lds + CB * ASZ, tid);
       if constexpr (OB == 2) stB1.commit_raw16(lds + CB * ASZ + BSZ, tid);
@@ -421,10 +441,12 @@ int launch_b(const vv_wgrad_params* p, hipStream_t st) {
   if (p->ksplit > NT) return VV_ERR_BAD_ARG;
   const int total = p->G * (NCI / CB) * (NCO / OB) * p->ksplit;
   const int nper = (total + 7) / 8;
-  if (p->pad0 & VV_WGRAD_DY_BF16)
-    VV_LAUNCH((wgrad_bf16_kernel<TH, TW, NI, CB, OB, true>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  if ((p->pad0 & VV_WGRAD_X_BF16) && (p->pad0 & VV_WGRAD_DY_BF16))
+    VV_LAUNCH((wgrad_bf16_kernel<TH, TW, NI, CB, OB, true, true>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  else if (p->pad0 & VV_WGRAD_DY_BF16)
+    VV_LAUNCH((wgrad_bf16_kernel<TH, TW, NI, CB, OB, true, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
   else
-    VV_LAUNCH((wgrad_bf16_kernel<TH, TW, NI, CB, OB, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+    VV_LAUNCH((wgrad_bf16_kernel<TH, TW, NI, CB, OB, false, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -436,10 +458,12 @@ int launch_t(const vv_wgrad_params* p, hipStream_t st) {
   if (p->ksplit > NT) return VV_ERR_BAD_ARG;
   const int total = p->G * (NCI / CB) * (NCO / OB) * p->ksplit;
   const int nper = (total + 7) / 8;
-  if (p->pad0 & VV_WGRAD_DY_BF16)
-    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, true>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  if ((p->pad0 & VV_WGRAD_X_BF16) && (p->pad0 & VV_WGRAD_DY_BF16))
+    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, true, true>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  else if (p->pad0 & VV_WGRAD_DY_BF16)
+    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, true, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
   else
-    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+    VV_LAUNCH((wgradT_bf16_kernel<TH, TW, NI, CB, OB, false, false>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -487,6 +511,7 @@ extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
   if (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE) return VV_ERR_UNSUPPORTED;   // feed the materialised tensor
   hipStream_t st = (hipStream_t)stream;
   if ((p->pad0 & VV_WGRAD_DY_BF16) && p->dy.coff % 2) return VV_ERR_BAD_ARG;
+  if ((p->pad0 & VV_WGRAD_X_BF16) && !(p->pad0 & VV_WGRAD_DY_BF16)) return VV_ERR_UNSUPPORTED;
   if (p->kind != VV_CONV3) {                   // weight gradient of the transposed conv (H x W = its input resolution)
     switch (p->H == p->W ? p->H : 0) {
       case 16: return dispatch_t<8, 16, 1>(p, st);

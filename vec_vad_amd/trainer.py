@@ -100,6 +100,7 @@ class FusedTrainer:
         # gradient is done and the next data gradient waits for it, so the only thing sharing the chip with a weight
         # gradient is the next layer's HBM-bound BatchNorm backward; every conv_mfma launch still runs alone.
         self.overlap = overlap
+        self.debug_delay = None          # (stream id, cycles): see _run_dual
         self.side = torch.cuda.Stream(device=self.bank.device) if overlap else None
 
     # ---- plan execution with optional per-launch HIP events and a mid-plan callback
@@ -141,6 +142,9 @@ class FusedTrainer:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)
+            if self.debug_delay and self.debug_delay[0] == sid:      # test knob: stall one stream before each of its launches, so
+                with torch.cuda.stream(st):                            # that a missing cross-stream dependency shows as wrong numbers
+                    torch.cuda._sleep(self.debug_delay[1])
             rc = fn(*args, st.cuda_stream)
             if rc:
                 L.check(rc, label)
