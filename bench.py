@@ -44,16 +44,17 @@ def conv_flops(lay, B, G):
     return fl
 
 
-def conv_bytes(lay, B, G, dy_bytes=4):
-    """algorithmic HBM bytes of the same launches: the input tensor read once + the output tensor written once, fp32
+def conv_bytes(lay, B, G, y_bytes=4, dy_bytes=4, da_bytes=4):
+    """algorithmic HBM bytes of the same launches: the input tensor read once + the output tensor written once
     (every conv output round-trips HBM exactly once); weights (L2 resident) not counted.
-    dy_bytes = 2 when BatchNorm backward stores the data-gradient's input as bf16 (mixed precision)."""
+    Element sizes: 4 everywhere in fp32; in mixed precision the bank stores conv outputs / inputs (y_bytes), the data gradient's
+    input dy (dy_bytes) and the activation gradients it writes (da_bytes) as bf16."""
     by = {}
     for l in lay.convs:
         cin = l.cinp if l.idx == 0 else l.cin                 # layer 0 reads the 16-channel frame-erased buffer
-        by['conv%d' % l.idx] = 4.0 * B * l.H * l.H * G * (cin + l.cout)
+        by['conv%d' % l.idx] = 1.0 * B * l.H * l.H * G * y_bytes * (cin + l.cout)
         if l.idx > 0:
-            by['dgrad%d' % l.idx] = 1.0 * B * l.H * l.H * G * (dy_bytes * l.cout + 4 * l.cin)
+            by['dgrad%d' % l.idx] = 1.0 * B * l.H * l.H * G * (dy_bytes * l.cout + da_bytes * l.cin)
     return by
 
 
@@ -162,7 +163,8 @@ def main():
     torch.cuda.synchronize()
     ws = bank.workspace(B)
     fl = conv_flops(bank.lay, B, bank.Ga)
-    by = conv_bytes(bank.lay, B, bank.Ga, 2 if getattr(bank, 'dz16', False) else 4)
+    by = conv_bytes(bank.lay, B, bank.Ga, 2 if getattr(bank, 'y16', False) else 4, 2 if getattr(bank, 'dz16', False) else 4,
+                    2 if getattr(bank, 'da16', False) else 4)
     # HIP events around every MFMA 3x3-conv launch (forward conv + data-gradient) of the timed region
     ev = []
     trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
@@ -272,8 +274,8 @@ def main():
         mf = out['roofline']
         out['roofline'] = {'bound': 'hbm',
                            'kernel': 'conv_mfma_kernel<..., BF=true> (3x3 implicit GEMM, bf16 operands / fp32 accumulation, forward + '
-                                     'data-gradient launches): achieved = algorithmic bytes (input read once + output written once; fp32 '
-                                     'tensors, except the data gradient\'s input which BatchNorm backward stores as bf16) / time',
+                                     'data-gradient launches): achieved = algorithmic bytes (input read once + output written once; bf16 '
+                                     'tensors) / time.  At 325 FLOP/B these launches sit on the ridge of the bf16 roofline: see frac_of_bf16_mfma_peak',
                            'achieved': (conv_b / conv_t / 1e9) if conv_t > 0 else None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                            'frac': (conv_b / conv_t / HBM_PEAK) if conv_t > 0 else None,
                            'traffic': pmc_traffic('r01_pmc_hbm_traffic_bf16.json') if pmc_ok else None, 'launches_timed': conv_n,
