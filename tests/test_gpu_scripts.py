@@ -11,7 +11,13 @@ from _util import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precision):
+    """train.py's training block + test.py's scoring / frame maps / AUROC against the reference's own outputs (golden).  fp32: the
+    north-star tolerances.  bf16 (`[mi355x] precision = bf16`, BASELINE config 4): judged on AUROC -- within 2e-2
+    of the reference's on this 10-frame set -- with the per-cube / per-frame quantities within 5 %."""
+    monkeypatch.setenv('VV_PRECISION', precision)
+    tol = {'fp32': dict(train=5e-3, loss=1e-3, frame=1e-2, auc=1e-3), 'bf16': dict(train=5e-2, loss=1e-2, frame=1e-1, auc=2e-2)}[precision]
     from oracle import unet_oracle as O
     import train as T
     import test as S
@@ -26,13 +32,13 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch):
     sd, raw_train, of_train = T.train_block(net, [lambda: (raw, flow[:, 0])], epochs=2, batch_size=8, shuffle_seed=-1,
                                             device='cuda', log=lines.append)
     assert all(k.startswith('module.') for k in sd)
-    np.testing.assert_allclose(raw_train, g['raw_train'], rtol=5e-3)
-    np.testing.assert_allclose(of_train, g['of_train'], rtol=5e-3)
+    np.testing.assert_allclose(raw_train, g['raw_train'], rtol=tol['train'])
+    np.testing.assert_allclose(of_train, g['of_train'], rtol=tol['train'])
     # running-average loss lines (printed every 5 batches): first line is batch 0 of epoch 0
     first = lines[0]
     assert 'raw loss: ' in first
     l_raw0 = float(first.split('raw loss: ')[1].split(',')[0])
-    assert abs(l_raw0 - g['losses'][0][0]) <= 1e-3 * g['losses'][0][0]
+    assert abs(l_raw0 - g['losses'][0][0]) <= tol['loss'] * g['losses'][0][0]
 
     # ---- test stage on synthetic frames (same construction as the golden script)
     rng = np.random.default_rng(77)
@@ -64,13 +70,13 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch):
     out_dir = str(tmp_path / 'score_mask')
     fs = S.score_frames([[[net2]]], stats_r, stats_o, fset, fset2, bset, h, w, 1.0, 1.0, True, 'cuda', score_batch=5,
                         result_dir=out_dir)
-    np.testing.assert_allclose(fs, g['frame_scores'], rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(fs, g['frame_scores'], rtol=tol['frame'], atol=tol['frame'])
     # the saved maps have the reference's format (torch-pickled float64 [h,w]) and the same maxima
     m3 = torch.load(os.path.join(out_dir, '3'), weights_only=False)
     assert m3.shape == (h, w) and m3.dtype == np.float64 and abs(m3.max() - fs[3]) < 1e-12
     from utils import save_roc_pr_curve_data, frame_roc_auc
     auc = save_roc_pr_curve_data(fs, np.array(labels), str(tmp_path / 'roc.npz'), verbose=False)
-    assert abs(auc - float(g['auc'])) <= 1e-3
+    assert abs(auc - float(g['auc'])) <= tol['auc']
     assert abs(frame_roc_auc(fs, np.array(labels)) - auc) < 1e-12
 
 
