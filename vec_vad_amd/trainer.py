@@ -89,9 +89,13 @@ class FusedTrainer:
             self.world = dist.get_world_size(process_group)
         if self.world > 1:
             lay = self.bank.lay
-            split = lay.p['c8.w'][0]          # [0, split): encoder convs, [split, U): decoder convs, convT, 1x1 out
-            self.buckets = GradBuckets(self.bank.grads, [0, split, lay.U], process_group)
+            # three buckets in the order the backward pass completes them: [c8.w, U) decoder convs + transposed convs + 1x1 out
+            # (45 % of the parameters), [c4.w, c8.w) the deep encoder layers (51 %), [0, c4.w) the shallow encoder layers (3 %).
+            # Each all-reduce is launched right after the last kernel that writes into its columns and overlaps everything that
+            # follows; only the 3 % bucket is exposed at the end of the step.
+            self.buckets = GradBuckets(self.bank.grads, [0, lay.p['c4.w'][0], lay.p['c8.w'][0], lay.U], process_group)
             self.split_label = 'wgradT_reduce0'   # last launch of the decoder half of the backward plan
+            self.split_label_mid = 'wgrad_reduce4'  # last launch that writes gradients of layers 4..7
         self.event_hook = None
         self.event_labels = None
         # overlap=True ('free'): weight gradients (MFMA-bound, one workgroup per CU) run on a side stream under the
@@ -117,8 +121,8 @@ class FusedTrainer:
             if timed:
                 e1.record()
                 hook(label, e0, e1)
-            if after is not None and label == after[0]:
-                after[1]()
+            if after is not None and label in after:
+                after[label]()
 
     def _run_dual(self, plan, after=None):
         """Two-stream executor of a plan: meta = (stream id, events to wait for, event to record)."""
@@ -155,8 +159,8 @@ class FusedTrainer:
                 ev = torch.cuda.Event()
                 ev.record(st)
                 events[rec] = ev
-            if after is not None and label == after[0]:
-                after[1](events)
+            if after is not None and label in after:
+                after[label](events)
         main.wait_stream(self.side)
 
     def _step(self, ws):
@@ -172,14 +176,19 @@ class FusedTrainer:
             else:
                 def dec(events):     # decoder bucket: needs the side stream's decoder weight-grads too
                     torch.cuda.current_stream(bank.device).wait_event(events['sideT0'])
+                    self.buckets.launch(2)
+
+                def mid(events):     # deep-encoder bucket: its last weight-grad reduction ran on the side stream
+                    torch.cuda.current_stream(bank.device).wait_stream(self.side)
                     self.buckets.launch(1)
-                self._run_dual(ws.bwd, after=('wgradT_reduce0', dec))
+                self._run_dual(ws.bwd, after={self.split_label: dec, self.split_label_mid: mid})
                 self.buckets.launch(0)
                 self.buckets.finish()
         elif self.buckets is None:
             self._run(ws.bwd, stream)
         else:
-            self._run(ws.bwd, stream, after=(self.split_label, lambda: self.buckets.launch(1)))
+            self._run(ws.bwd, stream, after={self.split_label: lambda: self.buckets.launch(2),
+                                              self.split_label_mid: lambda: self.buckets.launch(1)})
             self.buckets.launch(0)
             self.buckets.finish()
         if self.event_hook is not None and (self.event_labels is None or 'adam' in self.event_labels):
