@@ -192,7 +192,7 @@ def main():
         trainer.event_labels = set(fl.keys())
         trainer.overlap = False
         for it in range(3):
-            trainer.step_cubes(raw, flow, perm[it])
+            trainer.step_cubes(raw, flow, perm[it % perm.shape[0]])
         torch.cuda.synchronize()
         trainer.overlap = True
         trainer.event_hook = None
@@ -203,7 +203,7 @@ def main():
     bufs, nbt = bank.bufs.clone(), bank.nbt.clone()          # forward(train=True) moves the BatchNorm running statistics
     f0.record()
     for it in range(fwd_n):
-        bank.set_input_cubes(raw, flow, perm[it], B)
+        bank.set_input_cubes(raw, flow, perm[it % perm.shape[0]], B)
         bank.forward(ws, True)
     f1.record()
     torch.cuda.synchronize()
