@@ -281,6 +281,30 @@ def test_bf16_stored_activation_gradients(H, Cin, Cout, B):
         for x, z in zip(res[0], res[1]):
             assert torch.equal(x, z)
         assert res[0][0].abs().max() > 0
+        # (c) every tensor bf16 (y, dA, dpool in; dy out): the 8-channel-per-lane kernel against the path above fed with fp32 tensors
+        # that hold the same rounded values -- another summation order of the partial sums, so fp32 round-off on dgamma / dbeta and
+        # at most a bf16 ulp on dy
+        yr = _r(y)
+        dz0 = torch.zeros(G, B * H * H, Cc, device='cuda')
+        part = torch.zeros(G, nblk * 2 * Cc, device='cuda')
+        g0, b0, scr = torch.zeros(G, Cc, device='cuda'), torch.zeros(G, Cc, device='cuda'), torch.zeros(G, 2 * Cc, device='cuda')
+        bp = L.BnBwdParams(G, B, H, H, Cc, 0, yr.data_ptr(), yr.stride(0), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cc,
+                           L.view(dA, Cc, 0, dA.stride(0)), dP.data_ptr() if pool else None, dP.stride(0) if pool else 0,
+                           dz0.data_ptr(), dz0.stride(0), part.data_ptr())
+        L.check(lib.vv_bn_bwd_reduce(C.byref(bp), st), 'reduce')
+        L.check(lib.vv_bn_bwd_apply(C.byref(bp), gamma.data_ptr(), Cc, g0.data_ptr(), b0.data_ptr(), Cc, scr.data_ptr(), st), 'apply')
+        y16, dA16, dP16 = _as_bf16_storage(y), _as_bf16_storage(dA), _as_bf16_storage(dP)
+        dz1 = torch.zeros(G, B * H * H, Cc, device='cuda')
+        g1, b1 = torch.zeros(G, Cc, device='cuda'), torch.zeros(G, Cc, device='cuda')
+        bp = L.BnBwdParams(G, B, H, H, Cc, L.BNBWD_DA_BF16 | L.BNBWD_Y_BF16 | L.BNBWD_DZ_BF16, y16.data_ptr(), y16.stride(0), a.data_ptr(),
+                           b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cc, L.view(dA16, Cc, 0, dA16.stride(0)),
+                           dP16.data_ptr() if pool else None, dP16.stride(0) if pool else 0, dz1.data_ptr(), dz1.stride(0), part.data_ptr())
+        L.check(lib.vv_bn_bwd_reduce(C.byref(bp), st), 'reduce16')
+        L.check(lib.vv_bn_bwd_apply(C.byref(bp), gamma.data_ptr(), Cc, g1.data_ptr(), b1.data_ptr(), Cc, scr.data_ptr(), st), 'apply16')
+        got = dz1.view(G, -1).view(torch.bfloat16)[:, :B * H * H * Cc].float().view(G, B * H * H, Cc)
+        torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b1, b0, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(got, dz0, rtol=2 ** -7, atol=1e-4)
 
 
 def _build_bf16(monkeypatch, kind='net4'):

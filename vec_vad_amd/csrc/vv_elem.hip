@@ -248,6 +248,120 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
   }
 }
 
+// The same two passes when y, dA, dpool and dy are ALL stored as bf16 (mixed precision): 8 channels = 16 bytes per lane and tensor
+// instead of 4 channels = 8 bytes, the same 256-pixel blocks and partial-sum layout.  fp32 arithmetic as above.
+struct vv_f8 { float v[8]; };
+__device__ __forceinline__ vv_f8 vv_unpack_bf16x8(const uint4 u) {
+  vv_f8 r;
+  r.v[0] = __builtin_bit_cast(float, u.x << 16); r.v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+  r.v[2] = __builtin_bit_cast(float, u.y << 16); r.v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+  r.v[4] = __builtin_bit_cast(float, u.z << 16); r.v[5] = __builtin_bit_cast(float, u.z & 0xFFFF0000u);
+  r.v[6] = __builtin_bit_cast(float, u.w << 16); r.v[7] = __builtin_bit_cast(float, u.w & 0xFFFF0000u);
+  return r;
+}
+__device__ __forceinline__ uint4 vv_pack_bf16x8(const vv_f8& f) {
+  const uint2 lo = vv_pack_bf16x4(make_float4(f.v[0], f.v[1], f.v[2], f.v[3]));
+  const uint2 hi = vv_pack_bf16x4(make_float4(f.v[4], f.v[5], f.v[6], f.v[7]));
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <bool POOL, int PASS>
+__global__ void __launch_bounds__(VV_WG)
+bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const float* __restrict__ gamma, const int64_t param_gstride,
+                const float* __restrict__ scratch) {
+  __shared__ float sh[2][VV_WG * 8];
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int C = p.C, Q8 = C >> 3, PL = VV_WG / Q8;
+  const int q = threadIdx.x % Q8, pl = threadIdx.x / Q8;
+  const int c = q * 8;
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  const unsigned short* __restrict__ yh = reinterpret_cast<const unsigned short*>(p.y + (int64_t)g * p.y_gstride);
+  unsigned short* __restrict__ dzh = reinterpret_cast<unsigned short*>(p.dz + (int64_t)g * p.dz_gstride);
+  const unsigned short* __restrict__ dAh = reinterpret_cast<const unsigned short*>(p.dA.ptr + (int64_t)g * p.dA.gstride) + p.dA.coff;
+  const int dcs = p.dA.cstride;
+  const int64_t abo = (int64_t)g * p.ab_gstride + c;
+  float a[8], b[8], m[8], iv[8], s1[8], s2[8], gk[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = p.a[abo + j]; b[j] = p.b[abo + j]; m[j] = p.mean[abo + j]; iv[j] = p.invstd[abo + j];
+    s1[j] = 0.f; s2[j] = 0.f; gk[j] = 0.f; c1[j] = 0.f; c2[j] = 0.f;
+  }
+  if constexpr (PASS == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gk[j] = gamma[(int64_t)g * param_gstride + c + j] * iv[j];
+      c1[j] = scratch[(int64_t)g * 2 * C + c + j];
+      c2[j] = scratch[(int64_t)g * 2 * C + C + c + j];
+    }
+  }
+  auto ld8 = [&](const unsigned short* q8) -> vv_f8 { return vv_unpack_bf16x8(*reinterpret_cast<const uint4*>(q8)); };
+  auto one = [&](const int64_t pix, vv_f8 d, const vv_f8& yv) {
+    vv_f8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = fmaf(a[j], yv.v[j], b[j]);
+      const float dj = z > 0.f ? d.v[j] : 0.f;
+      const float xh = (yv.v[j] - m[j]) * iv[j];
+      if constexpr (PASS == 0) { s1[j] += dj; s2[j] = fmaf(dj, xh, s2[j]); }
+      else o.v[j] = gk[j] * (dj - c1[j] - xh * c2[j]);
+    }
+    if constexpr (PASS == 1) *reinterpret_cast<uint4*>(dzh + pix * C + c) = vv_pack_bf16x8(o);
+  };
+  if constexpr (!POOL) {
+    for (int i = pl; i < 256; i += PL) {
+      const int64_t pix = (int64_t)blk * 256 + i;
+      if (pix < M) one(pix, ld8(dAh + pix * dcs + c), ld8(yh + pix * C + c));
+    }
+  } else {
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+    const int64_t MW = M >> 2;
+    const unsigned short* __restrict__ dPh = reinterpret_cast<const unsigned short*>(p.dpool + (int64_t)g * p.dpool_gstride);
+    for (int i = pl; i < 64; i += PL) {
+      const int64_t wi = (int64_t)blk * 64 + i;
+      if (wi >= MW) continue;
+      const int wx = (int)(wi % W2);
+      const int64_t t = wi / W2;
+      const int wy = (int)(t % H2);
+      const int64_t img = t / H2;
+      const int64_t p00 = (img * p.H + 2 * wy) * p.W + 2 * wx;
+      const int64_t px[4] = {p00, p00 + 1, p00 + p.W, p00 + p.W + 1};
+      vv_f8 yq[4];
+      int best[8];
+      float bv[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        yq[k] = ld8(yh + px[k] * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float zz = fmaxf(fmaf(a[j], yq[k].v[j], b[j]), 0.f);
+          if (k == 0 || zz > bv[j]) { bv[j] = zz; best[j] = k; }      // first maximum wins ties, like at::max_pool2d
+        }
+      }
+      const vv_f8 dp = ld8(dPh + wi * C + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        vv_f8 d = ld8(dAh + px[k] * dcs + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d.v[j] += best[j] == k ? dp.v[j] : 0.f;
+        one(px[k], d, yq[k]);
+      }
+    }
+  }
+  if constexpr (PASS == 1) return;
+  float* r1 = sh[0];
+  float* r2 = sh[1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { r1[pl * C + c + j] = s1[j]; r2[pl * C + c + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < PL; ++k) { t1 += r1[k * C + threadIdx.x]; t2 += r2[k * C + threadIdx.x]; }
+    float* o = p.partial + ((int64_t)(g * nblk + blk) * 2) * C + threadIdx.x;
+    o[0] = t1;
+    o[C] = t2;
+  }
+}
+
 // phase 2a: sum partials -> dbeta, dgamma, c1 = mean(dz), c2 = mean(dz*xhat)
 __global__ void __launch_bounds__(VV_WG)
 bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __restrict__ partial,
@@ -675,6 +789,12 @@ extern "C" int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t coun
   return VV_OK;
 }
 
+// every tensor of the BatchNorm backward stored as bf16, 16-byte aligned 8-channel items: the wide kernel
+static inline bool bn_all16(const vv_bnbwd_params* p) {
+  const int all = VV_BNBWD_DZ_BF16 | VV_BNBWD_DA_BF16 | VV_BNBWD_Y_BF16;
+  return (p->flags & all) == all && p->C % 8 == 0 && VV_WG % (p->C / 8) == 0 && p->dA.cstride % 8 == 0 && p->dA.coff % 8 == 0;
+}
+
 extern "C" int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C) {
   (void)C;
   const int64_t M = (int64_t)B * H * W;
@@ -685,7 +805,12 @@ extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
   if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial) return VV_ERR_BAD_ARG;
   if (p->C % 4 || p->C > 256 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
   const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
-  if (p->dpool)
+  if (bn_all16(p)) {
+    if (p->dpool)
+      VV_LAUNCH((bn_bwd16_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
+    else
+      VV_LAUNCH((bn_bwd16_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
+  } else if (p->dpool)
     VV_LAUNCH((bn_bwd_reduce_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
   else
     VV_LAUNCH((bn_bwd_reduce_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
@@ -703,7 +828,12 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
   VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(VV_WG), 0, (hipStream_t)stream, p->C, nblk, (double)M,
             p->partial, dgamma, dbeta, grad_gstride, scratch);
   VV_CHECK_LAUNCH();
-  if (p->dpool)
+  if (bn_all16(p)) {
+    if (p->dpool)
+      VV_LAUNCH((bn_bwd16_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
+    else
+      VV_LAUNCH((bn_bwd16_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
+  } else if (p->dpool)
     VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
   else
     VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
