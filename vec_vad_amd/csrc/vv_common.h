@@ -369,6 +369,53 @@ struct VVStagerB {
     }
   }
 
+  // The same with 16-byte items (8 channels): declare the loader with NCH = (channels per chunk) / 2, so that Q = channels / 8 items
+  // per pixel; c0 and cmax are still in channels.
+  float4 sa2, sb2;
+  __device__ __forceinline__ void prefetch16w(const VVSrc& s, int img0, int y0, int x0, int c0, int tid, int cmax = 1 << 30) {
+    const int q = tid % Q;
+    const int c = c0 + q * 8;
+    valid = 0;
+    act = (s.mode == VV_IN_ACT) || (s.mode == VV_IN_CAT && c < s.csplit);
+    if (act && c < cmax) {
+      sa = *reinterpret_cast<const float4*>(s.a + c); sa2 = *reinterpret_cast<const float4*>(s.a + c + 4);
+      sb = *reinterpret_cast<const float4*>(s.b + c); sb2 = *reinterpret_cast<const float4*>(s.b + c + 4);
+    }
+    const bool second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit)) != 0;
+    const float* base = second ? s.p1 : s.p0;
+    const int co = second ? s.co1 - s.csplit : s.co0;
+    const int cs = second ? s.cs1 : s.cs0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    const int tile = (img0 * s.SH + y0) * s.SW + x0;
+    const bool cok = c < cmax;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int y = y0 + hy[k];
+      const bool ok = cok && (unsigned)y < (unsigned)s.SH && (img0 + im[k]) < s.B && pix[k] >= 0;
+      const unsigned off = ok ? (unsigned)((tile + pix[k]) * cs + co + c) * 2u : OOB;
+      valid |= ok ? (1u << k) : 0u;
+      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      r[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  }
+  __device__ __forceinline__ void commit16w(float* lds, int tid) const {
+    const int q = tid % Q;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * NTH;
+      if (NITEMS % NTH == 0 || it < NITEMS) {
+        uint4 h = make_uint4(__builtin_bit_cast(unsigned, r[k].x), __builtin_bit_cast(unsigned, r[k].y),
+                             __builtin_bit_cast(unsigned, r[k].z), __builtin_bit_cast(unsigned, r[k].w));
+        if (act && ((valid >> k) & 1u)) {
+          const uint2 lo = vv_pack_bf16x4(vv_act4(vv_unpack_bf16x4(make_uint2(h.x, h.y)), sa, sb));
+          const uint2 hi = vv_pack_bf16x4(vv_act4(vv_unpack_bf16x4(make_uint2(h.z, h.w)), sa2, sb2));
+          h = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        *reinterpret_cast<uint4*>(lds + (it / Q) * S + q * 4) = h;
+      }
+    }
+  }
+
   // bf16 operand path: the same items, rounded to nearest-even bf16 (v_cvt_pk_bf16_f32) after the deferred BatchNorm+ReLU and
   // written as 8 B (4 channels) per item; S is still the pixel stride in floats (4 B units).
   __device__ __forceinline__ void commit_bf16(float* lds, int tid) const {

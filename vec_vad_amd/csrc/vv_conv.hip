@@ -100,7 +100,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 
   // ---- software pipeline over the K chunks: activation tile (BatchNorm+ReLU deferred to commit) and weight panel of
   // chunk c+1 are in flight in registers while chunk c runs on the matrix cores; nothing but LDS is read in the MFMA loop.
-  VVStagerB<NI, HH, HW, S, CK> stA;
+  VVStagerB<NI, HH, HW, S, (S16 == 2 ? CK / 2 : CK)> stA;      // all-bf16 sources: 16-byte items of 8 channels
   stA.init(s, ox0, tid);            // every tile spans full rows (TW == W): the column origin is tile independent
   unsigned boff[NBT];
   float4 rb[NBT];
@@ -117,7 +117,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   auto issue = [&](const int c0) {
-    if constexpr (S16 == 2) stA.prefetch16x(s, img0, oy0, ox0, c0, tid);
+    if constexpr (S16 == 2) stA.prefetch16w(s, img0, oy0, ox0, c0, tid);
     else if constexpr (S16 == 1) stA.prefetch16(s, img0, oy0, ox0, c0, tid);
     else stA.prefetch(s, img0, oy0, ox0, c0, tid);
     const int so = (BF ? (c0 >> 4) : (c0 >> 3)) * 2 * Cout * 16;
@@ -128,7 +128,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
   };
   auto commit = [&]() {
-    if constexpr (S16 == 2) stA.commit16(lds, tid);
+    if constexpr (S16 == 2) stA.commit16w(lds, tid);
     else if constexpr (S16 == 1) stA.commit_raw16(lds, tid);
     else if constexpr (BF) stA.commit_bf16(lds, tid);
     else stA.commit(lds, tid);
