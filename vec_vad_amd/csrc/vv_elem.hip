@@ -52,23 +52,25 @@ pack_weights_kernel(const vv_pack_entry* __restrict__ table, const float* __rest
   }
 }
 
-// Sum of the per-tile partials [n][2][C] of one channel over tiles part, part+8, ...: four independent fp64 accumulators so
-// that the (L2-resident, latency-bound) loads of consecutive tiles overlap.  Fixed order -> deterministic.
+// Sum of the per-tile partials [n][2][C] of one channel over tiles part, part+NP, ...: four independent fp64 accumulators so
+// that the (L2-resident, latency-bound) loads of consecutive tiles overlap.  Fixed order -> deterministic.  The callers run
+// 32 channels x NP = 32 partial-sum lanes per block (1024 threads): these launches are pure latency, up to 1024 tiles deep.
+constexpr int VV_NP = 32;
 __device__ __forceinline__ void vv_sum_partials(const float* __restrict__ st, const int n, const int C, const int part,
                                                 double& s1, double& s2) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
   const int64_t step = (int64_t)2 * C;
   int t = part;
-  for (; t + 24 < n; t += 32) {
+  for (; t + 3 * VV_NP < n; t += 4 * VV_NP) {
     const float* q = st + t * step;
-    const float x0 = q[0], y0 = q[C], x1 = q[8 * step], y1 = q[8 * step + C];
-    const float x2 = q[16 * step], y2 = q[16 * step + C], x3 = q[24 * step], y3 = q[24 * step + C];
+    const float x0 = q[0], y0 = q[C], x1 = q[VV_NP * step], y1 = q[VV_NP * step + C];
+    const float x2 = q[2 * VV_NP * step], y2 = q[2 * VV_NP * step + C], x3 = q[3 * VV_NP * step], y3 = q[3 * VV_NP * step + C];
     a0 += (double)x0; b0 += (double)y0;
     a1 += (double)x1; b1 += (double)y1;
     a2 += (double)x2; b2 += (double)y2;
     a3 += (double)x3; b3 += (double)y3;
   }
-  for (; t < n; t += 8) {
+  for (; t < n; t += VV_NP) {
     a0 += (double)st[t * step];
     b0 += (double)st[t * step + C];
   }
@@ -77,15 +79,15 @@ __device__ __forceinline__ void vv_sum_partials(const float* __restrict__ st, co
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalise
-// grid (C/32, G); 256 threads = 32 channels x 8 partial-sum lanes; fp64 accumulation of the fp32 tile partials.
-__global__ void __launch_bounds__(VV_WG)
+// grid (C/32, G); 1024 threads = 32 channels x 32 partial-sum lanes; fp64 accumulation of the fp32 tile partials.
+__global__ void __launch_bounds__(32 * VV_NP)
 bn_finalize_kernel(const int C, const int ntiles, const double count, const int train, const float momentum,
                    const float eps, const float* __restrict__ stats, const int64_t stats_gstride,
                    const float* __restrict__ gamma, const float* __restrict__ beta, const int64_t param_gstride,
                    float* __restrict__ rmean, float* __restrict__ rvar, const int64_t buf_gstride,
                    float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean, float* __restrict__ invstd,
                    const int64_t ab_gstride) {
-  __shared__ double sh[2][8][32];
+  __shared__ double sh[2][VV_NP][32];
   const int g = blockIdx.y;
   const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -107,7 +109,7 @@ bn_finalize_kernel(const int C, const int ntiles, const double count, const int 
   if (train) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+    for (int k = 0; k < VV_NP; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
     mu = s1 / count;
     var = s2 / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -363,11 +365,11 @@ bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const float* __restrict
 }
 
 // phase 2a: sum partials -> dbeta, dgamma, c1 = mean(dz), c2 = mean(dz*xhat)
-__global__ void __launch_bounds__(VV_WG)
+__global__ void __launch_bounds__(32 * VV_NP)
 bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __restrict__ partial,
                   float* __restrict__ dgamma, float* __restrict__ dbeta, const int64_t grad_gstride,
                   float* __restrict__ scratch) {
-  __shared__ double sh[2][8][32];
+  __shared__ double sh[2][VV_NP][32];
   const int g = blockIdx.y;
   const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -382,7 +384,7 @@ bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __re
   if (part != 0 || c >= C) return;
   s1 = 0.0; s2 = 0.0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+  for (int k = 0; k < VV_NP; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
   dbeta[(int64_t)g * grad_gstride + c] = (float)s1;
   dgamma[(int64_t)g * grad_gstride + c] = (float)s2;
   scratch[(int64_t)g * 2 * C + c] = (float)(s1 / M);
@@ -605,10 +607,10 @@ bias_grad_stage2(const int C, const int nblk, const float* __restrict__ scratch,
 // Bias gradient of the transposed conv from the per-tile column sums the data-gradient kernel of the consuming (concat) layer
 // leaves in its `stats` partials: db[j] = sum over pixels of d(cat)[pixel][coff + j] = sum over tiles of partial[tile][0][coff + j].
 // Same fixed-order fp64 reduction as the BatchNorm partials.
-__global__ void __launch_bounds__(VV_WG)
+__global__ void __launch_bounds__(32 * VV_NP)
 bias_from_partials_kernel(const int C, const int ntiles, const int coff, const int n, const float* __restrict__ partial,
                           const int64_t partial_gstride, float* __restrict__ db, const int64_t grad_gstride) {
-  __shared__ double sh[8][32];
+  __shared__ double sh[VV_NP][32];
   const int g = blockIdx.y;
   const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cl;
@@ -619,7 +621,7 @@ bias_from_partials_kernel(const int C, const int ntiles, const int coff, const i
   if (part != 0 || j >= n) return;
   s1 = 0.0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s1 += sh[k][cl];
+  for (int k = 0; k < VV_NP; ++k) s1 += sh[k][cl];
   db[(int64_t)g * grad_gstride + j] = (float)s1;
 }
 
@@ -782,7 +784,7 @@ extern "C" int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t coun
                               int64_t ab_gstride, vv_stream stream) {
   if (!gamma || !beta || !running_mean || !running_var || !a || !b || !mean || !invstd) return VV_ERR_BAD_ARG;
   if (train && !stats) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, ntiles,
+  VV_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32, G), dim3(32 * VV_NP), 0, (hipStream_t)stream, C, ntiles,
                      (double)count, train, momentum, eps, stats, stats_gstride, gamma, beta, param_gstride,
                      running_mean, running_var, buf_gstride, a, b, mean, invstd, ab_gstride);
   VV_CHECK_LAUNCH();
@@ -825,7 +827,7 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
   const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B : vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   const int nblk_apply = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   const int64_t M = (int64_t)p->B * p->H * p->W;
-  VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(VV_WG), 0, (hipStream_t)stream, p->C, nblk, (double)M,
+  VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(32 * VV_NP), 0, (hipStream_t)stream, p->C, nblk, (double)M,
             p->partial, dgamma, dbeta, grad_gstride, scratch);
   VV_CHECK_LAUNCH();
   if (bn_all16(p)) {
@@ -891,7 +893,7 @@ extern "C" int vv_bias_grad(int32_t G, int64_t M, int32_t C, const float* dy, in
 extern "C" int vv_bias_from_partials(int32_t G, int32_t C, int32_t ntiles, int32_t coff, int32_t n, const float* partial,
                                      int64_t partial_gstride, float* db, int64_t grad_gstride, vv_stream stream) {
   if (!partial || !db || n <= 0 || coff < 0 || coff + n > C || ntiles <= 0) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(bias_from_partials_kernel, dim3((n + 31) / 32, G), dim3(VV_WG), 0, (hipStream_t)stream, C, ntiles, coff, n, partial,
+  VV_LAUNCH(bias_from_partials_kernel, dim3((n + 31) / 32, G), dim3(32 * VV_NP), 0, (hipStream_t)stream, C, ntiles, coff, n, partial,
             partial_gstride, db, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
