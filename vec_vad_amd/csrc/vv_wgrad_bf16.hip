@@ -4,15 +4,18 @@
 // K values (= 8 pixels) of ONE channel, while the tensors are NHWC (channels contiguous).  Instead of transposing through
 // LDS, the staged tiles stay pixel-major ([pixel][32 channels] bf16, 72 B pixel stride -- the forward kernel's layout, written
 // by the same register-staged loader with the producer's BatchNorm+ReLU applied on the way in) and every lane gathers its 8
-// pixels with ds_read_u16 (lane&31 = channel, so a wave reads 64 contiguous bytes per pixel, lanes 32-63 eight pixels further:
-// conflict free).  The three column-shifted operands of one input row share 10 reads; the three row shifts are a sliding
+// pixels as aligned dwords (lane&31 = channel: two neighbouring lanes share a dword = broadcast, a wave reads 64 contiguous bytes
+// per pixel, lanes 32-63 eight pixels further = the other banks) and picks its half while packing pixel pairs (v_perm_b32 with a
+// per-lane selector).  The three column-shifted operands of one input row share 10 reads; the three row shifts are a sliding
 // window over the rows a wave walks down: 10 + 8 LDS reads and 16 packs per 9 MFMAs.
 //
-// The matrix work is 1/16 of the fp32 instruction's, so this kernel is bound by HBM and its first concern is not to re-read:
+// The matrix work is 1/16 of the fp32 instruction's, so this kernel is bound by memory and its first concern is not to re-read:
 // one workgroup stages up to 64 input channels x 64 output channels per pixel tile (each tensor crosses HBM once when the
 // layer has <= 64 channels) and its four waves own the (ci-block, co-block) pairs -- or split the pixels when the layer has
-// fewer blocks -- so every wave keeps its own 9 x (32 x 32) accumulators and writes its own slab: no cross-wave reduction.
+// fewer blocks, and are then summed through LDS in wave order -- so every wave keeps its own 9 x (32 x 32) accumulators.
 // Slabs leave through vv_wgrad_reduce like those of the fp32 kernels (fixed order: bitwise reproducible).
+// DY16 / A16 (compile-time): dy / the layer input are bf16 tensors in HBM (what the mixed-precision bank stores) -- 8-byte items,
+// copied (dy, plain inputs) or unpacked -> BatchNorm+ReLU -> repacked (pre-BN inputs) on their way into LDS.
 //
 // Replaces the autograd weight gradient of nn.Conv2d(k3, p1) (model/unet.py:10,13; cuDNN in the reference) under
 // torch.autocast(bfloat16)-style operand rounding.
