@@ -411,6 +411,39 @@ def test_bf16_dy_storage_is_bitwise_neutral(monkeypatch):
     assert torch.equal(grads[0], grads[1])
 
 
+def test_bf16_odd_batch_sizes(monkeypatch):
+    """ragged batches in the mixed mode (images per tile do not divide B on any level; B = 1 in eval mode as test.py scores a
+    single cube): losses / scores against the mixed oracle, rel 5e-3 (2e-2 for B = 2: BatchNorm over two cubes at 4x4 amplifies
+    the rounding-boundary steps)."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    spec = O.bank_spec('net4')
+    for B in (2, 7, 17):
+        net, sd, tot_of = _build_bf16(monkeypatch)
+        raw, flow = O.seeded_cubes(B, 1, 11)
+        x, x_of = O.cubes_to_inputs(raw, flow)
+        net.train()
+        tr = FusedTrainer(net)
+        ws = tr.step_nchw(x.cuda(), x_of.cuda())
+        l_raw, l_of = (float(v) for v in tr.losses(ws))
+        monkeypatch.setattr(O, 'MIXED', O.MIXED_BF16)
+        lr, lo, _ = O.train_step(sd, spec, x, x_of, O.AdamState(O.param_names(sd)))
+        monkeypatch.setattr(O, 'MIXED', None)
+        tol = 2e-2 if B == 2 else 5e-3
+        assert abs(l_raw - lr) <= tol * lr and abs(l_of - lo) <= tol * lo, (B, l_raw, lr, l_of, lo)
+        assert torch.isfinite(tr.bank.params).all()
+    net, sd, tot_of = _build_bf16(monkeypatch)
+    net.eval()
+    raw, flow = O.seeded_cubes(1, 1, 12)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    r, o = FusedTrainer(net).score_nchw(x.cuda(), x_of.cuda())
+    monkeypatch.setattr(O, 'MIXED', O.MIXED_BF16)
+    rs, os_ = O.score_pass(sd, spec, x, x_of, 1)
+    monkeypatch.setattr(O, 'MIXED', None)
+    np.testing.assert_allclose(r.cpu().numpy(), rs, rtol=1e-2)
+    np.testing.assert_allclose(o.cpu().numpy(), os_, rtol=1e-2)
+
+
 def test_bf16_scores_and_auc_close_to_fp32(monkeypatch):
     """Config 4's bar: the bf16 path is judged on AUROC.  Same weights, same cubes, eval mode: per-cube
     scores of the two precisions within 10 % of each other after 40 training steps each (observed: 1 cube of 96 beyond 5 %), and the AUROC of a labelled cube set
