@@ -551,13 +551,29 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
   }
 }
 
-__global__ void __launch_bounds__(VV_WG)
+// grid (G); 1056 -> 1024 threads: 132 outputs x 7 partial-sum lanes (+ tail), fixed order, fp64
+__global__ void __launch_bounds__(1024)
 outconv_bwd_reduce_kernel(const int C, const int nblk, const float* __restrict__ partial, const int* __restrict__ oc,
                           float* __restrict__ dW, float* __restrict__ db, const int64_t grad_gstride) {
+  constexpr int NPL = 7;                       // 132 * 7 = 924 threads carry a partial sum
+  __shared__ double sh[NPL][132];
   const int g = blockIdx.x, tid = threadIdx.x;
+  const int e = tid % 132, part = tid / 132;
+  if (part < NPL) {
+    double s0 = 0.0, s1 = 0.0;
+    int k = part;
+    for (; k + NPL < nblk; k += 2 * NPL) {
+      s0 += (double)partial[((int64_t)g * nblk + k) * 132 + e];
+      s1 += (double)partial[((int64_t)g * nblk + k + NPL) * 132 + e];
+    }
+    if (k < nblk) s0 += (double)partial[((int64_t)g * nblk + k) * 132 + e];
+    sh[part][e] = s0 + s1;
+  }
+  __syncthreads();
   if (tid >= 132) return;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)partial[((int64_t)g * nblk + k) * 132 + tid];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) s += sh[k][tid];
   const int n = oc[g];
   if (tid < 128) {
     const int co = tid >> 5, cc = tid & 31;
@@ -871,7 +887,7 @@ extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const
 extern "C" int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
                                      float* dW, float* db, int64_t grad_gstride, vv_stream stream) {
   if (!partial || !oc || !dW || !db) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(outconv_bwd_reduce_kernel, dim3(G), dim3(VV_WG), 0, (hipStream_t)stream, C, nblk, partial, oc, dW,
+  VV_LAUNCH(outconv_bwd_reduce_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, C, nblk, partial, oc, dW,
                      db, grad_gstride);
   VV_CHECK_LAUNCH();
   return VV_OK;
