@@ -450,7 +450,6 @@ def test_bf16_scores_and_auc_close_to_fp32(monkeypatch):
     within 1e-2."""
     from oracle import unet_oracle as O
     from vec_vad_amd.trainer import FusedTrainer
-    from vec_vad_amd import scoring
     from test_gpu_unet import _build
     n = 96
     raw, flow = O.seeded_cubes(n, 1, 5)
