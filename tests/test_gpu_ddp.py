@@ -11,8 +11,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, precision='fp32'):
     import torch.distributed as dist
+    os.environ['VV_PRECISION'] = precision
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -96,3 +97,30 @@ def test_two_rank_step_matches_dataparallel_semantics():
             if k.endswith('running_mean') or k.endswith('running_var'):
                 # running statistics sit downstream of those Adam sign flips (a flipped weight moves by 2*lr = 2e-3)
                 assert torch.allclose(res[r][k], sds[r][k], rtol=5e-3, atol=1.5e-3), (r, k)
+
+
+def test_two_rank_step_mixed_precision_ranks_agree():
+    """The same two-rank schedule in mixed precision (`precision = bf16`): the gradient exchange is fp32 either way, so both
+    ranks must end with bit-identical, finite parameters that moved away from the initial ones, and per-rank BatchNorm statistics."""
+    import torch.multiprocessing as mp
+    from oracle import unet_oracle as O
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, 'bf16')) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(120)
+    sd0 = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
+    names = O.param_names(sd0)
+    moved = 0.0
+    for k in names:
+        a, b = np.asarray(res[0][k]), np.asarray(res[1][k])
+        assert np.array_equal(a, b), k
+        assert np.isfinite(a).all(), k
+        moved = max(moved, float(np.abs(a - sd0[k].numpy()).max()))
+    assert 5e-4 < moved < 1e-2                      # two Adam steps of lr = 1e-3
+    rm = [k for k in res[0] if k.endswith('running_mean')]
+    assert any(not np.array_equal(np.asarray(res[0][k]), np.asarray(res[1][k])) for k in rm)      # per-rank statistics
