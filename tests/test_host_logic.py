@@ -235,6 +235,10 @@ def test_read_config_accepts_both_layouts(tmp_path):
     assert (c['dataset_name'], c['mode_fg'], c['modality'], c['method']) == ('UCSDped2', 'obj_det_with_motion', 'raw2flow', 'SelfComplete')
     assert (c['h_block'], c['w_block'], c['tot_frame_num'], c['tot_of_num'], c['rawRange']) == (1, 1, 5, 5, None)
     assert c['cp'].getint('ShanghaiTech', 'saveSegNum') == 40000 and c['cp'].getint('avenue', 'patch_size') == 32
+    assert c['precision'] == 'fp32'                     # [mi355x] precision: the shipped default is the reference's arithmetic
+    mixed = tmp_path / 'mixed.cfg'
+    mixed.write_text(open(os.path.join(root, 'config.cfg')).read().replace('precision = fp32', 'precision = BF16'))
+    assert T.read_config(str(mixed))['precision'] == 'bf16'
     flat = '''[shared_parameters]
 dataset_name = avenue
 raw_dataset_dir = raw_datasets
