@@ -25,10 +25,13 @@ extern "C" {
 
 typedef void* vv_stream; /* hipStream_t */
 
+/* Every entry point returns an int: 0 on success, otherwise (status & 0xff) is one of the codes below and, for VV_ERR_LAUNCH,
+ * (status >> 8) is the hipError_t the runtime reported -- the whole error travels in the return value, the library keeps no
+ * last-error variable or any other mutable state between calls.  vv_status_string() renders a returned value as text. */
 enum vv_status {
   VV_OK = 0,
   VV_ERR_BAD_ARG = 1,      /* unsupported shape / null pointer */
-  VV_ERR_LAUNCH = 2,       /* hipGetLastError() != hipSuccess after the launch */
+  VV_ERR_LAUNCH = 2,       /* hipGetLastError() != hipSuccess after the launch; the hipError_t sits in bits 8.. of the return */
   VV_ERR_UNSUPPORTED = 3
 };
 
@@ -350,10 +353,29 @@ int vv_deconv4x4_c2(const float* src, int32_t src_cstride, int32_t B, int32_t H,
 /* w: Conv2d [N][K][R][R] (transposed = 0) or ConvTranspose2d [K][N][4][4] (transposed = 1); taps = R*R */
 int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32_t KP, int32_t N, int32_t NP,
                    int32_t transposed, vv_stream stream);
-/* nn.Upsample(scale_factor=4, mode='bilinear' (align_corners=False) | 'nearest') on NCHW planes, times `scale`
- * (flownet2.py:28,34,43-44,76,90,105,122) */
+/* nn.Upsample(scale_factor=4) on NCHW planes, times `scale` (flownet2.py:28,34,43-44,76,90,105,122).
+ * bilinear: 0 = 'nearest', 1 = 'bilinear' with align_corners=False (torch >= 0.4), 2 = 'bilinear' with align_corners=True
+ * (what 'bilinear' meant under the PyTorch 0.3 the reference's README pins for the flow extraction) */
 int vv_upsample4(const float* src, float* dst, int32_t BC, int32_t H, int32_t W, int32_t bilinear, float scale,
                  vv_stream stream);
+
+/* ---- FlowNet2 plumbing between the sub-networks (FlowNet2_src/models/flownet2.py:65-136), NHWC, no temporaries ----
+ * vv_flownet_prep: inputs [B,3,2,H,W] fp32 (0..rgb_max) -> rgb_mean over (frame, H, W) per image and colour (:66-67),
+ *   x = (inputs - rgb_mean) / rgb_max (:69), x6 [B,H,W,8] = cat(x1, x2) + 2 zero channels (:70-72), img0 / img1 [B,H,W,4] =
+ *   the two frames + 1 zero channel (FlowNetC's siamese stem).  workspace: vv_flownet_prep_workspace_bytes(B) bytes, 16-byte
+ *   aligned like every tensor here.
+ * vv_warp_pack12: flow = Upsample x4 (mode as vv_upsample4's `bilinear`) of flow2 [B,H/4,W/4,flow_cstride] (channels 0,1)
+ *   times `scale` (:76,90); out12 [B,H,W,12] = cat(x6[0:6], Resample2d(img1, flow), flow / div_flow, ChannelNorm(x1 - warped))
+ *   (:79-86, 93-100).
+ * vv_fusion_pack11: s2 = nearest x4 of s2_flow2 * div_flow (:105), sd = nearest x4 of sd_flow2 / div_flow (:122);
+ *   out12 [B,H,W,12] = cat(x1, sd, s2, |sd|, |s2|, |x1 - warp(img1, sd)|, |x1 - warp(img1, s2)|) + 1 zero channel (:132-136). */
+int64_t vv_flownet_prep_workspace_bytes(int32_t B);
+int vv_flownet_prep(const float* inputs, int32_t B, int32_t H, int32_t W, float rgb_max, void* workspace,
+                    int64_t workspace_bytes, float* x6, float* img0, float* img1, vv_stream stream);
+int vv_warp_pack12(const float* x6, const float* img1, const float* flow2, int32_t flow_cstride, int32_t B, int32_t H,
+                   int32_t W, int32_t mode, float scale, float div_flow, float* out12, vv_stream stream);
+int vv_fusion_pack11(const float* x6, const float* img1, const float* s2_flow2, int32_t s2_cstride, const float* sd_flow2,
+                     int32_t sd_cstride, int32_t B, int32_t H, int32_t W, float div_flow, float* out12, vv_stream stream);
 
 /* ---- cube extraction (vad_datasets.py:70-93 get_foreground, calc_optical_flow.py:46-59,82) ----
  * One launch crops n boxes out of T decoded frames and resizes each crop with cv2.resize's default INTER_LINEAR
@@ -378,9 +400,9 @@ int vv_roc_auc_counts(const double* scores, const uint8_t* labels, int32_t n, ui
 
 /* library self-description */
 const char* vv_version(void);
-/* text of the HIP error behind the last VV_ERR_LAUNCH returned on this thread ("" if none); never printed by the library */
-const char* vv_last_hip_error(void);
-void vv_set_last_hip_error(int code);
+/* text for a value returned by any entry point (a pure function of its argument: pointer to a static string; for
+ * VV_ERR_LAUNCH the HIP runtime's own text for the hipError_t carried in bits 8..); never printed by the library */
+const char* vv_status_string(int status);
 int vv_device_arch_ok(void); /* 1 when the current device is gfx950 */
 
 #ifdef __cplusplus

@@ -124,13 +124,15 @@ def _cnorm(x):
 
 
 @torch.no_grad()
-def flownet2_forward(sd, inputs, rgb_max=255.0, div_flow=20.0, return_parts=False):
-    """inputs [B,3,2,H,W] float32 0..255 -> flow [B,2,H,W]  (flownet2.py:65-149; nn.Upsample bilinear = align_corners False)."""
+def flownet2_forward(sd, inputs, rgb_max=255.0, div_flow=20.0, return_parts=False, align_corners=False):
+    """inputs [B,3,2,H,W] float32 0..255 -> flow [B,2,H,W]  (flownet2.py:65-149).  ``nn.Upsample(scale_factor=4,
+    mode='bilinear')`` (flownet2.py:28,34) is align_corners=False under the torch that imports the reference today (the pinned
+    golden) and was align_corners=True under the authors' PyTorch 0.3 (README.md:10,64): ``align_corners`` selects which."""
     rgb_mean = inputs.contiguous().view(inputs.size()[:2] + (-1,)).mean(dim=-1).view(inputs.size()[:2] + (1, 1, 1))
     x = (inputs - rgb_mean) / rgb_max
     x1, x2 = x[:, :, 0], x[:, :, 1]
     x = torch.cat((x1, x2), 1)
-    up_b = lambda t: F.interpolate(t, scale_factor=4, mode='bilinear', align_corners=False)
+    up_b = lambda t: F.interpolate(t, scale_factor=4, mode='bilinear', align_corners=bool(align_corners))
     up_n = lambda t: F.interpolate(t, scale_factor=4, mode='nearest')
     c2 = flownetc(sd, 'flownetc.', x)
     c_flow = up_b(c2 * div_flow)

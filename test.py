@@ -44,31 +44,38 @@ def load_model(net, state_dict, device):
 
 def score_cubes_device(trainer, cube_list, flow_list, score_batch):
     """cube_list / flow_list: per-frame arrays [n_i,5,32,32,3] uint8 / [n_i,(Tf,)32,32,2] fp32 (n_i may be 0).
-    Scores as many frames per launch as fit in ``score_batch`` and returns the DEVICE tensors (raw [n], of [n] | None) of
-    all cubes in frame order -- they feed vv_frame_scores without visiting the host."""
+    All cubes are uploaded ONCE and scored in launches of exactly ``score_batch`` cubes (the tail launch re-scores the last cube
+    as padding: eval-mode scores do not depend on the batch), so one workspace and one launch plan serve the whole test set.
+    Returns the DEVICE tensors (raw [n], of [n] | None) of all cubes in frame order -- they feed vv_frame_scores without
+    visiting the host."""
     dev = trainer.bank.device
-    rs, os_ = [], []
-    i = 0
-    while i < len(cube_list):
-        j, tot = i, 0
-        while j < len(cube_list) and (tot == 0 or tot + len(cube_list[j]) <= score_batch):
-            tot += len(cube_list[j])
-            j += 1
-        if tot:
-            raw = np.concatenate([np.asarray(cube_list[k]) for k in range(i, j) if len(cube_list[k])])
-            flow = np.concatenate([np.asarray(flow_list[k], dtype=np.float32) for k in range(i, j) if len(cube_list[k])])
-            if raw.ndim == 4:
-                raw = raw[:, None]
-            if flow.ndim == 4:
-                flow = flow[:, None]
-            r, o = trainer.score_cubes(torch.from_numpy(np.ascontiguousarray(raw)).to(dev),
-                                       torch.from_numpy(np.ascontiguousarray(flow)).to(dev), None, raw.shape[0])
-            rs.append(r.clone())
-            os_.append(o.clone() if o is not None else None)
-        i = j
-    if not rs:
+    keep = [k for k in range(len(cube_list)) if len(cube_list[k])]
+    if not keep:
         return torch.zeros(0, device=dev), None
-    return torch.cat(rs), (torch.cat(os_) if os_[0] is not None else None)
+    raw = np.concatenate([np.asarray(cube_list[k]) for k in keep])
+    flow = np.concatenate([np.asarray(flow_list[k], dtype=np.float32) for k in keep])
+    if raw.dtype != np.uint8:
+        raise TypeError('foreground cubes must be uint8 (the -raw.npy files of train.py:218-222), got %s' % raw.dtype)
+    if raw.ndim == 4:
+        raw = raw[:, None]
+    if flow.ndim == 4:
+        flow = flow[:, None]
+    n = raw.shape[0]
+    rawd = torch.from_numpy(np.ascontiguousarray(raw)).to(dev)
+    flowd = torch.from_numpy(np.ascontiguousarray(flow)).to(dev)
+    B = int(min(score_batch, n)) if n < score_batch else int(score_batch)
+    r_all = torch.empty(n, device=dev)
+    o_all = None
+    for s0 in range(0, n, B):
+        idx = torch.arange(s0, s0 + B, device=dev).clamp_(max=n - 1)
+        r, o = trainer.score_cubes(rawd, flowd, idx)
+        m = min(B, n - s0)
+        r_all[s0:s0 + m] = r[:m]
+        if o is not None:
+            if o_all is None:
+                o_all = torch.empty(n, device=dev)
+            o_all[s0:s0 + m] = o[:m]
+    return r_all, o_all
 
 
 def score_cubes_batched(trainer, cube_list, flow_list, score_batch):
@@ -105,7 +112,7 @@ def score_frames(net_set, stats_raw, stats_of, foreground_set, foreground_set2, 
     (= the maximum of the reference's painted h x w mask, test.py:350-357,391).  Only when ``result_dir`` is given are the
     masks themselves painted (on the host) and saved as ``<result_dir>/<frame>`` like the reference does."""
     n_frames = len(foreground_set)
-    frame_maps = [(-1.0 * np.ones((h, w)) * BIG) for _ in range(n_frames)] if result_dir else None
+    mask_groups = [] if result_dir else None      # per scored group: (frame -> slice, host cube scores, boxes); masks are painted one frame at a time
     fs_dev = torch.full((n_frames,), -float(BIG), dtype=torch.float64, device=device)
     hb, wb = len(foreground_set[0]), len(foreground_set[0][0])
     trainers = {}
@@ -140,22 +147,23 @@ def score_frames(net_set, stats_raw, stats_of, foreground_set, foreground_set2, 
                     stats = np.array([[0.0, 1.0, 0.0, 1.0]])
                     cube_stat = np.full(n, -1, np.int32)
                 scoring.frame_scores(r, o, off, cube_stat, stats, scoring.box_paints(boxes, h, w), w_raw, w_of, out=fs_dev)
-                if frame_maps is not None:
-                    rh = r.cpu().numpy().astype(np.float32)
-                    oh = o.cpu().numpy().astype(np.float32) if o is not None else None
-                    for f in frames:
-                        sl = slice(off[f], off[f + 1])
-                        if len(models) > 0:
-                            sc = w_raw * ((rh[sl] - stats[0, 0]) / stats[0, 1])
-                            if oh is not None:
-                                sc = sc + w_of * ((oh[sl] - stats[0, 2]) / stats[0, 3])
-                        else:
-                            sc = np.ones(counts[f]) * BIG
-                        np.maximum(frame_maps[f], paint_frame(sc, boxes[sl], h, w), out=frame_maps[f])
+                if mask_groups is not None:
+                    if len(models) > 0:
+                        sc = w_raw * ((r.cpu().numpy().astype(np.float32) - stats[0, 0]) / stats[0, 1])
+                        if o is not None:
+                            sc = sc + w_of * ((o.cpu().numpy().astype(np.float32) - stats[0, 2]) / stats[0, 3])
+                    else:
+                        sc = np.ones(n) * BIG
+                    mask_groups.append((off, sc, boxes))           # off is indexed by frame: cubes of frame f = [off[f], off[f+1])
     if result_dir:
         os.makedirs(result_dir, exist_ok=True)
-        for f in range(n_frames):
-            torch.save(frame_maps[f], os.path.join(result_dir, '{}'.format(f)))
+        for f in range(n_frames):       # one h x w float64 mask alive at a time, like the reference (test.py:350-358)
+            fmap = -1.0 * np.ones((h, w)) * BIG
+            for off, sc, boxes in mask_groups:
+                if off[f + 1] > off[f]:
+                    sl = slice(off[f], off[f + 1])
+                    np.maximum(fmap, paint_frame(sc[sl], boxes[sl], h, w), out=fmap)
+            torch.save(fmap, os.path.join(result_dir, '{}'.format(f)))
     return fs_dev if return_device else fs_dev.cpu().numpy()
 
 

@@ -124,3 +124,103 @@ def test_two_rank_step_mixed_precision_ranks_agree():
     assert 5e-4 < moved < 1e-2                      # two Adam steps of lr = 1e-3
     rm = [k for k in res[0] if k.endswith('running_mean')]
     assert any(not np.array_equal(np.asarray(res[0][k]), np.asarray(res[1][k])) for k in rm)      # per-rank statistics
+
+
+def _worker_default_init(rank, world, port, q):
+    """Ranks build the net from DIFFERENT unseeded-style initialisers (what `torchrun train.py` does): the trainer must
+    broadcast rank 0's parameters / buffers before the first step (train.py:217)."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import unet_oracle as O
+    from model.unet import SelfCompleteNet4
+    from vec_vad_amd.trainer import FusedTrainer, shard_batch
+    torch.cuda.set_device(0)
+    torch.manual_seed(1000 + rank)
+    net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=True,
+                           padding=False).cuda().train()
+    before = net.bank().params.clone()
+    tr = FusedTrainer(net, process_group=dist.group.WORLD)
+    after_init = tr.bank.params.clone()
+    raw, flow = O.seeded_cubes(8, 1, 21)
+    idx = shard_batch(torch.arange(8, device='cuda'), rank, world)
+    for _ in range(2):
+        tr.step_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), idx)
+    tr.sync_from_rank0(params=False)          # what train.py does before the eval-mode scoring pass / the save
+    torch.cuda.synchronize()
+    q.put((rank, before.cpu().numpy(), after_init.cpu().numpy(), tr.bank.params.cpu().numpy(), tr.bank.bufs.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_default_init_is_broadcast_from_rank0():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    ps = [ctx.Process(target=_worker_default_init, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in ps)}
+    for p in ps:
+        p.join(120)
+    assert not np.array_equal(res[0][0], res[1][0])              # the two ranks really started from different weights
+    assert np.array_equal(res[0][1], res[0][0])                  # rank 0 keeps its own
+    assert np.array_equal(res[1][1], res[0][0])                  # rank 1 took rank 0's
+    assert np.array_equal(res[0][2], res[1][2])                  # ... and they stay bit-identical through the steps
+    assert not np.array_equal(res[0][2], res[0][1])
+    assert np.array_equal(res[0][3], res[1][3])                  # running statistics: rank 0's after sync_from_rank0
+
+
+def _worker_rccl_world1(port, q):
+    """The real backend ('nccl' = RCCL) in a one-rank group on the one GPU of the box: init_process_group(device_id=...),
+    GradBuckets staging + all_reduce on device tensors on the communication stream, 1/world in Adam."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import unet_oracle as O
+    from model.unet import SelfCompleteNet4
+    from vec_vad_amd.trainer import FusedTrainer
+    raw, flow = O.seeded_cubes(12, 1, 33)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    outs = []
+    for group, overlap in ((None, False), (dist.group.WORLD, False), (dist.group.WORLD, True)):
+        net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=True,
+                               padding=False)
+        net.load_state_dict(O.seeded_state_dict('net4', nf=32, padding=False, seed=0))
+        net = net.cuda().train()
+        tr = FusedTrainer(net, process_group=group, overlap=overlap, always_bucket=True)
+        assert (tr.buckets is not None) == (group is not None)
+        if tr.buckets is not None:
+            tr.buckets.timing = []
+        for _ in range(2):
+            tr.step_cubes(rawd, flowd, torch.arange(12, device='cuda'))
+        torch.cuda.synchronize()
+        n_coll = len(tr.buckets.timing) if tr.buckets is not None else 0
+        outs.append((tr.bank.params.cpu().numpy(), n_coll))
+    t = torch.ones(4, device='cuda')
+    dist.all_reduce(t)
+    q.put((outs, float(t.sum()), dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_bucketed_step_bitwise_equal_to_no_group():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 30900 + (os.getpid() % 1000)
+    p = ctx.Process(target=_worker_rccl_world1, args=(port, q))
+    p.start()
+    outs, s, backend = q.get(timeout=600)
+    p.join(120)
+    assert backend == 'nccl' and s == 4.0
+    assert outs[0][1] == 0 and outs[1][1] == 6 and outs[2][1] == 6        # 3 buckets x 2 steps went through RCCL
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], outs[2][0])

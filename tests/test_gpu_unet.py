@@ -212,7 +212,7 @@ def test_odd_batch_sizes_train():
     """ragged batches (last partial batch is kept, train.py:373 drop_last=False): B = 1, 2, 7, 17."""
     from oracle import unet_oracle as O
     from vec_vad_amd.trainer import FusedTrainer
-    for B in (2, 7, 17):
+    for B in (1, 2, 7, 17):
         net, sd, tot_of = _build('net4', False)
         raw, flow = O.seeded_cubes(B, 1, 11)
         x, x_of = O.cubes_to_inputs(raw, flow)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from vec_vad_amd import _lib
     hdr = open(os.path.join(ROOT, 'include', 'vecvad_hip.h')).read()
-    declared = set(re.findall(r'^\s*(?:int|void|const char\*)\s+(vv_\w+)\s*\(', hdr, flags=re.M))
+    declared = set(re.findall(r'^\s*(?:int|int64_t|void|const char\*)\s+(vv_\w+)\s*\(', hdr, flags=re.M))
     assert declared, 'no declarations parsed'
     l = _lib.lib()                      # raises if the .so is missing or a bound symbol is absent
     for name in declared:

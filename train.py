@@ -108,9 +108,28 @@ def _dist():
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     return dist, dist.get_rank(), dist.get_world_size()
+
+
+def _extract_once(c, device, poll_s=2.0):
+    """Rank 0 cuts the training cubes and then drops a marker file; every other rank of the same torchrun job polls for it."""
+    import time
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    job = '%s_%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.environ.get('MASTER_PORT', '0'))
+    marker = os.path.join(c['data_root_dir'], c['modality'], '.%s_train_extracted_%s' % (c['dataset_name'], job))
+    if rank == 0:
+        from foreground import extract_train
+        extract_train(c, device)
+        if world > 1:
+            os.makedirs(os.path.dirname(marker), exist_ok=True)
+            with open(marker, 'w') as f:
+                f.write('done')
+    else:
+        while not os.path.exists(marker):
+            time.sleep(poll_s)
 
 
 def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0, shuffle_seed=0, device='cuda',
@@ -146,21 +165,29 @@ def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0
             perm = torch.from_numpy(perm).to(device)
             nb = (n + batch_size - 1) // batch_size
             for idx in range(nb):
-                bidx = perm[idx * batch_size:(idx + 1) * batch_size]
+                bidx = perm[idx * batch_size:(idx + 1) * batch_size]          # the last partial batch is kept (train.py:373)
+                n_glob = int(bidx.numel())
                 if world > 1:
-                    keep = (bidx.numel() // world) * world        # DataParallel would scatter unevenly; we drop < world cubes
-                    if keep == 0:
-                        continue
-                    bidx = shard_batch(bidx[:keep], rank, world)
-                if bidx.numel() * world < 2:
-                    continue                                      # BatchNorm needs > 1 value per channel
-                ws = trainer.step_cubes(st.raw, st.flow, bidx)
-                l_raw, l_of = trainer.losses(ws)
-                raw_losses.update(l_raw, bidx.numel())
-                of_losses.update(l_of if l_of is not None else torch.zeros((), device=device), bidx.numel())
-                if idx % 5 == 0 and rank == 0:
-                    log('Block: {}, epoch {}, seg {}, batch {} of {}, raw loss: {}, of loss: {}'.format(
-                        tag, epoch, si, idx, n // batch_size, raw_losses.avg, of_losses.avg))
+                    if n_glob % world == 0:
+                        bidx = shard_batch(bidx, rank, world)
+                        ws = trainer.step_cubes(st.raw, st.flow, bidx)
+                    else:       # DataParallel's uneven scatter (chunks of ceil(n / world), trailing replicas may get nothing)
+                        per = -(-n_glob // world)
+                        bidx = bidx[rank * per:(rank + 1) * per]
+                        ws = trainer.step_cubes_uneven(st.raw, st.flow, bidx, n_glob)
+                else:
+                    ws = trainer.step_cubes(st.raw, st.flow, bidx)           # a single cube is a valid batch (BatchNorm over H x W)
+                if ws is not None:
+                    l_raw, l_of = trainer.losses(ws)
+                    raw_losses.update(l_raw, bidx.numel())
+                    of_losses.update(l_of if l_of is not None else torch.zeros((), device=device), bidx.numel())
+                if idx % 5 == 0:
+                    avg_r, avg_o = _global_avg(dist, raw_losses, of_losses, device)      # every rank takes part; rank 0 prints
+                    if rank == 0:
+                        log('Block: {}, epoch {}, seg {}, batch {} of {}, raw loss: {}, of loss: {}'.format(
+                            tag, epoch, si, idx, n // batch_size, avg_r, avg_o))
+    # DataParallel keeps replica 0's BatchNorm statistics (train.py:375): every rank scores with -- and rank 0 saves -- those
+    trainer.sync_from_rank0(params=False)
     sd = {('module.' + k): v.detach().clone() for k, v in net.state_dict().items()}     # train.py:410 (DataParallel keys)
 
     # A forward pass to store the training scores (train.py:413-427), eval mode, shuffle=False
@@ -180,16 +207,27 @@ def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0
         r_loc = torch.cat(r_loc) if r_loc else torch.zeros(0, device=device)
         o_loc = torch.cat(o_loc) if o_loc else torch.zeros(0, device=device)
         if world > 1:
-            r_loc, o_loc = _gather_var(dist, r_loc, n, world), _gather_var(dist, o_loc, n, world)
+            r_loc, o_loc = _gather_var(dist, r_loc, n, world), _gather_var(dist, o_loc, n, world, net.useFlow)
         rs.append(r_loc.cpu().numpy())
         os_.append(o_loc.cpu().numpy())
     return sd, np.concatenate(rs), np.concatenate(os_)
 
 
-def _gather_var(dist, t, n, world):
-    """all-gather of per-rank contiguous score shards (tiny; no collective in the math)."""
-    if t.numel() == 0 and n == 0:
-        return t
+def _global_avg(dist, raw_m, of_m, device):
+    """running-average losses over ALL ranks' shards (the reference logs the loss of the whole batch, train.py:394-399)."""
+    if dist is None:
+        return raw_m.avg, of_m.avg
+    t = torch.stack([raw_m.sum, of_m.sum, torch.tensor(float(raw_m.count), device=device, dtype=torch.float64)])
+    dist.all_reduce(t)
+    cnt = max(1.0, float(t[2]))
+    return float(t[0]) / cnt, float(t[1]) / cnt
+
+
+def _gather_var(dist, t, n, world, present=True):
+    """all-gather of per-rank contiguous score shards (tiny; no collective in the math).  present=False: this score does not
+    exist (useFlow = False) -> empty on every rank."""
+    if not present or (t.numel() == 0 and n == 0):
+        return t[:0]
     mx = (n + world - 1) // world + 1
     pad = torch.zeros(mx, device=t.device, dtype=t.dtype)
     pad[:t.numel()] = t
@@ -205,15 +243,13 @@ def _gather_var(dist, t, n, world):
 def main(config_path='config.cfg'):
     c = read_config(config_path)
     cp, ds, fg, root, mod, method = c['cp'], c['dataset_name'], c['mode_fg'], c['data_root_dir'], c['modality'], c['method']
-    dist, rank, world = _dist()
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(device)
     if not cp.getboolean(ds, 'train_foreground_saved'):      # train.py:102-226, cubes cut on the GPU (vv_crop_resize)
-        if rank == 0:
-            from foreground import extract_train
-            extract_train(c, device)
-        if dist is not None:
-            dist.barrier()
+        # BEFORE the process group exists: extraction of a large dataset takes longer than a collective's watchdog allows, so
+        # the other ranks wait on a marker file, not on a barrier
+        _extract_once(c, device)
+    dist, rank, world = _dist()
     net = build_network(c)
     base = os.path.join(root, mod, ds + '_')
     shanghai = ds == 'ShanghaiTech'
@@ -266,6 +302,11 @@ def main(config_path='config.cfg'):
         print('Training of {} for dataset: {} has completed!'.format(method, ds))
     if dist is not None:
         dist.barrier()
+        if rank == 0:
+            job = '%s_%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.environ.get('MASTER_PORT', '0'))
+            marker = os.path.join(root, mod, '.%s_train_extracted_%s' % (ds, job))
+            if os.path.exists(marker):
+                os.remove(marker)
 
 
 if __name__ == '__main__':

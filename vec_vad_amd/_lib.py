@@ -124,13 +124,16 @@ _SIGS = {
     'vv_correlation_nhwc': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_f32, c_vp]),
     'vv_resample2d_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_channelnorm_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_flownet_prep_workspace_bytes': (C.c_int64, [c_i32]),
+    'vv_flownet_prep': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp]),
+    'vv_warp_pack12': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    'vv_fusion_pack11': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
     'vv_crop_resize': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'vv_frame_scores': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_double, C.c_double, C.c_double, c_i32, c_vp,
                                 c_vp]),
     'vv_roc_auc_counts': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     'vv_version': (C.c_char_p, []),
-    'vv_last_hip_error': (C.c_char_p, []),
-    'vv_set_last_hip_error': (None, [c_i32]),
+    'vv_status_string': (C.c_char_p, [c_i32]),
     'vv_device_arch_ok': (c_i32, []),
 }
 
@@ -162,11 +165,12 @@ _STATUS = {1: 'VV_ERR_BAD_ARG', 2: 'VV_ERR_LAUNCH', 3: 'VV_ERR_UNSUPPORTED'}
 
 
 def check(status, what=''):
+    """status: the int every entry point returns (low byte = vv_status, bits 8.. = hipError_t of a failed launch)."""
     if status != 0:
         detail = ''
-        if status == 2 and _lib is not None:
-            detail = ' (%s)' % _lib.vv_last_hip_error().decode()
-        raise VecVadHipError('%s failed: %s%s' % (what or 'libvecvad_hip call', _STATUS.get(status, status), detail))
+        if (status & 0xff) == 2 and _lib is not None:
+            detail = ' (hipError %d: %s)' % (status >> 8, _lib.vv_status_string(status).decode())
+        raise VecVadHipError('%s failed: %s%s' % (what or 'libvecvad_hip call', _STATUS.get(status & 0xff, status), detail))
 
 
 def view(t, cstride, coff=0, gstride=0):

@@ -314,9 +314,11 @@ class UNetBank:
         n_raw = sum(1 for u in self.units[self.g0:self.g0 + Ga] if u.role == 'raw')
         n_of = Ga - n_raw
         gs = []
+        # train.py:385-392: loss = lambda_raw * L_raw + lambda_of * L_of with flow, plain L_raw (no lambda) without
+        lam_raw = self.lambda_raw if n_of else 1.0
         for u in self.units[self.g0:self.g0 + Ga]:
             if u.role == 'raw':
-                gs.append(2.0 * self.lambda_raw / (B * n_raw * RAW_C * HWp))
+                gs.append(2.0 * lam_raw / (B * n_raw * RAW_C * HWp))
             else:
                 gs.append(2.0 * self.lambda_of / (B * n_of * OF_C * HWp))
         ws.gscale.copy_(torch.tensor(gs))

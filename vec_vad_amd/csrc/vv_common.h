@@ -27,14 +27,12 @@ __device__ __forceinline__ void vv_static_for(F&& f) {
     hipLaunchKernelGGL(__VA_ARGS__);    \
   } while (0)
 
-extern "C" void vv_set_last_hip_error(int code);   // thread-local record for vv_last_hip_error()
+// the hipError_t travels in the return value (bits 8..): no last-error variable anywhere in the library
+#define VV_HIP_STATUS(e) (VV_ERR_LAUNCH | ((int)(e) << 8))
 #define VV_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \
-    if (e__ != hipSuccess) {                                \
-      vv_set_last_hip_error((int)e__);                      \
-      return VV_ERR_LAUNCH;                                 \
-    }                                                       \
+    if (e__ != hipSuccess) return VV_HIP_STATUS(e__);       \
   } while (0)
 
 // XCD-aware work-item remap: the dispatcher places block b on XCD b%8 (observed, MI355X_MICROARCH.md);

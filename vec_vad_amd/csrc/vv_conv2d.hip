@@ -334,7 +334,8 @@ pack_conv2d_kernel(const float* __restrict__ w, float* __restrict__ packed, cons
 __global__ void __launch_bounds__(VV_WG)
 upsample4_kernel(const int64_t n, const float* __restrict__ src, float* __restrict__ dst, const int C, const int H,
                  const int W, const int bilinear, const float scale) {
-  // NCHW, x4: nn.Upsample(scale_factor=4, mode='bilinear' (align_corners=False) | 'nearest'), flownet2.py:28,34,43-44
+  // NCHW, x4: nn.Upsample(scale_factor=4, mode='nearest' (0) | 'bilinear' align_corners=False (1) | align_corners=True (2)),
+  // flownet2.py:28,34,43-44; (2) is what the authors' PyTorch 0.3 computed for 'bilinear' 
   const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
   if (e >= n) return;
   const int OW = 4 * W, OH = 4 * H;
@@ -344,8 +345,15 @@ upsample4_kernel(const int64_t n, const float* __restrict__ src, float* __restri
   const float* p = src + bc * H * W;
   float v;
   if (bilinear) {
-    const float sy = fmaxf((oy + 0.5f) * 0.25f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.25f - 0.5f, 0.f);
-    const int y0 = (int)sy, x0 = (int)sx;
+    float sy, sx;
+    if (bilinear == 2) {      // src = dst * (in - 1) / (out - 1)
+      sy = (H > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f) * (float)oy;
+      sx = (W > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f) * (float)ox;
+    } else {
+      sy = fmaxf((oy + 0.5f) * 0.25f - 0.5f, 0.f);
+      sx = fmaxf((ox + 0.5f) * 0.25f - 0.5f, 0.f);
+    }
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = sy - (float)y0, lx = sx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;

@@ -982,10 +982,14 @@ extern "C" int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, co
 
 extern "C" const char* vv_version(void) { return "vecvad_hip 0.1 (gfx950)"; }
 
-static thread_local int g_last_hip_error = 0;
-extern "C" void vv_set_last_hip_error(int code) { g_last_hip_error = code; }
-extern "C" const char* vv_last_hip_error(void) {
-  return g_last_hip_error ? hipGetErrorString((hipError_t)g_last_hip_error) : "";
+extern "C" const char* vv_status_string(int status) {
+  switch (status & 0xff) {
+    case VV_OK: return "VV_OK";
+    case VV_ERR_BAD_ARG: return "VV_ERR_BAD_ARG";
+    case VV_ERR_UNSUPPORTED: return "VV_ERR_UNSUPPORTED";
+    case VV_ERR_LAUNCH: return (status >> 8) ? hipGetErrorString((hipError_t)(status >> 8)) : "VV_ERR_LAUNCH";
+    default: return "unknown vv_status";
+  }
 }
 
 extern "C" int vv_device_arch_ok(void) {

@@ -289,12 +289,10 @@ static int launch_corr_nhwc(const float* f1, const float* f2, int cs, int B, int
   constexpr int DYB = 4 * (128 / W_);
   constexpr int QS = ((W_ + 40 + 3) / 4 + 15) / 16 * 16, Q1 = (W_ / 4 + 15) / 16 * 16;
   constexpr size_t bytes = (size_t)(8 * (4 * Q1 + 1) + DYB * 8 * (4 * QS + 1)) * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(correlation_nhwc_kernel<W_>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-      return VV_ERR_LAUNCH;
-    attr_set = true;
+  {   // idempotent and cheap: set on every call rather than remembering it in a static
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(correlation_nhwc_kernel<W_>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return VV_HIP_STATUS(e);
   }
   const int NG = (21 + DYB - 1) / DYB;
   VV_LAUNCH(correlation_nhwc_kernel<W_>, dim3(H * NG, B), dim3(VV_WG), bytes, st, f1, f2, cs, C, H, out, ocs, ocoff,

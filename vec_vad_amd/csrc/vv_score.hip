@@ -105,7 +105,10 @@ extern "C" int vv_frame_scores(const float* raw, const float* of, const int32_t*
 extern "C" int vv_roc_auc_counts(const double* scores, const uint8_t* labels, int32_t n, uint64_t* out3,
                                  vv_stream stream) {
   if (!scores || !labels || !out3 || n < 0) return VV_ERR_BAD_ARG;
-  if (hipMemsetAsync(out3, 0, 3 * sizeof(uint64_t), (hipStream_t)stream) != hipSuccess) return VV_ERR_LAUNCH;
+  {
+    const hipError_t e = hipMemsetAsync(out3, 0, 3 * sizeof(uint64_t), (hipStream_t)stream);
+    if (e != hipSuccess) return VV_HIP_STATUS(e);
+  }
   if (n == 0) return VV_OK;
   VV_LAUNCH(auc_count_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores, labels, n,
             (unsigned long long*)out3);

@@ -5,8 +5,9 @@ components/FlowNetC.py:10-132, FlowNetS.py:11-96, FlowNetSD.py:9-103, FlowNetFus
 ``FlowNet2_checkpoint.pth.tar['state_dict']`` loads unchanged.  What runs: every conv / deconv / predict_flow layer is
 the hand-written MFMA kernel ``vv_conv2d_mfma`` on NHWC buffers (producers write straight into the channel slices of
 the consumer's concat buffer), the three native ops are ``vv_correlation_fwd / vv_resample2d_fwd / vv_channelnorm_fwd``
-and the x4 flow up-sampling is ``vv_upsample4``.  Only tensor plumbing (mean subtraction of the input, NCHW<->NHWC
-views, packing 12/11-channel network inputs) uses torch tensor ops.  No torch.nn op, no fallback.
+and the plumbing between the sub-networks (input normalisation, x4 flow up-sampling, warp, brightness error, concat) is three
+NHWC kernels (``vv_flownet_prep / vv_warp_pack12 / vv_fusion_pack11``).  No torch.nn op, no ATen kernel between input and
+output, no fallback.
 
 ``with_bn`` must be False and ``fp16`` False (what VEC_VAD instantiates, flownet2.py:12-17).
 """
@@ -213,11 +214,12 @@ class _Runner:
         return dst
 
 
-def _upsample4(x_nchw, bilinear, scale):
+def _upsample4(x_nchw, bilinear, scale, align_corners=False):
+    """nn.Upsample(scale_factor=4) on NCHW planes times ``scale``: nearest, bilinear, or bilinear with align_corners=True."""
     x = x_nchw.contiguous()
     B, Cc, H, W = x.shape
     out = torch.empty(B, Cc, 4 * H, 4 * W, device=x.device, dtype=torch.float32)
-    L.check(L.lib().vv_upsample4(x.data_ptr(), out.data_ptr(), B * Cc, H, W, 1 if bilinear else 0, float(scale),
+    L.check(L.lib().vv_upsample4(x.data_ptr(), out.data_ptr(), B * Cc, H, W, (2 if align_corners else 1) if bilinear else 0, float(scale),
                                  torch.cuda.current_stream(x.device).cuda_stream), 'upsample4')
     return out
 
@@ -494,10 +496,15 @@ class FlowNetFusion(nn.Module):
 class FlowNet2(nn.Module):
     """FlowNetC -> warp -> FlowNetS -> warp -> FlowNetS, || FlowNetSD, -> FlowNetFusion (flownet2.py:65-149)."""
 
-    def __init__(self, with_bn=False, fp16=False, rgb_max=255., div_flow=20., grads=None):
+    def __init__(self, with_bn=False, fp16=False, rgb_max=255., div_flow=20., grads=None, upsample_align_corners=False):
+        """Signature of flownet2.py:12-17 plus ``upsample_align_corners``: the two bilinear x4 up-samplings
+        (``nn.Upsample(scale_factor=4, mode='bilinear')``, flownet2.py:28,34) meant align_corners=True under the PyTorch 0.3 the
+        authors ran (README.md:10,64) and mean align_corners=False under every torch >= 0.4 -- which is what importing the
+        reference today computes and therefore the default; pass True to reproduce the published checkpoint's behaviour."""
         super().__init__()
         if with_bn or fp16:
             raise NotImplementedError('VEC_VAD instantiates FlowNet2() with_bn=False, fp16=False (calc_optical_flow.py:15)')
+        self.upsample_align_corners = bool(upsample_align_corners)
         self.with_bn, self.div_flow, self.rgb_max = with_bn, div_flow, rgb_max
         self.grads = {} if grads is None else grads
         self.channelnorm = ChannelNorm()
@@ -539,37 +546,35 @@ class FlowNet2(nn.Module):
             self._pool.end()
 
     def _forward(self, run, inputs):
-        # per-image, per-colour mean over both frames (flownet2.py:67); two-level sum: a [B,3]-row reduction over ~1e6
-        # elements per row is a 3-workgroup kernel in torch
-        flat = inputs.contiguous().view(inputs.size()[:2] + (-1,))
-        n = flat.shape[-1]
-        k = 1024 if n % 1024 == 0 else 1
-        rgb_mean = (flat.view(flat.shape[0], flat.shape[1], n // k, k).sum(dim=-1).sum(dim=-1) / n).view(inputs.size()[:2] + (1, 1, 1))
-        x = (inputs - rgb_mean) / self.rgb_max
-        x1, x2 = x[:, :, 0].contiguous(), x[:, :, 1].contiguous()
-        xcat = torch.cat((x1, x2), dim=1)
-        img0, img1, x6 = _to_buf(x1), _to_buf(x2), _to_buf(xcat)
+        """flownet2.py:65-149 as launches: vv_flownet_prep (mean / normalise / split / cat), the five conv stacks, and one
+        packing launch in front of each refinement network (x4 up-sampling + Resample2d + ChannelNorm + torch.cat fused,
+        written straight into the consumer's NHWC buffer).  No ATen kernel runs between the input and the returned flow."""
+        lib = L.lib()
+        dev = inputs.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        inputs = inputs.contiguous()
+        B, _, _, H, W = inputs.shape
+        x6, img0, img1 = _Buf(B, H, W, 6, dev), _Buf(B, H, W, 3, dev), _Buf(B, H, W, 3, dev)
+        ws = self._pool.take((int(lib.vv_flownet_prep_workspace_bytes(B)) // 4,), dev)
+        L.check(lib.vv_flownet_prep(inputs.data_ptr(), B, H, W, float(self.rgb_max), ws.data_ptr(), ws.numel() * 4,
+                                    x6.t.data_ptr(), img0.t.data_ptr(), img1.t.data_ptr(), st), 'flownet_prep')
+        bil = 2 if self.upsample_align_corners else 1
 
-        def warp_pack(flow):
-            """[x, resample(img1, flow), flow/div_flow, |img0 - warped|] as a 12-channel NHWC buffer (flownet2.py:78-86)."""
-            warped = resample2d(x2, flow)
-            norm = channelnorm(x1 - warped)
-            return _to_buf(torch.cat([xcat, warped, flow / self.div_flow, norm], dim=1))
+        def warp_pack(flow2):
+            """[x, resample(img1, flow), flow / div_flow, |img0 - warped|], flow = upsample x4(flow2 * div_flow) (flownet2.py:76-86)."""
+            out = _Buf(B, H, W, 12, dev)
+            L.check(lib.vv_warp_pack12(x6.t.data_ptr(), img1.t.data_ptr(), flow2.t.data_ptr(), flow2.cs, B, H, W, bil,
+                                       float(self.div_flow), float(self.div_flow), out.t.data_ptr(), st), 'warp_pack12')
+            return out
 
-        c_flow2 = self.flownetc.run(run, img0, img1).nchw(0, 2)
-        c_flow = _upsample4(c_flow2, True, self.div_flow)
-        s1_flow2 = self.flownets_1.run(run, warp_pack(c_flow)).nchw(0, 2)
-        s1_flow = _upsample4(s1_flow2, True, self.div_flow)
-        s2_flow2 = self.flownets_2.run(run, warp_pack(s1_flow)).nchw(0, 2)
-        s2_flow = _upsample4(s2_flow2, False, self.div_flow)
-        norm_s2 = channelnorm(s2_flow)
-        diff_s2 = channelnorm(x1 - resample2d(x2, s2_flow))
-        sd_flow2 = self.flownets_d.run(run, x6).nchw(0, 2)
-        sd_flow = _upsample4(sd_flow2, False, 1.0 / self.div_flow)
-        norm_sd = channelnorm(sd_flow)
-        diff_sd = channelnorm(x1 - resample2d(x2, sd_flow))
-        concat3 = torch.cat((x1, sd_flow, s2_flow, norm_sd, norm_s2, diff_sd, diff_s2), dim=1)
-        return self.flownetfusion.run(run, _to_buf(concat3)).nchw(0, 2)
+        c_flow2 = self.flownetc.run(run, img0, img1)
+        s1_flow2 = self.flownets_1.run(run, warp_pack(c_flow2))
+        s2_flow2 = self.flownets_2.run(run, warp_pack(s1_flow2))
+        sd_flow2 = self.flownets_d.run(run, x6)
+        cat3 = _Buf(B, H, W, 11, dev)
+        L.check(lib.vv_fusion_pack11(x6.t.data_ptr(), img1.t.data_ptr(), s2_flow2.t.data_ptr(), s2_flow2.cs, sd_flow2.t.data_ptr(),
+                                     sd_flow2.cs, B, H, W, float(self.div_flow), cat3.t.data_ptr(), st), 'fusion_pack11')
+        return self.flownetfusion.run(run, cat3).nchw(0, 2)
 
     @torch.no_grad()
     def forward_graphed(self, inputs):

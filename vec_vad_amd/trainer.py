@@ -3,9 +3,10 @@
 One process per GPU.  Data parallelism replaces the reference's single-process ``nn.DataParallel`` (train.py:375):
 every rank runs the grouped HIP forward/backward on its own shard of the global batch with per-rank BatchNorm
 statistics (what DataParallel does), gradients are summed over RCCL (``torch.distributed`` backend
-"nccl") in two buckets -- the decoder bucket is reduced on a side stream while the encoder half of the backward pass
-is still running -- and scaled by 1/world inside the fused Adam kernel.  No parameter broadcast per step (ranks start
-from identical weights and apply identical updates).
+"nccl") in three buckets -- the decoder and deep-encoder buckets are reduced on a communication stream while the rest of the
+backward pass is still running -- and scaled by 1/world inside the fused Adam kernel.  No parameter broadcast per step:
+parameters, BatchNorm buffers and step counters are broadcast from rank 0 ONCE when the trainer is built (DataParallel
+replicates rank 0's module, train.py:375) and the ranks then apply identical updates.
 """
 import torch
 
@@ -39,6 +40,7 @@ class GradBuckets:
                       for a, b in zip(self.bounds[:-1], self.bounds[1:])]
         self.comm_stream = torch.cuda.Stream(device=grads.device) if self.cuda else None
         self.pending = []
+        self.timing = None          # set to [] to collect (bucket, start event, end event) per collective (bench diagnostics)
 
     def launch(self, k):
         a, b = self.bounds[k], self.bounds[k + 1]
@@ -47,8 +49,16 @@ class GradBuckets:
             ready.record()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
+                if self.timing is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 self.stage[k].copy_(self.grads[:, a:b])
                 work = self.dist.all_reduce(self.stage[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.timing is not None:
+                    work.wait()                 # stream-level wait (comm stream): the end event follows the collective
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.comm_stream)
+                    self.timing.append((k, e0, e1))
         else:
             self.stage[k].copy_(self.grads[:, a:b])
             work = self.dist.all_reduce(self.stage[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -73,7 +83,7 @@ class FusedTrainer:
     """forward(train) -> backward -> [bucketed RCCL all-reduce] -> Adam, all asynchronous on the current stream."""
 
     def __init__(self, net, lr=1e-3, eps=1e-7, betas=(0.9, 0.999), lambda_raw=1.0, lambda_of=1.0, process_group=None,
-                 reset_optimizer=True, overlap=False):
+                 reset_optimizer=True, overlap=False, always_bucket=False, sync_init=True):
         net.set_loss_weights(lambda_raw, lambda_of)
         self.net = net
         self.bank = net.bank()
@@ -87,7 +97,11 @@ class FusedTrainer:
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
-        if self.world > 1:
+        if self.world > 1 and sync_init:
+            self.sync_from_rank0()
+        # always_bucket: run the bucketed exchange even in a one-rank group (a sum over one rank is the identity): exercises
+        # init_process_group('nccl') + GradBuckets on device tensors on a single-GPU box, bit-equal to the no-group path
+        if self.world > 1 or (always_bucket and process_group is not None):
             lay = self.bank.lay
             # three buckets in the order the backward pass completes them: [c8.w, U) decoder convs + transposed convs + 1x1 out
             # (45 % of the parameters), [c4.w, c8.w) the deep encoder layers (51 %), [0, c4.w) the shallow encoder layers (3 %).
@@ -106,6 +120,20 @@ class FusedTrainer:
         self.overlap = overlap
         self.debug_delay = None          # (stream id, cycles): see _run_dual
         self.side = torch.cuda.Stream(device=self.bank.device) if overlap else None
+
+    def sync_from_rank0(self, params=True, buffers=True):
+        """Every rank takes rank 0's parameters / BatchNorm running statistics / step counters.  nn.DataParallel (train.py:375)
+        replicates device 0's module, so rank 0's state is THE model: at start-up the ranks must hold the same weights (they are
+        built from unseeded initialisers), and before an eval-mode scoring pass or a save they must hold rank 0's running
+        statistics (per-rank statistics in between are DataParallel's own semantics)."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        bank = self.bank
+        ts = ([bank.params] if params else []) + ([bank.bufs, bank.nbt] if buffers else [])
+        for t in ts:
+            dist.broadcast(t, src=src, group=self.group)
 
     # ---- plan execution with optional per-launch HIP events and a mid-plan callback
     def _run(self, plan, stream, after=None):
@@ -204,6 +232,32 @@ class FusedTrainer:
     def step_cubes(self, raw_u8, flow, idx):
         """One optimisation step on cubes ``idx`` of a device-resident cube store (uint8 [N,5,32,32,3], fp32 [N,Tf,32,32,2])."""
         return self._step(self.bank.set_input_cubes(raw_u8, flow, idx))
+
+    def step_cubes_uneven(self, raw_u8, flow, idx, n_global):
+        """A global batch that does not split evenly over the ranks (the last batch of an epoch; the reference keeps it,
+        train.py:373, and DataParallel scatters it in chunks of ceil(n / world)): this rank holds ``idx`` (possibly empty) of
+        ``n_global`` cubes.  The loss is the mean over the GLOBAL batch, so the local mean-loss gradient is weighted by
+        B_local * world / n_global before the sum (Adam then divides by world); a rank without cubes contributes zeros.  One
+        plain all-reduce of the whole buffer -- no bucket overlap on this rare step.  Returns the workspace, or None for an
+        empty shard."""
+        import torch.distributed as dist
+        bank = self.bank
+        b = int(idx.numel())
+        ws = None
+        if b:
+            ws = bank.set_input_cubes(raw_u8, flow, idx)
+            self._run(ws.fwd[True], bank._stream())
+            bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+            if ws.bwd is None:
+                ws.bwd = bank._plan_backward(ws, ws.B)
+            self._run(ws.bwd, bank._stream())
+            bank.grads.mul_(b * self.world / float(n_global))
+        else:
+            bank.grads.zero_()
+        if self.world > 1:
+            dist.all_reduce(bank.grads, op=dist.ReduceOp.SUM, group=self.group)
+        bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+        return ws
 
     def step_nchw(self, x, x_of):
         """One optimisation step on the reference's DataLoader tensors (train.py:380-383)."""
