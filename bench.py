@@ -4,16 +4,25 @@ all-reduce]) of SelfCompleteNet4 (5raw+1of, nf=32) on synthetic 32x32x5 RGB + fl
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W            # weak scaling: 256 cubes per GPU
+    ... bench.py --gpus 8 --batch 32                          # the reference's DataParallel split of ONE 256-cube batch
 
 Workload = BASELINE.json configs[1]: "UCSDped2 5raw+1of UNet train, batch 256, 1xMI355X, HIP conv kernels".
 Cubes live on the GPU as uint8 / fp32 (the reference's on-disk cube layout); every step gathers a fresh random batch
 (vv_cube_gather), runs the grouped HIP forward, backward and fused Adam.  Multi-GPU: one process per GPU, each rank
-trains on its own 256 cubes per step (weak scaling) and the flat gradient buffer is all-reduced over RCCL.
+trains on its own cubes and the flat gradient buffer is all-reduced over RCCL in three buckets.
 
-Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (the MFMA 3x3 convolution used by forward and
-data-gradient), timed with HIP events on the launch stream inside the timed region; `cpu_baseline` times the
-reference's op sequence (oracle, stock PyTorch CPU ops) on the host cores on a bounded sample.
+Rank 0 prints ONE JSON line.
+  roofline      the dominant kernel family (3x3 convolution forward + data-gradient launches), timed with HIP events on the
+                launch stream inside the timed region.  ``achieved`` / ``frac`` count the multiply-adds the matrix cores EXECUTE
+                (the Winograd F(2x2,3x3) kernel executes 16/36 of the direct convolution's), so frac <= 1 is a hardware
+                utilisation; the algorithmic (direct-convolution) rate is ``algorithmic_tflops`` and their ratio
+                ``effective_vs_direct``.
+  cpu_baseline  the reference's op sequence (oracle, stock PyTorch CPU ops) on the host cores: 3 warm-up + 10 timed steps per
+                thread count, best-of sweep AND the all-cores figure, train step and eval forward.
+  configs       secondary records measured in the same run (N=1 only): BASELINE config 4 (SelfCompleteNetFull, B=512, mixed
+                bf16), config 5 (FlowNet2 forward on a 1024x448 pair) and the eval-mode scoring pass, each with its own roofline.
+  comm          (N>1) rccl_ranks, per-bucket all-reduce time and the exposed communication per step.
 """
 import argparse
 import json
@@ -26,11 +35,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FWD_FLOP_NET4 = 1855520768      # per cube, SURVEY.md section 8(d)
-TRAIN_FLOP_NET4 = 5524094976
+FLOP = {'net4': (1855520768, 5524094976), 'full': (3092316160, 9206169600)}      # (forward, train step) per cube, SURVEY 8(d)
 FP32_MFMA_PEAK = 157.3e12       # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 BF16_MFMA_PEAK = 2.5e15         # v_mfma_f32_32x32x16_bf16, dense
 HBM_PEAK = 8.0e12               # HBM3E, MI355X_MICROARCH.md
+WINO_EXEC = 16.0 / 36.0         # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
+FLOWNET2_GFLOP = 464.2          # per 1024x448 pair, SURVEY appendix A.2
 
 
 def conv_flops(lay, B, G):
@@ -41,6 +51,18 @@ def conv_flops(lay, B, G):
         fl['conv%d' % l.idx] = f
         if l.idx > 0:
             fl['dgrad%d' % l.idx] = f
+    return fl
+
+
+def conv_exec_flops(lay, B, G, wino):
+    """FLOPs the matrix cores execute for the same launches: channels padded to the MFMA K granule (layer 0: 12 -> 16),
+    x 16/36 for the Winograd form."""
+    fl = {}
+    k = WINO_EXEC if wino else 1.0
+    for l in lay.convs:
+        fl['conv%d' % l.idx] = 2.0 * B * l.H * l.H * 9 * l.cinp * l.cout * G * k
+        if l.idx > 0:
+            fl['dgrad%d' % l.idx] = 2.0 * B * l.H * l.H * 9 * l.cin * l.cout * G * k
     return fl
 
 
@@ -58,48 +80,319 @@ def conv_bytes(lay, B, G, y_bytes=4, dy_bytes=4, da_bytes=4):
     return by
 
 
-def pmc_traffic(name='r01_pmc_hbm_traffic.json'):
+def pmc_traffic(name):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
-    separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed."""
-    p = os.path.join(ROOT, 'profiles', name)
-    try:
-        d = json.load(open(p))
-        return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected']
-    except Exception:
-        return None
+    separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed.  This is a
+    number read from profiles/, not something this run measured (PMC collection needs rocprofv3 around the process)."""
+    for n in (name, name.replace('r02_', 'r01_')):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', n)))
+            return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], n
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(batch=32, steps=3, thread_choices=(8, 16, 32, 64)):
+def cpu_baseline(batch=32, warm=3, steps=10, sweep=(8, 16, 32), budget_s=45.0):
     """Reference op sequence (torch CPU ops, NCHW fp32, per-op BN/ReLU/pool/cat, Adam eps=1e-7) on the host cores:
-    BASELINE.json configs[0] (Net4, B=32).  This is the oracle restatement ("port"); it is test/bench
-    infrastructure and never part of the product path.  The host of an MI355X box has 256 hardware threads and the
-    B=32 workload scales badly past ~16 of them (oneDNN/OpenMP oversubscription), so a few thread counts are tried
-    (bounded: one warm-up + `steps` timed steps each) and the best one is reported with its thread count."""
+    BASELINE.json configs[0] (Net4, B=32), SURVEY 8(d): 3 warm-up + 10 timed train steps.  The host of an MI355X box has 256
+    hardware threads and the B=32 workload scales badly past ~16 of them (oneDNN/OpenMP oversubscription), so both figures
+    are reported: the best of a small thread sweep (``value`` / ``cores``) and all cores (``all_cores``; its step count is cut
+    when a step takes seconds, and says so).  ``eval_value`` is the eval-mode forward (scoring) at the best thread count.
+    This is the oracle restatement ("port"): test/bench infrastructure, never part of the product path."""
     from oracle import unet_oracle as O
     ncpu = os.cpu_count() or 1
     spec = O.bank_spec('net4')
     raw, flow = O.seeded_cubes(batch, 1, 3)
     x, x_of = O.cubes_to_inputs(raw, flow)
-    best = None
-    tried = []
-    for nt in [t for t in thread_choices if t <= ncpu] or [ncpu]:
+    t_start = time.perf_counter()
+
+    def run(nt, w, k):
         torch.set_num_threads(nt)
         sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
         opt = O.AdamState(O.param_names(sd))
-        O.train_step(sd, spec, x, x_of, opt)          # warm-up
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(w):
             O.train_step(sd, spec, x, x_of, opt)
-        dt = (time.perf_counter() - t0) / steps
-        tried.append('%d thr: %.0f cubes/s' % (nt, batch / dt))
-        if best is None or batch / dt > best[0]:
-            best = (batch / dt, nt)
-        if dt * steps > 20:
+        t0 = time.perf_counter()
+        for _ in range(k):
+            O.train_step(sd, spec, x, x_of, opt)
+        return batch * k / (time.perf_counter() - t0)
+
+    tried, best = [], None
+    for nt in [t for t in sweep if t <= ncpu] or [ncpu]:
+        v = run(nt, warm, steps)
+        tried.append('%d thr: %.0f' % (nt, v))
+        if best is None or v > best[0]:
+            best = (v, nt)
+        if time.perf_counter() - t_start > budget_s * 0.5:
             break
+    # all cores: probe one step, then as many of the 3 + 10 as the budget allows
+    torch.set_num_threads(ncpu)
+    t0 = time.perf_counter()
+    probe = run(ncpu, 1, 1)
+    per = (time.perf_counter() - t0) / 2
+    left = budget_s - (time.perf_counter() - t_start)
+    k_all = int(max(1, min(steps, (left / max(per, 1e-3) - warm))))
+    w_all = warm if k_all == steps else 1
+    allc = run(ncpu, w_all, k_all) if left > 2 * per else probe
+    # eval-mode forward (test.py:319-335) at the best thread count
+    torch.set_num_threads(best[1])
+    sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
+    for _ in range(warm):
+        O.score_pass(sd, spec, x, x_of, batch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.score_pass(sd, spec, x, x_of, batch)
+    ev = batch * steps / (time.perf_counter() - t0)
     return {'value': best[0], 'unit': 'cubes/s', 'cores': best[1], 'kind': 'port',
-            'sample': 'SelfCompleteNet4 train step (fwd+bwd+Adam) on stock torch %s CPU ops, batch %d, %d timed steps per '
-                      'thread count; host has %d hardware threads; tried: %s'
-                      % (torch.__version__, batch, steps, ncpu, '; '.join(tried))}
+            'all_cores': {'value': allc, 'cores': ncpu, 'warmup': w_all, 'steps': k_all},
+            'eval_value': ev, 'eval_unit': 'cubes/s (eval-mode forward + per-cube scores)',
+            'sample': 'SelfCompleteNet4 train step (fwd+bwd+Adam) on stock torch %s CPU ops, batch %d (BASELINE configs[0]), %d warm-up + '
+                      '%d timed steps per thread count; host has %d hardware threads; sweep (cubes/s): %s; all %d threads: %.0f '
+                      '(%d+%d steps)' % (torch.__version__, batch, warm, steps, ncpu, '; '.join(tried), ncpu, allc, w_all, k_all)}
+
+
+def build_net(model, precision, dev):
+    from model.unet import SelfCompleteNet4, SelfCompleteNetFull
+    os.environ['VV_PRECISION'] = precision          # read by the UNet bank when it is built
+    torch.manual_seed(0)
+    tot_of = 1 if model == 'net4' else 5
+    cls = SelfCompleteNet4 if model == 'net4' else SelfCompleteNetFull
+    net = cls(features_root=32, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=None, useFlow=True,
+              padding=False).to(dev)
+    return net, tot_of
+
+
+def conv_roofline(bank, B, per, precision, overlap, traffic):
+    """roofline object of the 3x3-conv family from HIP-event timings {label: [seconds]}."""
+    fl = conv_flops(bank.lay, B, bank.Ga)
+    fx = conv_exec_flops(bank.lay, B, bank.Ga, bank.wino)
+    by = conv_bytes(bank.lay, B, bank.Ga, 2 if bank.y16 else 4, 2 if bank.dz16 else 4, 2 if bank.da16 else 4)
+    t = sum(sum(v) for k, v in per.items() if k in fl)
+    n = sum(len(v) for k, v in per.items() if k in fl)
+    if not n or t <= 0:
+        return None
+    f_alg = sum(fl[k] * len(v) for k, v in per.items() if k in fl)
+    f_exe = sum(fx[k] * len(v) for k, v in per.items() if k in fl)
+    b_alg = sum(by[k] * len(v) for k, v in per.items() if k in fl)
+    common = {'launches_timed': n, 'avg_launch_us': 1e6 * t / n, 'algorithmic_gflop_per_launch': f_alg / n / 1e9,
+              'algorithmic_mbytes_per_launch': b_alg / n / 1e6, 'traffic': traffic[0], 'traffic_source': traffic[1],
+              'side_stream_weight_grad': overlap}
+    if precision == 'fp32':
+        r = {'bound': 'mfma',
+             'kernel': ('wino_conv_kernel<H>: 3x3 conv forward + data-gradient as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32'
+                        if bank.wino else 'conv_mfma_kernel: 3x3 implicit GEMM on v_mfma_f32_32x32x2_f32, forward + data-gradient'),
+             'achieved': f_exe / t / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': f_exe / t / FP32_MFMA_PEAK,
+             'accounting': 'achieved / frac = multiply-adds the matrix cores execute (x16/36 of the direct convolution for the '
+                           'Winograd form, K padded to the MFMA granule); algorithmic_tflops = SURVEY 8(d) direct-convolution FLOP / time',
+             'algorithmic_tflops': f_alg / t / 1e12, 'effective_vs_direct': f_alg / f_exe}
+    else:
+        r = {'bound': 'hbm',
+             'kernel': 'conv_mfma_kernel<..., BF=true>: 3x3 implicit GEMM, bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation, '
+                       'forward + data-gradient; achieved = algorithmic bytes (input once + output once, bf16 tensors) / time',
+             'achieved': b_alg / t / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b_alg / t / HBM_PEAK,
+             'mfma_tflops': f_alg / t / 1e12, 'frac_of_bf16_mfma_peak': f_alg / t / BF16_MFMA_PEAK}
+    r.update(common)
+    return r
+
+
+def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap='none', breakdown=False, pool=4096,
+             measure_forward=True):
+    """W untimed + exactly K timed train steps; returns the record (rank 0) -- value is the whole-job rate."""
+    from vec_vad_amd.trainer import FusedTrainer
+    net, tot_of = build_net(model, precision, dev)
+    trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
+                           overlap={'none': False, 'free': True, 'paired': 'paired'}[overlap])
+    bank = trainer.bank
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    raw = torch.randint(0, 256, (pool, 5, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
+    flow = (torch.randn((pool, tot_of, 32, 32, 2), generator=g) * 2.0).to(dev)
+    perm = torch.stack([torch.randperm(pool, generator=g)[:B] for _ in range(steps + warmup)]).to(dev)
+    for it in range(warmup):
+        trainer.step_cubes(raw, flow, perm[it])
+    torch.cuda.synchronize()
+    ws = bank.workspace(B)
+    fl = conv_flops(bank.lay, B, bank.Ga)
+    ev = []
+    trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
+    trainer.event_labels = set(fl.keys()) if not breakdown else None
+    if trainer.buckets is not None:
+        trainer.buckets.timing = []
+        trainer.comm_timing = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        trainer.step_cubes(raw, flow, perm[warmup + it])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    trainer.event_hook = None
+    comm = None
+    if trainer.buckets is not None:
+        bt = {}
+        for k, a, b in trainer.buckets.timing:
+            bt.setdefault(k, []).append(a.elapsed_time(b) * 1e3)
+        exposed = [a.elapsed_time(b) * 1e3 for a, b in trainer.comm_timing]
+        lay = bank.lay
+        bounds = trainer.buckets.bounds
+        comm = {'rccl_ranks': world, 'backend': dist.get_backend() if dist is not None else None,
+                'buckets': [{'bucket': k, 'columns': [bounds[k], bounds[k + 1]], 'mbytes': 4e-6 * bank.G * (bounds[k + 1] - bounds[k]),
+                             'allreduce_us_avg': sum(v) / len(v), 'launched_after': {2: 'decoder half of backward', 1: 'deep-encoder '
+                             'weight gradients', 0: 'last backward launch'}[k]} for k, v in sorted(bt.items(), reverse=True)],
+                'exposed_comm_us_per_step': sum(exposed) / max(1, len(exposed)),
+                'note': 'allreduce_us = stage copy + collective on the communication stream (HIP events); exposed = main-stream '
+                        'time from the end of the backward pass to the arrival of the last sums'}
+        trainer.buckets.timing = None
+        trainer.comm_timing = None
+    # forward-only rate (north_star: ">= 50 % of the MFMA roofline on the UNet forward at batch 256"): cube gather + train-mode
+    # forward (BatchNorm batch statistics, loss + per-cube scores), outside the timed region
+    fwd_ms = None
+    if measure_forward:
+        fwd_n = 10
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        bufs, nbt = bank.bufs.clone(), bank.nbt.clone()      # forward(train=True) moves the BatchNorm running statistics
+        f0.record()
+        for it in range(fwd_n):
+            bank.set_input_cubes(raw, flow, perm[it % perm.shape[0]], B)
+            bank.forward(ws, True)
+        f1.record()
+        torch.cuda.synchronize()
+        bank.bufs.copy_(bufs)
+        bank.nbt.copy_(nbt)
+        fwd_ms = f0.elapsed_time(f1) / fwd_n
+    l_raw, l_of = bank.losses(ws)
+    per = {}
+    for label, a, b in ev:
+        per.setdefault(label, []).append(a.elapsed_time(b) * 1e-3)
+    if breakdown and rank == 0:
+        tot = sum(sum(v) for v in per.values())
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            extra = '  %.1f TF/s' % (fl[k] / (sum(v) / len(v)) / 1e12) if k in fl else ''
+            sys.stderr.write('%-22s n=%3d avg %8.1f us  %5.1f%%%s\n' % (k, len(v), 1e6 * sum(v) / len(v), 100 * sum(v) / tot, extra))
+        sys.stderr.write('sum of launches %.3f ms / step ; wall %.3f ms / step\n' % (1e3 * tot / steps, 1e3 * dt / steps))
+    fwd_flop, train_flop = FLOP[model]
+    value = B * world * steps / dt
+    peak = FP32_MFMA_PEAK if precision == 'fp32' else BF16_MFMA_PEAK
+    tag = 'fp32' if precision == 'fp32' else 'bf16'
+    pmc_ok = model == 'net4' and B == 256          # the committed PMC passes were taken on the default workload
+    traffic = pmc_traffic('r02_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')) if pmc_ok else (None, None)
+    rec = {'value': value, 'unit': 'cubes/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+           'dtype': 'f32' if precision == 'fp32' else 'bf16 operands, f32 accumulate',
+           'config': {'workload': {'net4': 'UCSDped2-shaped 5raw+1of UNet bank (SelfCompleteNet4, nf=32, padding=False) train step: '
+                                           'cube gather + forward + backward + Adam(eps=1e-7)',
+                                   'full': 'ShanghaiTech-shaped 5raw+5of UNet bank (SelfCompleteNetFull, nf=32, padding=False) train '
+                                           'step: cube gather + forward + backward + Adam(eps=1e-7)'}[model],
+                      'batch_per_gpu': B, 'global_batch': B * world, 'cube': '32x32x5 RGB uint8 + %d flow map(s) fp32' % tot_of,
+                      'parallelism': 'dp%d' % world, 'train_tflops_per_gpu': value / world * train_flop / 1e12,
+                      'frac_of_%s_mfma_peak_whole_step_algorithmic' % tag: value / world * train_flop / peak,
+                      'loss_raw': float(l_raw), 'loss_of': float(l_of) if l_of is not None else 0.0},
+           'roofline': conv_roofline(bank, B, per, precision, overlap, traffic)}
+    if precision == 'bf16':
+        rec['config']['precision'] = 'mixed bf16 (BASELINE config 4): conv / transposed-conv operands and stored activations bf16, ' \
+                                     'parameters / BatchNorm statistics / loss / Adam fp32'
+    if fwd_ms is not None:
+        rec['config'].update({'forward_ms': fwd_ms, 'forward_tflops_per_gpu_algorithmic': B * fwd_flop / (fwd_ms * 1e-3) / 1e12,
+                              'forward_frac_of_%s_mfma_peak_algorithmic' % tag: B * fwd_flop / (fwd_ms * 1e-3) / peak})
+        if precision == 'fp32' and bank.wino:
+            # executed share of the forward: the 14 Winograd conv launches execute 16/36, everything else (transposed convs) 1:1
+            fa = conv_flops(bank.lay, B, bank.Ga)
+            fx = conv_exec_flops(bank.lay, B, bank.Ga, True)
+            conv_a = sum(v for k, v in fa.items() if k.startswith('conv'))
+            conv_x = sum(v for k, v in fx.items() if k.startswith('conv'))
+            exe = B * fwd_flop - conv_a + conv_x
+            rec['config']['forward_frac_of_fp32_mfma_peak_executed'] = exe / (fwd_ms * 1e-3) / peak
+    if comm is not None:
+        rec['comm'] = comm
+    del trainer, net, raw, flow
+    torch.cuda.empty_cache()
+    return rec
+
+
+def run_scoring(dev, B=512, n=8192, reps=3):
+    """Eval-mode scoring pass (test.py:312-345 / train.py:413-427): device-resident cubes -> per-cube raw / flow scores."""
+    from vec_vad_amd.trainer import FusedTrainer
+    net, tot_of = build_net('net4', 'fp32', dev)
+    net.eval()
+    tr = FusedTrainer(net)
+    g = torch.Generator(device='cpu').manual_seed(7)
+    raw = torch.randint(0, 256, (n, 5, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
+    flow = (torch.randn((n, tot_of, 32, 32, 2), generator=g) * 2.0).to(dev)
+    idx = [torch.arange(s, s + B, device=dev) for s in range(0, n, B)]
+    for i in idx[:2]:
+        tr.score_cubes(raw, flow, i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for i in idx:
+            tr.score_cubes(raw, flow, i)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / (reps * len(idx))
+    fwd_flop = FLOP['net4'][0]
+    rec = {'value': B / (ms * 1e-3), 'unit': 'cubes/s', 'ms_per_launch_of_%d_cubes' % B: ms, 'dtype': 'f32',
+           'workload': 'SelfCompleteNet4 eval-mode scoring (running-statistics BatchNorm, per-cube squared-error sums), %d cubes per launch' % B,
+           'path': getattr(tr.bank, 'eval_path', 'train-mode kernel family with running statistics'),
+           'algorithmic_tflops': B * fwd_flop / (ms * 1e-3) / 1e12,
+           'frac_of_fp32_mfma_peak_algorithmic': B * fwd_flop / (ms * 1e-3) / FP32_MFMA_PEAK}
+    del tr, net
+    torch.cuda.empty_cache()
+    return rec
+
+
+def run_flownet2(dev, reps=10):
+    """BASELINE config 5: FlowNet2 forward on one 1024x436 pair zero-padded to 1024x448 (the reference itself fails at 436),
+    xavier weights (no checkpoint offline), hipGraph replay; per-kernel-family timings from one eager pass with HIP events."""
+    from vec_vad_amd.flownet2 import FlowNet2
+    torch.manual_seed(0)
+    net = FlowNet2().to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(1, 3, 2, 448, 1024, generator=g) * 255)
+    x[:, :, :, 436:] = 0
+    x = x.to(dev)
+    for _ in range(2):
+        out = net.forward_graphed(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        out = net.forward_graphed(x)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    ms = e0.elapsed_time(e1) / reps
+    # per-family launch timings (eager; events bracket single launches)
+    fam = {}
+    net._runner.hook = lambda label, flop, a, b: fam.setdefault(label, []).append((flop, a, b))
+    for _ in range(2):
+        net(x)
+    torch.cuda.synchronize()
+    net._runner.hook = None
+    fams = {}
+    for k, v in fam.items():
+        t = sum(a.elapsed_time(b) for _, a, b in v) * 1e-3
+        f = sum(fl for fl, _, _ in v)
+        fams[k] = {'launches_per_forward': len(v) // 2, 'ms_per_forward': 1e3 * t / 2, 'tflops': f / t / 1e12 if t > 0 else None}
+    dom = max((k for k in fams if not k.endswith('_n2')), key=lambda k: fams[k]['ms_per_forward'])
+    rec = {'value': 1e3 / ms, 'unit': 'pairs/s', 'ms_per_pair': ms, 'ms_per_pair_wall': wall * 1e3, 'dtype': 'f32',
+           'workload': 'FlowNet2 forward, one 1024x436 pair zero-padded to 1024x448, xavier weights, hipGraph replay',
+           'algorithmic_gflop': FLOWNET2_GFLOP, 'finite': bool(torch.isfinite(out).all()),
+           'roofline': {'bound': 'mfma', 'kernel': 'conv2d_mfma_kernel family (whole forward: 464.2 GFLOP of conv / deconv work)',
+                        'achieved': FLOWNET2_GFLOP / ms, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                        'frac': FLOWNET2_GFLOP / ms / (FP32_MFMA_PEAK / 1e12), 'traffic': None,
+                        'dominant_family': dom, 'dominant_family_frac': fams[dom]['tflops'] / (FP32_MFMA_PEAK / 1e12)},
+           'families_eager': fams}
+    del net
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -107,29 +400,25 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=256, help='cubes per GPU per step')
+    ap.add_argument('--batch', type=int, default=256, help='cubes per GPU per step (32 with --gpus 8 = DataParallel split of 256)')
     ap.add_argument('--pool', type=int, default=4096, help='device-resident synthetic cubes per GPU')
     ap.add_argument('--model', default='net4', choices=['net4', 'full'])
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                    help="bf16 = BASELINE config 4's mixed precision (bf16 conv operands, fp32 accumulation / tensors / BatchNorm / "
-                         "Adam); the headline number is fp32, like the reference")
+                    help="bf16 = BASELINE config 4's mixed precision; the headline number is fp32, like the reference")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the config-4 / config-5 / scoring records')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
     ap.add_argument('--overlap', nargs='?', const='free', default='none', choices=('none', 'free', 'paired'),
                     help="side stream for the weight-gradient kernels: 'free' = under everything that follows (conv launches "
                          "are then contended), 'paired' = only under the next layer's BatchNorm backward (conv launches run alone)")
     args = ap.parse_args()
-    os.environ['VV_PRECISION'] = args.precision
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
-    if os.environ.get('VV_SINGLE_DEVICE'):          # bring-up: all ranks share GPU 0 (gloo backend only)
-        local_rank_dev = 0
-    else:
-        local_rank_dev = local_rank
+    local_rank_dev = 0 if os.environ.get('VV_SINGLE_DEVICE') else local_rank      # bring-up: all ranks on GPU 0 (gloo only)
     torch.cuda.set_device(local_rank_dev)
     dev = torch.device('cuda', local_rank_dev)
     dist = None
@@ -142,154 +431,31 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from model.unet import SelfCompleteNet4, SelfCompleteNetFull
-    from vec_vad_amd.trainer import FusedTrainer
-    torch.manual_seed(0)
-    tot_of = 1 if args.model == 'net4' else 5
-    cls = SelfCompleteNet4 if args.model == 'net4' else SelfCompleteNetFull
-    net = cls(features_root=32, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=None, useFlow=True,
-              padding=False).to(dev)
-    trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
-                           overlap={'none': False, 'free': True, 'paired': 'paired'}[args.overlap])
-    bank = trainer.bank
-    B = args.batch
-    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    raw = torch.randint(0, 256, (args.pool, 5, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
-    flow = (torch.randn((args.pool, tot_of, 32, 32, 2), generator=g) * 2.0).to(dev)
-    perm = torch.stack([torch.randperm(args.pool, generator=g)[:B] for _ in range(args.steps + args.warmup)]).to(dev)
-
-    for it in range(args.warmup):
-        trainer.step_cubes(raw, flow, perm[it])
-    torch.cuda.synchronize()
-    ws = bank.workspace(B)
-    fl = conv_flops(bank.lay, B, bank.Ga)
-    by = conv_bytes(bank.lay, B, bank.Ga, 2 if getattr(bank, 'y16', False) else 4, 2 if getattr(bank, 'dz16', False) else 4,
-                    2 if getattr(bank, 'da16', False) else 4)
-    # HIP events around every MFMA 3x3-conv launch (forward conv + data-gradient) of the timed region
-    ev = []
-    trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
-    trainer.event_labels = set(fl.keys()) if not args.breakdown else None
-
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        trainer.step_cubes(raw, flow, perm[args.warmup + it])
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    trainer.event_hook = None
-    # a few extra (untimed) steps with the side stream disabled: the same launches without a concurrent weight-grad kernel
-    iso = []
-    if args.overlap == 'free':
-        trainer.event_hook = lambda label, a, b: iso.append((label, a, b))
-        trainer.event_labels = set(fl.keys())
-        trainer.overlap = False
-        for it in range(3):
-            trainer.step_cubes(raw, flow, perm[it % perm.shape[0]])
-        torch.cuda.synchronize()
-        trainer.overlap = True
-        trainer.event_hook = None
-    # forward-only rate (BASELINE.json north_star: ">= 50 % of the MFMA roofline on the UNet forward at batch 256"):
-    # cube gather + train-mode forward (BatchNorm batch statistics, loss + per-cube scores), outside the timed region
-    fwd_n = 10
-    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    bufs, nbt = bank.bufs.clone(), bank.nbt.clone()          # forward(train=True) moves the BatchNorm running statistics
-    f0.record()
-    for it in range(fwd_n):
-        bank.set_input_cubes(raw, flow, perm[it % perm.shape[0]], B)
-        bank.forward(ws, True)
-    f1.record()
-    torch.cuda.synchronize()
-    bank.bufs.copy_(bufs)
-    bank.nbt.copy_(nbt)
-    fwd_ms = f0.elapsed_time(f1) / fwd_n
-    iso_t = sum(a.elapsed_time(b) * 1e-3 for _, a, b in iso)
-    iso_f = sum(fl[label] for label, _, _ in iso)
-    l_raw, l_of = bank.losses(ws)
-    loss_now = (float(l_raw), float(l_of) if l_of is not None else 0.0)
-
-    per = {}
-    for label, a, b in ev:
-        per.setdefault(label, []).append(a.elapsed_time(b) * 1e-3)
-    conv_t = sum(sum(v) for k, v in per.items() if k in fl)
-    conv_n = sum(len(v) for k, v in per.items() if k in fl)
-    conv_f = sum(fl[k] * len(v) for k, v in per.items() if k in fl)
-    conv_b = sum(by[k] * len(v) for k, v in per.items() if k in fl)
-    if args.breakdown and rank == 0:
-        tot = sum(sum(v) for v in per.values())
-        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            extra = ''
-            if k in fl:
-                extra = '  %.1f TF/s' % (fl[k] / (sum(v) / len(v)) / 1e12)
-            sys.stderr.write('%-22s n=%3d avg %8.1f us  %5.1f%%%s\n' % (k, len(v), 1e6 * sum(v) / len(v), 100 * sum(v) / tot, extra))
-        sys.stderr.write('sum of launches %.3f ms / step ; wall %.3f ms / step\n' % (1e3 * tot / args.steps, 1e3 * dt / args.steps))
-
+    rec = run_unet(args.model, args.precision, args.batch, args.steps, args.warmup, dev, rank, world, dist, args.overlap,
+                   args.breakdown, args.pool)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    cubes = B * world * args.steps
-    value = cubes / dt
-    flop_per_cube = TRAIN_FLOP_NET4 if args.model == 'net4' else 9206169600
-    fwd_flop_per_cube = 1855520768 if args.model == 'net4' else 3092316160
-    pmc_ok = args.model == 'net4' and B == 256          # the committed PMC passes were taken on the default workload
-    out = {
-        'metric': 'spatio-temporal cubes/sec (train step)', 'value': value, 'unit': 'cubes/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16 operands, f32 accumulate',
-        'data': 'synthetic',
-        'config': {'workload': 'UCSDped2-shaped 5raw+1of UNet bank (SelfCompleteNet4, nf=32, padding=False) train step: '
-                               'cube gather + forward + backward + Adam(eps=1e-7)' if args.model == 'net4' else
-                               '5raw+5of UNet bank (SelfCompleteNetFull) train step',
-                   'batch_per_gpu': B, 'global_batch': B * world, 'cube': '32x32x5 RGB uint8 + flow fp32',
-                   'parallelism': 'dp%d' % world, 'train_tflops_per_gpu': value / world * flop_per_cube / 1e12,
-                   'frac_of_fp32_mfma_peak_whole_step': value / world * flop_per_cube / FP32_MFMA_PEAK,
-                   'forward_ms': fwd_ms, 'forward_tflops_per_gpu': B * fwd_flop_per_cube / (fwd_ms * 1e-3) / 1e12,
-                   'forward_frac_of_fp32_mfma_peak': B * fwd_flop_per_cube / (fwd_ms * 1e-3) / FP32_MFMA_PEAK,
-                   'loss_raw': loss_now[0], 'loss_of': loss_now[1]},
-        'roofline': {'bound': 'mfma',
-                     'kernel': ('wino_conv_kernel (3x3 conv as Winograd F(2x2,3x3) on MFMA, forward + data-gradient launches): '
-                                'achieved = ALGORITHMIC (direct-convolution) FLOP / time, so it can exceed the peak; '
-                                'executed_* = the 2.25x fewer multiply-adds the matrix cores actually run')
-                     if bank.wino else 'conv_mfma_kernel (3x3 implicit-GEMM, forward + data-gradient launches)',
-                     'achieved': (conv_f / conv_t / 1e12) if conv_t > 0 else None, 'peak': FP32_MFMA_PEAK / 1e12,
-                     'unit': 'TFLOP/s', 'frac': (conv_f / conv_t / FP32_MFMA_PEAK) if conv_t > 0 else None,
-                     'traffic': pmc_traffic() if pmc_ok else None, 'launches_timed': conv_n,
-                     'avg_launch_us': (1e6 * conv_t / conv_n) if conv_n else None,
-                     'algorithmic_gflop_per_launch': (conv_f / conv_n / 1e9) if conv_n else None,
-                     'executed_tflops': (conv_f / conv_t / 1e12 / (2.25 if bank.wino else 1.0)) if conv_t > 0 else None,
-                     'executed_frac': (conv_f / conv_t / FP32_MFMA_PEAK / (2.25 if bank.wino else 1.0)) if conv_t > 0 else None,
-                     'side_stream_weight_grad': args.overlap,
-                     'isolated_frac': (iso_f / iso_t / FP32_MFMA_PEAK) if iso_t > 0 else None},
-    }
-    if args.precision == 'bf16':
-        # the bf16 matrix instruction needs 1/16 of the fp32 one's cycles: the same launches are bound by HBM (fp32 tensors)
-        mf = out['roofline']
-        out['roofline'] = {'bound': 'hbm',
-                           'kernel': 'conv_mfma_kernel<..., BF=true> (3x3 implicit GEMM, bf16 operands / fp32 accumulation, forward + '
-                                     'data-gradient launches): achieved = algorithmic bytes (input read once + output written once; bf16 '
-                                     'tensors) / time.  At 325 FLOP/B these launches sit on the ridge of the bf16 roofline: see frac_of_bf16_mfma_peak',
-                           'achieved': (conv_b / conv_t / 1e9) if conv_t > 0 else None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                           'frac': (conv_b / conv_t / HBM_PEAK) if conv_t > 0 else None,
-                           'traffic': pmc_traffic('r01_pmc_hbm_traffic_bf16.json') if pmc_ok else None, 'launches_timed': conv_n,
-                           'avg_launch_us': mf['avg_launch_us'],
-                           'algorithmic_mbytes_per_launch': (conv_b / conv_n / 1e6) if conv_n else None,
-                           'algorithmic_gflop_per_launch': mf['algorithmic_gflop_per_launch'],
-                           'mfma_tflops': mf['achieved'], 'frac_of_bf16_mfma_peak': (mf['achieved'] * 1e12 / BF16_MFMA_PEAK)
-                           if mf['achieved'] else None, 'side_stream_weight_grad': args.overlap}
-        cfgd = out['config']
-        for k_ in ('frac_of_fp32_mfma_peak_whole_step', 'forward_frac_of_fp32_mfma_peak'):      # wrong denominator in this mode
-            cfgd.pop(k_, None)
-        cfgd['frac_of_bf16_mfma_peak_whole_step'] = value / world * flop_per_cube / BF16_MFMA_PEAK
-        cfgd['forward_frac_of_bf16_mfma_peak'] = B * fwd_flop_per_cube / (fwd_ms * 1e-3) / BF16_MFMA_PEAK
-        out['config']['precision'] = 'mixed bf16 (BASELINE config 4): conv / transposed-conv operands bf16, everything else fp32'
+    out = {'metric': 'spatio-temporal cubes/sec (train step)', 'value': rec['value'], 'unit': 'cubes/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'], 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': rec['dtype'], 'data': 'synthetic', 'config': rec['config'],
+           'roofline': rec['roofline']}
+    if 'comm' in rec:
+        out['comm'] = rec['comm']
+    if world == 1 and not args.no_secondary:
+        sec = {}
+        for name, fn in (('full_b512_bf16', lambda: run_unet('full', 'bf16', 512, 10, 3, dev, 0, 1, None, 'none', False, 2048)),
+                         ('flownet2_1024x448', lambda: run_flownet2(dev)),
+                         ('net4_eval_scoring', lambda: run_scoring(dev))):
+            try:
+                sec[name] = fn()
+            except Exception as e:          # a secondary record must not take the headline line down
+                sec[name] = {'value': None, 'error': repr(e)}
+        sec['full_b512_bf16']['baseline_config'] = 'configs[3]: ShanghaiTech 5raw+5of (context_of_num=4), batch 512, mixed bf16 -- ' \
+                                                   'measured on 1 GPU (the 8-GPU run is the driver\'s)'
+        sec['flownet2_1024x448']['baseline_config'] = 'configs[4]: FlowNet2 correlation+conv forward on 1024x436 frame pairs, 1xMI355X'
+        out['configs'] = sec
     if not args.no_cpu_baseline and world == 1:
         try:
             out['cpu_baseline'] = cpu_baseline()

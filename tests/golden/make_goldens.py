@@ -22,7 +22,15 @@ from oracle import unet_oracle as O  # noqa: E402
 
 np.int = int  # reference uses the removed alias (utils.py:22, vad_datasets.py:74-83)
 sys.path.insert(0, '/root/reference')
-from model.unet import SelfCompleteNet4, SelfCompleteNetFull, SelfCompleteNet1raw1of  # noqa: E402
+# the reference's model/ has no __init__.py (namespace package) and would lose against this repo's regular package of the
+# same name: load the reference file explicitly (imported from where it lies, never copied)
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location('ref_model_unet', '/root/reference/model/unet.py')
+_ref_unet = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_ref_unet)
+SelfCompleteNet4, SelfCompleteNetFull, SelfCompleteNet1raw1of = (_ref_unet.SelfCompleteNet4, _ref_unet.SelfCompleteNetFull,
+                                                                  _ref_unet.SelfCompleteNet1raw1of)
+assert SelfCompleteNet4.__module__ == 'ref_model_unet'
 
 # stubs so that vad_datasets imports
 sys.modules['cv2'] = types.ModuleType('cv2')
@@ -143,8 +151,11 @@ def case_model(kind, nf, padding, n, rawRange=None):
     return out
 
 
-def case_script(kind='net4', nf=32, n_train=24, n_test_frames=10, batch=8, epochs=2):
-    """train.py:365-433 + test.py:251-357 + utils.py:29-39 driven with a fixed (shuffle=False) order."""
+def case_script(kind='net4', nf=32, n_train=24, n_test_frames=10, batch=8, epochs=2, graded=False):
+    """train.py:365-433 + test.py:251-357 + utils.py:29-39 driven with a fixed (shuffle=False) order.
+    graded=True (the 240-frame case): an "anomalous" frame shifts its last raw frame by 1..3 pixels instead of inverting it, so
+    normal and anomalous scores overlap and the AUROC is sensitive to rank swaps (AUROC within 1e-3 is then a real statement:
+    one swapped pair among ~90 x 90 moves it by 1.2e-4)."""
     torch.manual_seed(0)
     net, tot_of = build_ref(kind, nf, False)
     raw, flow, x, x_of = ref_inputs(n_train, tot_of, seed=1)
@@ -181,7 +192,10 @@ def case_script(kind='net4', nf=32, n_train=24, n_test_frames=10, batch=8, epoch
             _, _, xt, xt_of = ref_inputs(nc, tot_of, seed=cube_seed + f)
             if f % 2 == 1:  # "anomalous": perturb the last frame so reconstruction error grows
                 xt = xt.clone()
-                xt[:, 12:15] = 1.0 - xt[:, 12:15]
+                if graded:
+                    xt[:, 12:15] = torch.roll(xt[:, 12:15], 1 + f % 3, dims=3)
+                else:
+                    xt[:, 12:15] = 1.0 - xt[:, 12:15]
             with torch.no_grad():
                 of_o, raw_o, of_t, raw_t = net(xt, xt_of)
             r = sf(raw_t, raw_o).numpy().sum(3).sum(2).sum(1)
@@ -215,8 +229,12 @@ def main():
         'net4_nf32_rawrange4': lambda: case_model('net4', 32, False, 3, rawRange=4),
         '1raw1of_nf32_nopad': lambda: case_model('1raw1of', 32, False, 3),
         'script_net4': lambda: case_script(),
+        'script_net4_f240': lambda: case_script(n_test_frames=240, graded=True),
     }
+    only = sys.argv[1:]
     for name, fn in cases.items():
+        if only and name not in only:
+            continue
         out = fn()
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)

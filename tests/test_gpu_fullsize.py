@@ -29,10 +29,15 @@ def _grad_table(net):
 
 
 def test_net4_b256_train_step_gradients_vs_oracle():
-    """BASELINE config 2 at full size.  Bars: loss rel <= 1e-3 (observed ~1e-6); per-tensor gradient error
-    ||g_hip - g_oracle|| / ||g_oracle|| <= 1e-3 (norm-wise: a ReLU / max-pool decision within round-off of a tie flips single
-    elements, never the norm); conv biases in front of BatchNorm have a mathematically zero gradient (HIP writes exact zeros,
-    torch round-off noise) and are checked against the size of their weight tensor's gradient instead."""
+    """BASELINE config 2 at full size: losses rel <= 1e-3 (observed ~1e-6) and EVERY parameter gradient against the oracle.
+    Gradients of a 256-cube train-mode step are sums with heavy cancellation (BatchNorm backward removes mean and projection) over
+    ReLU / max-pool gates, a few of which sit within round-off of a tie: the reference's own fp32 arithmetic (oracle fp32) is
+    1.4e-3 (median) / 5.7e-3 (max) away from the oracle run in FLOAT64, per tensor, norm-wise -- so "<= 1e-3 of the fp32
+    oracle" is a bar the reference itself does not meet.  The test therefore measures against the fp64 gradient and calibrates
+    on the reference arithmetic in the same run: per tensor ||g_hip - g_f64|| / ||g_f64|| <= 3 x the fp32 oracle's distance
+    (+2e-4 floor), median over tensors <= 1.25 x the fp32 oracle's median, and the whole gradient (all tensors as one vector)
+    <= 1.5 x.  Observed on MI355X: median 1.2e-3 (HIP) vs 1.35e-3 (oracle fp32), max 4.1e-3 vs 5.7e-3.  Conv biases in front of
+    BatchNorm have a mathematically zero gradient (HIP writes exact zeros, torch round-off noise)."""
     from oracle import unet_oracle as O
     from test_gpu_unet import _build
     from vec_vad_amd.trainer import FusedTrainer
@@ -46,23 +51,34 @@ def test_net4_b256_train_step_gradients_vs_oracle():
     ws = tr.step_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), torch.arange(B, device='cuda'))
     l_raw, l_of = [float(v) for v in tr.losses(ws)]
     grads = {k: v.detach().cpu().double() for k, v in _grad_table(net).items()}
-    sdo = {k: v.clone() for k, v in sd.items()}
-    opt = O.AdamState(O.param_names(sdo))
-    lr_, lo_, gref = O.train_step(sdo, O.bank_spec('net4'), x, x_of, opt)
+    ref = {}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        sdo = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        opt = O.AdamState(O.param_names(sdo))
+        ref[tag] = O.train_step(sdo, O.bank_spec('net4'), x.to(dt), x_of.to(dt), opt)
+    lr_, lo_, g32 = ref['f32']
+    g64 = ref['f64'][2]
     assert abs(l_raw - lr_) <= 1e-3 * lr_ and abs(l_of - lo_) <= 1e-3 * lo_, (l_raw, lr_, l_of, lo_)
-    worst = (0.0, None)
-    for k, gr in gref.items():
-        gr = gr.double()
+    e_hip, e_ref = [], []
+    n_hip = n_ref = den = 0.0
+    for k, g in g64.items():
         gh = grads[k]
         if k.endswith('.0.bias') or k.endswith('.3.bias'):
             wk = k[:-4] + 'weight'
-            assert float(gh.abs().max()) <= 1e-6 * float(gref[wk].abs().max()) + 1e-12, k
+            assert float(gh.abs().max()) <= 1e-6 * float(g64[wk].abs().max()) + 1e-12, k
             continue
-        err = float((gh - gr).norm() / gr.norm())
-        if err > worst[0]:
-            worst = (err, k)
-        assert err <= 1e-3, (k, err)
-    print('worst per-tensor gradient error %.2e (%s)' % worst)
+        nrm = float(g.norm())
+        eh, er = float((gh - g).norm()) / nrm, float((g32[k].double() - g).norm()) / nrm
+        assert eh <= 3 * er + 2e-4, (k, eh, er)
+        e_hip.append(eh)
+        e_ref.append(er)
+        n_hip += float(((gh - g) ** 2).sum())
+        n_ref += float(((g32[k].double() - g) ** 2).sum())
+        den += float((g ** 2).sum())
+    print('per-tensor gradient error vs fp64: HIP median %.2e max %.2e ; oracle fp32 median %.2e max %.2e ; whole gradient %.2e vs %.2e'
+          % (np.median(e_hip), max(e_hip), np.median(e_ref), max(e_ref), (n_hip / den) ** 0.5, (n_ref / den) ** 0.5))
+    assert np.median(e_hip) <= 1.25 * np.median(e_ref), (np.median(e_hip), np.median(e_ref))
+    assert (n_hip / den) ** 0.5 <= 1.5 * (n_ref / den) ** 0.5, (n_hip, n_ref, den)
     # per-cube scores of the train-mode forward (batch statistics) vs the oracle's train-mode forward
     with torch.no_grad():
         sd2 = {k: v.clone() for k, v in sd.items()}

@@ -11,18 +11,25 @@ from _util import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precision):
-    """train.py's training block + test.py's scoring / frame maps / AUROC against the reference's own outputs (golden).  fp32: the
-    north-star tolerances.  bf16 (`[mi355x] precision = bf16`, BASELINE config 4): judged on AUROC -- within 2e-2
-    of the reference's on this 10-frame set -- with the per-cube / per-frame quantities within 5 %."""
+@pytest.mark.parametrize('precision,golden', [('fp32', 'script_net4'), ('fp32', 'script_net4_f240'), ('bf16', 'script_net4'),
+                                              ('bf16', 'script_net4_f240')])
+def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precision, golden):
+    """train.py's training block + test.py's scoring / frame maps / AUROC against the reference's own outputs (golden).
+    fp32: the north-star tolerances -- per-cube training scores rel <= 1e-3, z-normalised frame scores abs
+    <= 1e-3, AUROC abs <= 1e-3; the oracle's own fp32-vs-fp64 spread through the same 6 Adam steps is ~2e-4 on the scores
+    (tests/test_oracle_golden.py::test_oracle_fp32_fp64_spread_after_training).  The 240-frame golden has graded anomalies
+    (normal and anomalous scores overlap, AUROC 0.768): one swapped pair moves its AUROC by 1.2e-4, so the AUROC bar is a real
+    statement there; on the 10-frame golden it only says the ranking is identical.
+    bf16 (`[mi355x] precision = bf16`, BASELINE config 4): judged on AUROC -- within 2e-2 of the reference's --
+    with the per-cube / per-frame quantities within 5 % / 0.1."""
     monkeypatch.setenv('VV_PRECISION', precision)
-    tol = {'fp32': dict(train=5e-3, loss=1e-3, frame=1e-2, auc=1e-3), 'bf16': dict(train=5e-2, loss=1e-2, frame=1e-1, auc=2e-2)}[precision]
+    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=1e-3, auc=1e-3), 'bf16': dict(train=5e-2, loss=1e-2, frame=1e-1, auc=2e-2)}[precision]
     from oracle import unet_oracle as O
     import train as T
     import test as S
     from model.unet import SelfCompleteNet4
-    g = load_golden('script_net4')
+    g = load_golden(golden)
+    n_frames, graded = len(g['frame_scores']), golden.endswith('f240')
     torch.manual_seed(0)
     net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None,
                            useFlow=True, padding=False)
@@ -44,7 +51,7 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
     rng = np.random.default_rng(77)
     h, w = 240, 360
     fset, fset2, bset, labels = [], [], [], []
-    for f in range(10):
+    for f in range(n_frames):
         nc = f % 4
         if nc == 0:
             fset.append([[np.zeros((0, 5, 32, 32, 3), np.uint8)]])
@@ -54,7 +61,10 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
             rw, fl = O.seeded_cubes(nc, 1, 100 + f)
             if f % 2 == 1:
                 rw = rw.copy()
-                rw[:, 4] = 255 - rw[:, 4]           # same perturbation as 1 - x on the [0,1] tensor
+                if graded:
+                    rw[:, 4] = np.roll(rw[:, 4], 1 + f % 3, axis=2)        # torch.roll(x[:, 12:15], k, dims=3) on the NCHW tensor
+                else:
+                    rw[:, 4] = 255 - rw[:, 4]           # same perturbation as 1 - x on the [0,1] tensor
             bbs = []
             for m in range(nc):
                 x0, y0 = rng.uniform(0, w - 60), rng.uniform(0, h - 60)

@@ -97,8 +97,74 @@ def test_three_train_steps_fused(name, kind, padding, n, rawRange):
     net.eval()
     with torch.no_grad():
         of_o, raw_o, of_t, raw_t = net(xs, xo)
-    np.testing.assert_allclose(((raw_t - raw_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), g['post_raw_scores'], rtol=5e-3)
-    np.testing.assert_allclose(((of_t - of_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), g['post_of_scores'], rtol=5e-3)
+    # post-training scores at the north-star bar (1e-3).  The reference arithmetic itself (oracle fp32 vs fp64 through the same 3
+    # Adam steps) spreads ~2e-5 here and the HIP path sits at the same distance from fp64 (tools/diag_post_train.py,
+    # test_post_training_distance_from_fp64_is_the_reference_arithmetics_own)
+    np.testing.assert_allclose(((raw_t - raw_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), g['post_raw_scores'], rtol=1e-3)
+    np.testing.assert_allclose(((of_t - of_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), g['post_of_scores'], rtol=1e-3)
+
+
+def _oracle_trajectory(dt, nthr, kind, tot_of, n, steps, seed=0):
+    """The oracle through `steps` train steps (train.py:383-402) + the eval-mode score pass, in dtype dt on nthr threads."""
+    from oracle import unet_oracle as O
+    torch.set_num_threads(nthr)
+    sd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in O.seeded_state_dict(kind, nf=32, padding=False, seed=0).items()}
+    raw, flow = O.seeded_cubes(n, tot_of, seed)
+    x, xo = O.cubes_to_inputs(raw, flow)
+    x, xo = x.to(dt), xo.to(dt)
+    spec = O.bank_spec(kind)
+    opt = O.AdamState(O.param_names(sd))
+    losses = np.array([O.train_step(sd, spec, x, xo, opt)[:2] for _ in range(steps)])
+    rs, os_ = O.score_pass(sd, spec, x, xo, n)
+    return losses, rs.astype(np.float64), os_.astype(np.float64), sd
+
+
+def _param_rel_l2(a, ref):
+    from oracle import unet_oracle as O
+    num = den = 0.0
+    for k in O.param_names(ref):
+        if k.endswith('.0.bias') or k.endswith('.3.bias'):
+            continue            # conv bias in front of BatchNorm: zero gradient, never moves
+        d = a[k].double().cpu() - ref[k].double()
+        num += float((d ** 2).sum())
+        den += float((ref[k].double() ** 2).sum())
+    return (num / den) ** 0.5
+
+
+@pytest.mark.parametrize('kind,tot_of,n,steps', [('net4', 1, 6, 3), ('net4', 1, 6, 6), ('full', 5, 4, 3), ('net4', 1, 64, 6)])
+def test_post_training_distance_from_fp64_is_the_reference_arithmetics_own(kind, tot_of, n, steps):
+    """the post-training tolerances, demonstrated instead of loosened.  After 3 / 6 fused train steps the
+    HIP path's losses, eval-mode scores and parameters are compared with the oracle run in FLOAT64 (the exact trajectory), next
+    to the distance of the oracle's own fp32 run (the reference's arithmetic) from that fp64 trajectory on 32 and on 4 threads.
+    Bars: scores / losses abs-rel <= 1e-3 (north star) AND <= 4 x the reference arithmetic's own spread (+1e-5 floor); updated
+    parameters (Adam's first steps are lr*sign(g): a gradient whose sign is decided by round-off flips a 2e-3 move) relative L2
+    <= 2 x the fp32 oracle's.  Observed on MI355X: scores 2e-5 (3 steps) / 2e-4 (6 steps) for both, parameters 2.6e-3 vs
+    4.3e-3 (3 steps), 7e-3 vs 1e-2 (6 steps)."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    net, sd, _ = _build(kind, False)
+    raw, flow = O.seeded_cubes(n, tot_of, 0)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    net.train()
+    tr = FusedTrainer(net)
+    ls = []
+    for s in range(steps):
+        ws = tr.step_cubes(rawd, flowd, torch.arange(n, device='cuda'))
+        ls.append([float(v) for v in tr.losses(ws)])
+    net.eval()
+    r, o = [t.cpu().numpy().astype(np.float64) for t in tr.score_cubes(rawd, flowd)]
+    f64 = _oracle_trajectory(torch.float64, 32, kind, tot_of, n, steps)
+    f32a = _oracle_trajectory(torch.float32, 32, kind, tot_of, n, steps)
+    f32b = _oracle_trajectory(torch.float32, 4, kind, tot_of, n, steps)
+    rel = lambda p, q: float((np.abs(p - q) / np.abs(q)).max())
+    for name, got, i in (('loss', np.array(ls), 0), ('raw score', r, 1), ('of score', o, 2)):
+        e_hip = rel(got, f64[i])
+        e_ref = max(rel(f32a[i], f64[i]), rel(f32b[i], f64[i]))
+        assert e_hip <= 1e-3, (name, e_hip)
+        assert e_hip <= 4 * e_ref + 1e-5, (name, e_hip, e_ref)
+    p_hip = _param_rel_l2(net.state_dict(), f64[3])
+    p_ref = max(_param_rel_l2(f32a[3], f64[3]), _param_rel_l2(f32b[3], f64[3]))
+    assert p_hip <= 2 * p_ref, (p_hip, p_ref)
 
 
 def test_autograd_dropin_matches_oracle_grads():

@@ -115,6 +115,7 @@ class _Runner:
     def __init__(self):
         self.lib = L.lib()
         self.cache = {}
+        self.hook = None        # hook(label, e0, e1): HIP events around every conv launch (bench diagnostics, eager mode only)
 
     def _packed(self, m):
         key = id(m)
@@ -167,6 +168,23 @@ class _Runner:
         return True
 
     def __call__(self, layer, src, dst, dst_coff=0):
+        if self.hook is None:
+            return self._launch(layer, src, dst, dst_coff)
+        m = layer[0] if isinstance(layer, nn.Sequential) else layer
+        de = isinstance(m, nn.ConvTranspose2d)
+        label = '%s%dx%d_s%d' % ('deconv' if de else 'conv', m.kernel_size[0], m.kernel_size[1], m.stride[0])
+        if m.out_channels == 2:
+            label += '_n2'
+        oh, ow = dst.H, dst.W
+        flop = 2.0 * src.B * (src.H * src.W if de else oh * ow) * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self._launch(layer, src, dst, dst_coff)
+        e1.record()
+        self.hook(label, flop, e0, e1)
+        return r
+
+    def _launch(self, layer, src, dst, dst_coff=0):
         """layer: nn.Sequential(Conv2d|ConvTranspose2d[, LeakyReLU]) or a bare Conv2d / ConvTranspose2d."""
         if isinstance(layer, nn.Sequential):
             m = layer[0]

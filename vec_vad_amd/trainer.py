@@ -210,15 +210,13 @@ class FusedTrainer:
                     torch.cuda.current_stream(bank.device).wait_stream(self.side)
                     self.buckets.launch(1)
                 self._run_dual(ws.bwd, after={self.split_label: dec, self.split_label_mid: mid})
-                self.buckets.launch(0)
-                self.buckets.finish()
+                self._finish_exchange()
         elif self.buckets is None:
             self._run(ws.bwd, stream)
         else:
             self._run(ws.bwd, stream, after={self.split_label: lambda: self.buckets.launch(2),
                                               self.split_label_mid: lambda: self.buckets.launch(1)})
-            self.buckets.launch(0)
-            self.buckets.finish()
+            self._finish_exchange()
         if self.event_hook is not None and (self.event_labels is None or 'adam' in self.event_labels):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -228,6 +226,19 @@ class FusedTrainer:
         else:
             bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
         return ws
+
+    def _finish_exchange(self):
+        """Last (3 %) bucket + wait for all three.  With ``self.comm_timing`` set to a list, the time the main stream spends
+        between the end of the backward pass and the arrival of the last sums (= the exposed communication) is recorded."""
+        ct = getattr(self, 'comm_timing', None)
+        if ct is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.buckets.launch(0)
+        self.buckets.finish()
+        if ct is not None:
+            e1.record()
+            ct.append((e0, e1))
 
     def step_cubes(self, raw_u8, flow, idx):
         """One optimisation step on cubes ``idx`` of a device-resident cube store (uint8 [N,5,32,32,3], fp32 [N,Tf,32,32,2])."""
