@@ -126,15 +126,27 @@ def cpu_baseline(batch=32, warm=3, steps=10, sweep=(8, 16, 32), budget_s=45.0):
             best = (v, nt)
         if time.perf_counter() - t_start > budget_s * 0.5:
             break
-    # all cores: probe one step, then as many of the 3 + 10 as the budget allows
-    torch.set_num_threads(ncpu)
-    t0 = time.perf_counter()
-    probe = run(ncpu, 1, 1)
-    per = (time.perf_counter() - t0) / 2
-    left = budget_s - (time.perf_counter() - t_start)
-    k_all = int(max(1, min(steps, (left / max(per, 1e-3) - warm))))
-    w_all = warm if k_all == steps else 1
-    allc = run(ncpu, w_all, k_all) if left > 2 * per else probe
+    # all cores: in a child process with a hard time limit -- on a 256-thread host the 32-cube step thrashes (oneDNN / OpenMP
+    # oversubscription: one step was measured at minutes), and a hung baseline must not take the bench line with it
+    ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else ncpu
+    allc = {'value': None, 'cores': ncore, 'warmup': warm, 'steps': steps, 'note': None}
+    code = ('import sys, time, torch; sys.path.insert(0, %r); from oracle import unet_oracle as O\n'
+            'torch.set_num_threads(%d); spec = O.bank_spec("net4"); raw, flow = O.seeded_cubes(%d, 1, 3); x, xo = O.cubes_to_inputs(raw, flow)\n'
+            'sd = O.seeded_state_dict("net4", nf=32, padding=False, seed=0); opt = O.AdamState(O.param_names(sd))\n'
+            '[O.train_step(sd, spec, x, xo, opt) for _ in range(%d)]\n'
+            't0 = time.perf_counter(); [O.train_step(sd, spec, x, xo, opt) for _ in range(%d)]\n'
+            'print("RATE", %d * %d / (time.perf_counter() - t0))' % (ROOT, ncore, batch, warm, steps, batch, steps))
+    import subprocess
+    limit = max(10.0, min(40.0, budget_s - (time.perf_counter() - t_start)))
+    try:
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=limit)
+        for line in r.stdout.splitlines():
+            if line.startswith('RATE'):
+                allc['value'] = float(line.split()[1])
+        if allc['value'] is None:
+            allc['note'] = 'child failed: ' + r.stderr[-200:]
+    except subprocess.TimeoutExpired:
+        allc['note'] = 'did not finish %d+%d steps of %d cubes within %.0f s on %d threads (oversubscription)' % (warm, steps, batch, limit, ncore)
     # eval-mode forward (test.py:319-335) at the best thread count
     torch.set_num_threads(best[1])
     sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
@@ -145,11 +157,12 @@ def cpu_baseline(batch=32, warm=3, steps=10, sweep=(8, 16, 32), budget_s=45.0):
         O.score_pass(sd, spec, x, x_of, batch)
     ev = batch * steps / (time.perf_counter() - t0)
     return {'value': best[0], 'unit': 'cubes/s', 'cores': best[1], 'kind': 'port',
-            'all_cores': {'value': allc, 'cores': ncpu, 'warmup': w_all, 'steps': k_all},
+            'all_cores': allc,
             'eval_value': ev, 'eval_unit': 'cubes/s (eval-mode forward + per-cube scores)',
             'sample': 'SelfCompleteNet4 train step (fwd+bwd+Adam) on stock torch %s CPU ops, batch %d (BASELINE configs[0]), %d warm-up + '
-                      '%d timed steps per thread count; host has %d hardware threads; sweep (cubes/s): %s; all %d threads: %.0f '
-                      '(%d+%d steps)' % (torch.__version__, batch, warm, steps, ncpu, '; '.join(tried), ncpu, allc, w_all, k_all)}
+                      '%d timed steps per thread count; host has %d hardware threads (%d usable); sweep (cubes/s): %s; all usable threads: %s'
+                      % (torch.__version__, batch, warm, steps, ncpu, ncore, '; '.join(tried),
+                         ('%.0f cubes/s' % allc['value']) if allc['value'] else allc['note'])}
 
 
 def build_net(model, precision, dev):
