@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- MUST be imported before the .so: both link libamd
 #                       the dynamic linker bind our kernels to the same HIP runtime (one device context, shared streams)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'csrc', 'libvecvad_hip.so')
+LIB_PATH = os.environ.get('VV_LIB_PATH') or os.path.join(HERE, 'csrc', 'libvecvad_hip.so')      # VV_LIB_PATH: A/B experiments (tools/)
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

@@ -19,6 +19,12 @@
 //   Epilogue: each wave applies A^T . A to its xi half, the halves meet in LDS, then bias, NHWC store and the BatchNorm
 //   sum / sum-of-squares partials exactly like the direct kernel.
 #include "vv_common.h"
+// VV_EXP (compile-time, default 0): elimination switches used to find where the time goes (profiles/README.md, round 2) -- every
+// value other than 0 computes WRONG results: 1 = no MFMAs, 2 = no input transform, 3 = LDS commit of the first chunk only,
+// 4 = global loads of the first chunk only, 5 = no barriers.
+#ifndef VV_EXP
+#define VV_EXP 0
+#endif
 
 namespace {
 
@@ -98,29 +104,44 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   float4 sa, sb;
-  unsigned valid = 0;
   bool act = false;
+  // Everything about an item that does not depend on the chunk is computed ONCE: its validity (image row / image / column inside
+  // the tensor) and its byte offset inside the source tensor; a chunk only moves the scalar offset of the buffer load.  A
+  // concat input (VV_IN_CAT) switches to its second tensor at csplit: the offsets are rebuilt there (once per workgroup).
+  unsigned valid = 0;
+  unsigned voff[NIT];
+  const int tile = (img0 * H_ + y0) * H_ - 1;
+  const int q4 = (tid % Q) * 4;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int y = y0 + hyv[k];
+    const bool ok = (unsigned)y < (unsigned)H_ && (img0 + imv[k]) < s.B && pix[k] >= 0;
+    valid |= ok ? (1u << k) : 0u;
+  }
+  __amdgpu_buffer_rsrc_t rs;
+  int cur_second = -1, soff0 = 0;
+  auto set_source = [&](const bool second) {
+    const float* base = second ? s.p1 + s.co1 : s.p0 + s.co0;
+    const int cs = second ? s.cs1 : s.cs0;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    soff0 = second ? -s.csplit * 4 : 0;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      voff[k] = ((valid >> k) & 1u) ? (unsigned)((tile + pix[k]) * cs + q4) * 4u : 0x80000000u;
+    cur_second = second ? 1 : 0;
+  };
   auto issue = [&](const int c0) {
-    const int q = tid % Q;
-    const int c = c0 + q * 4;
-    valid = 0;
+    const int c = c0 + q4;
     act = (s.mode == VV_IN_ACT) || (s.mode == VV_IN_CAT && c < s.csplit);
     if (act) {
       sa = *reinterpret_cast<const float4*>(s.a + c);
       sb = *reinterpret_cast<const float4*>(s.b + c);
     }
-    const bool second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit)) != 0;
-    const float* base = second ? s.p1 + s.co1 - s.csplit : s.p0 + s.co0;
-    const int cs = second ? s.cs1 : s.cs0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
-    const int tile = (img0 * H_ + y0) * H_ - 1;
+    const int second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit));
+    if (second != cur_second) set_source(second != 0);
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int y = y0 + hyv[k];
-      const bool ok = (unsigned)y < (unsigned)H_ && (img0 + imv[k]) < s.B && pix[k] >= 0;
-      const unsigned off = ok ? (unsigned)((tile + pix[k]) * cs + c) * 4u : 0x80000000u;
-      valid |= ok ? (1u << k) : 0u;
-      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[k], c0 * 4 + soff0, 0);
       r[k] = make_float4(v.x, v.y, v.z, v.w);
     }
     const int so = (c0 >> 3) * 2 * Cout * 16;
@@ -130,16 +151,16 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       rb[k] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](const int bo) {                        // bo: float4 offset of the destination staging buffer
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
-      if (slot[k] >= 0) {
+      if (NITEMS % WN == 0 || k < NIT - 1 || slot[k] >= 0) {      // only the last item of a ragged item count can be void
         float4 v = r[k];
         if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
-        lds4[slot[k]] = v;
+        lds4[bo + slot[k]] = v;
       }
 #pragma unroll
-    for (int k = 0; k < NBT; ++k) lds4[A4 + tid + k * WN] = rb[k];
+    for (int k = 0; k < NBT; ++k) lds4[bo + A4 + tid + k * WN] = rb[k];
   };
 
   // ---- this lane's tile and its patch origin in LDS
@@ -148,8 +169,8 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   const int tyl = trem / TPI, tx = trem % TPI;
   // patch pixel (a, b): halo row 2*tyl + a, halo column 2*tx + b -> plane (b & 1), slot tx + (b >> 1)
   const int pbase = ((tim * HH + 2 * tyl) * HW + tx) * S4 + half;
-  auto patch = [&](const int a, const int b) -> v4f {
-    return ldsA[pbase + (a * HW + (b & 1) * HWH + (b >> 1)) * S4];
+  auto patch = [&](const int bo, const int a, const int b) -> v4f {
+    return ldsA[bo + pbase + (a * HW + (b & 1) * HWH + (b >> 1)) * S4];
   };
 
   v16f acc[2][4];
@@ -160,12 +181,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[x][n][i] = 0.f;
 
-  issue(0);
-  for (int c0 = 0; c0 < CinP; c0 += CK) {
-    if (c0) __syncthreads();            // every wave finished reading the previous chunk
-    commit();
-    __syncthreads();
-    if (c0 + CK < CinP) issue(c0 + CK);
+  auto compute = [&](const int bo) {
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
       // B^T rows: xi 0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3   ->   R = d[a1] + sg * d[a2]   (wave-uniform a1, a2, sg)
@@ -175,23 +191,54 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       v4f R[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const v4f d1 = patch(a1, b), d2 = patch(a2, b);
+#if VV_EXP == 2
+        R[b] = patch(bo, a1, b);
+#else
+        const v4f d1 = patch(bo, a1, b), d2 = patch(bo, a2, b);
         R[b] = d1 + sg * d2;
+#endif
       }
       v4f V[4];
+#if VV_EXP == 2
+      V[0] = R[0]; V[1] = R[1]; V[2] = R[2]; V[3] = R[3];
+#else
       V[0] = R[0] - R[2];
       V[1] = R[1] + R[2];
       V[2] = R[2] - R[1];
       V[3] = R[1] - R[3];
+#endif
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const v4f u = ldsB[((xi * 4 + n) * 2 + half) * 32 + l31];
+        const v4f u = ldsB[bo + ((xi * 4 + n) * 2 + half) * 32 + l31];
+#if VV_EXP == 1
+        acc[x][n][0] += V[n].x * u.x + V[n].y * u.y + V[n].z * u.z + V[n].w * u.w;
+#else
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u.x, acc[x][n], 0, 0, 0);
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u.y, acc[x][n], 0, 0, 0);
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u.z, acc[x][n], 0, 0, 0);
         acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u.w, acc[x][n], 0, 0, 0);
+#endif
       }
     }
+  };
+
+  issue(0);
+  for (int c0 = 0; c0 < CinP; c0 += CK) {
+#if VV_EXP != 5
+    if (c0) __syncthreads();            // every wave finished reading the previous chunk
+#endif
+#if VV_EXP == 3
+    if (c0 == 0)
+#endif
+    commit(0);
+#if VV_EXP != 5
+    __syncthreads();
+#endif
+#if VV_EXP == 4
+    if (false)
+#endif
+    if (c0 + CK < CinP) issue(c0 + CK);
+    compute(0);
   }
 
   // ---- epilogue.  Output transform of this wave's xi half:  T[x][q] = sum_nu M[x][nu] A[nu][q],  A^T = [1 1 1 0; 0 1 -1 -1]
