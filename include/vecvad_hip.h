@@ -80,6 +80,10 @@ typedef struct vv_view {
  * pooled / frame-erased inputs written by vv_pool_act / vv_cube_erase with their bf16 switch.  coff / cstride / csplit stay in
  * elements, gstride in floats. */
 #define VV_CONV_ALLSRC_BF16 16
+/* VV_CONV3 launches of vv_conv_mfma / vv_conv_wino: out = max(conv + bias, 0).  The eval-mode path (test.py:255-257,312-345): with
+ * running-statistics BatchNorm the affine map is a constant of the model, so vv_fold_bn folds it into the filter and the bias once per
+ * loaded model, the producing convolution applies the ReLU, and every consumer reads its input as VV_IN_PLAIN. */
+#define VV_CONV_RELU 32
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */
@@ -358,6 +362,20 @@ int vv_pack_conv2d(const float* w, float* packed, int32_t taps, int32_t K, int32
  * (what 'bilinear' meant under the PyTorch 0.3 the reference's README pins for the flow extraction) */
 int vv_upsample4(const float* src, float* dst, int32_t BC, int32_t H, int32_t W, int32_t bilinear, float scale,
                  vv_stream stream);
+
+/* ---- eval mode: nn.BatchNorm2d with running statistics folded into the convolution in front of it (model/unet.py:9-16 under
+ * net.eval(), test.py:255-257).  For every table entry and group g, with a[c] = gamma[c] / sqrt(running_var[c] + eps) (float64):
+ *   folded[w_off + c*row + k] = a[c] * params[w_off + c*row + k]         (row = Cin*9 filter elements per output channel)
+ *   folded[b_off + c]         = a[c] * (params[b_off + c] - running_mean[c]) + beta[c]
+ * Offsets are in floats inside one group's block; params / folded have params_gstride / folded_gstride floats per group, bufs
+ * (running statistics) bufs_gstride.  Entries the table does not name are left untouched (copy them first). */
+typedef struct vv_fold_entry {
+  int64_t w_off, b_off, g_off, beta_off; /* into the parameter block */
+  int64_t rm_off, rv_off;                /* into the buffer block */
+  int32_t cout, row;
+} vv_fold_entry;
+int vv_fold_bn(const vv_fold_entry* table_dev, int32_t nentries, int32_t G, const float* params, int64_t params_gstride,
+               const float* bufs, int64_t bufs_gstride, float eps, float* folded, int64_t folded_gstride, vv_stream stream);
 
 /* ---- FlowNet2 plumbing between the sub-networks (FlowNet2_src/models/flownet2.py:65-136), NHWC, no temporaries ----
  * vv_flownet_prep: inputs [B,3,2,H,W] fp32 (0..rgb_max) -> rgb_mean over (frame, H, W) per image and colour (:66-67),

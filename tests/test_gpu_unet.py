@@ -433,3 +433,47 @@ def test_winograd_weight_gradient_matches_direct(H, Cin, Cout, B):
     for (gi, co, ci, ky, kx) in ((0, 0, 0, 0, 0), (1, Cout - 1, Cin - 1, 2, 1), (0, 5, 7, 1, 1), (1, 17, 3, 0, 2)):
         ref = (pad[gi, :, ky:ky + H, kx:kx + H, ci] * dyd[gi, :, :, :, co]).sum().item()
         assert abs(outs[1][gi, co, ci, ky, kx].item() - ref) <= 2e-4 * scale + 1e-4 * abs(ref), (gi, co, ci, ky, kx)
+
+
+def test_eval_fold_matches_unfolded_path_and_tracks_updates(monkeypatch):
+    """Eval mode (test.py:255-257,312-345) runs on the folded model -- BatchNorm folded into filter + bias once per model state
+    (vv_fold_bn), ReLU in the conv epilogue (VV_CONV_RELU), plain loads -- instead of the train-mode kernel family with running
+    statistics (VV_EVAL_FOLD=0).  Both paths against each other (fp32 re-association of a*(W x): rel <= 2e-5 on per-cube scores) and
+    the folded model must follow every state change: a train step (raw-pointer writes by Adam / BatchNorm), load_state_dict, and
+    an in-place edit of a running statistic through the module's buffer."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    raw, flow = O.seeded_cubes(37, 1, 4)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    x, x_of = O.cubes_to_inputs(raw, flow)
+
+    def scores(fold, mutate):
+        monkeypatch.setenv('VV_EVAL_FOLD', '1' if fold else '0')
+        net, sd, _ = _build('net4', False)
+        assert net.bank().eval_fold == fold
+        tr = FusedTrainer(net)
+        out = []
+        net.eval()
+        out.append([t.clone() for t in tr.score_cubes(rawd, flowd)])
+        net.train()
+        tr.step_cubes(rawd, flowd, torch.arange(37, device='cuda'))            # Adam + running statistics move
+        net.eval()
+        out.append([t.clone() for t in tr.score_cubes(rawd, flowd)])
+        with torch.no_grad():
+            net.inc0.conv.conv[1].running_var.mul_(1.5)                             # in-place edit through the module
+        out.append([t.clone() for t in tr.score_cubes(rawd, flowd)])
+        net.load_state_dict(sd)                                                     # back to the seeded model
+        out.append([t.clone() for t in tr.score_cubes(rawd, flowd)])
+        return out, sd
+
+    a, sd = scores(True, True)
+    b, _ = scores(False, True)
+    for sa, sb in zip(a, b):
+        for ta, tb in zip(sa, sb):
+            torch.testing.assert_close(ta, tb, rtol=2e-5, atol=0)
+    assert not torch.allclose(a[0][0], a[1][0], rtol=1e-4)      # the train step changed the scores
+    assert not torch.allclose(a[1][0], a[2][0], rtol=1e-6)      # ... so did the edited running variance
+    torch.testing.assert_close(a[3][0], a[0][0], rtol=0, atol=0)  # ... and load_state_dict restores them bit for bit
+    rs, os_ = O.score_pass(sd, O.bank_spec('net4'), x, x_of, 37)
+    np.testing.assert_allclose(a[0][0].cpu().numpy(), rs, rtol=1e-3)
+    np.testing.assert_allclose(a[0][1].cpu().numpy(), os_, rtol=1e-3)

@@ -25,6 +25,7 @@ BNBWD_PARTIALS_PER_CUBE = 2
 BNBWD_DA_BF16 = 4
 CONV_OUT_BF16 = 8       # VV_CONV_OUT_BF16
 CONV_ALLSRC_BF16 = 16   # VV_CONV_ALLSRC_BF16
+CONV_RELU = 32          # VV_CONV_RELU: eval mode, BatchNorm folded into the filter, ReLU in the epilogue
 BNBWD_Y_BF16 = 8
 WGRAD_X_BF16 = 2
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
@@ -53,6 +54,11 @@ class WgradParams(C.Structure):
 
 class PackEntry(C.Structure):
     _fields_ = [('src_off', c_i64), ('dst_off', c_i64), ('mode', c_i32), ('K', c_i32), ('KP', c_i32), ('N', c_i32)]
+
+
+class FoldEntry(C.Structure):
+    _fields_ = [('w_off', c_i64), ('b_off', c_i64), ('g_off', c_i64), ('beta_off', c_i64), ('rm_off', c_i64), ('rv_off', c_i64),
+                ('cout', c_i32), ('row', c_i32)]
 
 
 class BnBwdParams(C.Structure):
@@ -124,6 +130,7 @@ _SIGS = {
     'vv_correlation_nhwc': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_f32, c_vp]),
     'vv_resample2d_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_channelnorm_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'vv_fold_bn': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_vp]),
     'vv_flownet_prep_workspace_bytes': (C.c_int64, [c_i32]),
     'vv_flownet_prep': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp]),
     'vv_warp_pack12': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp]),

@@ -247,17 +247,37 @@ class UNetBank:
             wmx = max(wmx, KP * N)
         self.pack_table_w = torch.frombuffer(bytearray(bytes(wents)), dtype=torch.uint8).to(d)
         self.pack_w_n, self.pack_w_max = len(lay.pkw), wmx
+        # ---- eval mode (test.py:255-257,312-345; train.py:413-427): running-statistics BatchNorm is a constant affine map, so it is
+        # folded into the filter + bias of the convolution in front of it ONCE per model state (vv_fold_bn -> params_eval ->
+        # packed_eval), the producing conv applies the ReLU (VV_CONV_RELU) and every consumer reads plain values: no per-forward
+        # weight packing, no BatchNorm launches, no activation arithmetic on the consumers' load path.  fp32 only: the mixed mode keeps
+        # the rounding points its oracle restates.  VV_EVAL_FOLD=0 keeps the train-mode kernel family with running statistics.
+        self.eval_fold = (not self.cflag) and os.environ.get('VV_EVAL_FOLD', '1') != '0'
+        self.eval_path = ('BatchNorm folded into filter + bias once per model state (vv_fold_bn), ReLU in the conv epilogue, plain loads'
+                          if self.eval_fold else 'train-mode kernel family with running statistics')
+        self.params_eval = self.packed_eval = None
+        self._eval_key = None
+        self._state_ver = 0          # bumped by everything that writes parameters / running statistics through raw pointers
+        fents = (L.FoldEntry * len(lay.convs))()
+        for i, l in enumerate(lay.convs):
+            fents[i] = L.FoldEntry(lay.p['c%d.w' % l.idx][0], lay.p['c%d.b' % l.idx][0], lay.p['c%d.g' % l.idx][0],
+                                   lay.p['c%d.beta' % l.idx][0], lay.b['c%d.rm' % l.idx][0], lay.b['c%d.rv' % l.idx][0],
+                                   l.cout, l.cin * 9)
+        self.fold_table = torch.frombuffer(bytearray(bytes(fents)), dtype=torch.uint8).to(d)
+        self.ab_ident = torch.stack([torch.ones(G, lay.cmax), torch.zeros(G, lay.cmax)]).to(d)      # a = 1, b = 0: relu(1*y + 0) = y for y >= 0
 
     def to(self, device):
         device = torch.device(device)
         if device == self.device:
             return self
-        for n in ('params', 'bufs', 'grads', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table', 'pack_table_w'):
+        for n in ('params', 'bufs', 'grads', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table', 'pack_table_w', 'fold_table', 'ab_ident'):
             setattr(self, n, getattr(self, n).to(device))
         if self.adam_m is not None:
             self.adam_m, self.adam_v = self.adam_m.to(device), self.adam_v.to(device)
         self.device = device
         self.ws = {}
+        self.params_eval = self.packed_eval = None
+        self._eval_key = None
         return self
 
     def param_view(self, g, key):
@@ -323,7 +343,8 @@ class UNetBank:
                 gs.append(2.0 * self.lambda_of / (B * n_of * OF_C * HWp))
         ws.gscale.copy_(torch.tensor(gs))
         ws.n_raw, ws.n_of = n_raw, n_of
-        ws.fwd = {True: self._plan_forward(ws, B, True), False: self._plan_forward(ws, B, False)}
+        ws.fwd = {True: self._plan_forward(ws, B, True),
+                  False: self._plan_eval(ws, B) if self.eval_fold else self._plan_forward(ws, B, False)}
         ws.bwd = None
         return ws
 
@@ -403,6 +424,91 @@ class UNetBank:
                              ws.flow.shape[2], 0, self._p(self.tsrc, g0), self._p(self.tcoff, g0), ws.out4.data_ptr(),
                              ws.score.data_ptr(), ws.gscale.data_ptr() if train else None,
                              ws.dout4.data_ptr() if train else None)
+        P.keep.append(op)
+        P.add(lib.vv_outconv_fwd, (C.byref(op),), 'outconv')
+        return P
+
+    def mark_dirty(self):
+        """Parameters or running statistics were written by a kernel (Adam, train-mode BatchNorm): torch's version counters do not
+        see raw-pointer writes, so the folded eval model is invalidated explicitly."""
+        self._state_ver += 1
+
+    def prepare_eval(self):
+        """(Re)build the folded filters / biases and their packed panels when the parameters or running statistics changed since the
+        last eval-mode forward (tensor version counters: Adam steps, load_state_dict, train-mode forwards all bump them)."""
+        key = (self._state_ver, self.params._version, self.bufs._version, self.params.data_ptr())
+        if self._eval_key == key:
+            return
+        lib, lay, G = self.lib, self.lay, self.G
+        if self.params_eval is None:
+            self.params_eval = torch.empty_like(self.params)
+            self.packed_eval = torch.zeros_like(self.packed)
+        st = self._stream()
+        self.params_eval.copy_(self.params)          # transposed convs, 1x1 output conv: unchanged
+        L.check(lib.vv_fold_bn(self.fold_table.data_ptr(), len(lay.convs), G, self.params.data_ptr(), lay.U, self.bufs.data_ptr(),
+                               lay.UB, 1e-5, self.params_eval.data_ptr(), lay.U, st), 'fold_bn')
+        L.check(lib.vv_pack_weights(self.pack_table.data_ptr(), self.pack_n, G, self.params_eval.data_ptr(), lay.U,
+                                    self.packed_eval.data_ptr(), lay.UP, self.pack_max, st), 'pack (eval)')
+        if self.wino:
+            L.check(lib.vv_pack_wino(self.pack_table_w.data_ptr(), self.pack_w_n, G, self.params_eval.data_ptr(), lay.U,
+                                     self.packed_eval.data_ptr(), lay.UP, self.pack_w_max, st), 'pack_wino (eval)')
+        self._eval_key = key
+
+    def _plan_eval(self, ws, B):
+        """Eval-mode forward on the folded model (see _alloc_state): cube_erase, 14 convs (+3 pools, +3 transposed convs), fused
+        1x1 conv + score.  33 launches fewer arithmetic on every load path than the train-mode plan; same tensors otherwise."""
+        lib, lay, Ga, g0 = self.lib, self.lay, self.Ga, self.g0
+        U, UP = lay.U, lay.UP
+        if self.params_eval is None:
+            self.params_eval = torch.empty_like(self.params)
+            self.packed_eval = torch.zeros_like(self.packed)
+        P = _Plan()
+        pbase, kbase = self._p(self.params_eval, g0 * U), self._p(self.packed_eval, g0 * UP)
+        abg = lay.cmax
+        one, zero = self._p(self.ab_ident[0], g0 * abg), self._p(self.ab_ident[1], g0 * abg)
+
+        def src(l):
+            if l.mode == L.IN_CUBE:
+                return (L.IN_PLAIN, L.view(ws.erased, l.cinp, 0, ws.erased.stride(0)), None, None, L.NULL_VIEW, 0)
+            if l.mode == L.IN_POOL:
+                pb = ws.pooled[l.idx]
+                return (L.IN_PLAIN, L.view(pb, l.cin, 0, pb.stride(0)), None, None, L.NULL_VIEW, 0)
+            if l.mode == L.IN_ACT:
+                y = ws.y[lay.convs[l.src].idx]
+                return (L.IN_PLAIN, L.view(y, lay.convs[l.src].cout, 0, y.stride(0)), None, None, L.NULL_VIEW, 0)
+            sk = lay.convs[l.skip]
+            y, t = ws.y[sk.idx], ws.t[l.up]          # concat: the skip tensor is already activated -> identity (a, b)
+            return (L.IN_CAT, L.view(y, sk.cout, 0, y.stride(0)), one, zero, L.view(t, t.shape[2], 0, t.stride(0)), sk.cout)
+
+        P.add(lib.vv_cube_erase, (Ga, B * HW0 * HW0, ws.cube.shape[2], lay.convs[0].cinp, ws.cube.data_ptr(),
+                                  self._p(self.chmap, g0 * lay.convs[0].cinp), ws.erased.data_ptr(), ws.erased.stride(0), 0), 'cube_erase')
+        for l in lay.convs:
+            if l.mode == L.IN_CAT:
+                sidx, H, ci, co = lay.convT[l.up]
+                y, t = ws.y[sidx], ws.t[l.up]
+                cp = L.ConvParams(L.CONVT_FWD, L.IN_PLAIN, Ga, B, H, H, ci, ci, co, L.view(y, ci, 0, y.stride(0)), None, None, 0,
+                                  L.NULL_VIEW, 0, 0, None, kbase + 4 * lay.pk['t%d.f' % l.up][0], UP,
+                                  pbase + 4 * lay.p['t%d.b' % l.up][0], U, L.view(t, co, 0, t.stride(0)), None)
+                P.keep.append(cp)
+                P.add(lib.vv_conv_mfma, (C.byref(cp),), 'convT%d' % l.up)
+            if l.mode == L.IN_POOL:
+                sl = lay.convs[l.src]
+                ys, pb = ws.y[sl.idx], ws.pooled[l.idx]
+                P.add(lib.vv_pool_act, (Ga, B, l.H, l.H, sl.cout, ys.data_ptr(), ys.stride(0), one, zero, abg, pb.data_ptr(),
+                                        pb.stride(0), 0), 'pool%d' % l.idx)
+            mode, s0, a, b, s1, csplit = src(l)
+            y = ws.y[l.idx]
+            panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
+            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, L.CONV_RELU, None,
+                              kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U, L.view(y, l.cout, 0, y.stride(0)), None)
+            P.keep.append(cp)
+            P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
+        last = lay.convs[-1]
+        y = ws.y[last.idx]
+        op = L.OutconvParams(Ga, B, HW0 * HW0, self.nf, y.data_ptr(), y.stride(0), one, zero, abg,
+                             pbase + 4 * lay.p['o.w'][0], pbase + 4 * lay.p['o.b'][0], U, self._p(self.oc, g0), ws.cube.data_ptr(),
+                             ws.cube.shape[2], 0, ws.flow.data_ptr(), ws.flow.shape[2], 0, self._p(self.tsrc, g0),
+                             self._p(self.tcoff, g0), ws.out4.data_ptr(), ws.score.data_ptr(), None, None)
         P.keep.append(op)
         P.add(lib.vv_outconv_fwd, (C.byref(op),), 'outconv')
         return P
@@ -614,9 +720,12 @@ class UNetBank:
 
     def forward(self, ws, train):
         """Runs the grouped forward.  train=True: batch statistics, running-stat update, dout4 = d(loss)/d(out)."""
+        if not train and self.eval_fold:
+            self.prepare_eval()
         ws.fwd[bool(train)].run(self._stream())
         if train:
             self.nbt[self.g0:self.g0 + self.Ga] += 1
+            self.mark_dirty()
         return ws.score
 
     def backward(self, ws):
@@ -650,6 +759,7 @@ class UNetBank:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
         self.adam_t += 1
+        self.mark_dirty()
         bc1 = 1.0 - beta1 ** self.adam_t
         bc2 = 1.0 - beta2 ** self.adam_t
         g = self.grads if grads is None else grads

@@ -980,6 +980,37 @@ extern "C" int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, co
   return VV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ eval mode: fold BatchNorm
+__global__ void __launch_bounds__(VV_WG)
+fold_bn_kernel(const vv_fold_entry* __restrict__ table, const float* __restrict__ params, const int64_t pg,
+               const float* __restrict__ bufs, const int64_t bg, const float eps, float* __restrict__ folded, const int64_t fg) {
+  const vv_fold_entry e = table[blockIdx.y];
+  const int g = blockIdx.z;
+  const float* P = params + (int64_t)g * pg;
+  const float* Bf = bufs + (int64_t)g * bg;
+  float* F = folded + (int64_t)g * fg;
+  const int64_t n = (int64_t)e.cout * e.row;
+  for (int64_t i = (int64_t)blockIdx.x * VV_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * VV_WG) {
+    const int c = (int)(i / e.row);
+    const double a = (double)P[e.g_off + c] / sqrt((double)Bf[e.rv_off + c] + (double)eps);
+    F[e.w_off + i] = (float)a * P[e.w_off + i];
+    if (i < e.cout) {            // thread i < cout also writes bias i
+      const double ai = (double)P[e.g_off + i] / sqrt((double)Bf[e.rv_off + i] + (double)eps);
+      F[e.b_off + i] = (float)(ai * ((double)P[e.b_off + i] - (double)Bf[e.rm_off + i]) + (double)P[e.beta_off + i]);
+    }
+  }
+}
+
+extern "C" int vv_fold_bn(const vv_fold_entry* table_dev, int32_t nentries, int32_t G, const float* params, int64_t params_gstride,
+                          const float* bufs, int64_t bufs_gstride, float eps, float* folded, int64_t folded_gstride,
+                          vv_stream stream) {
+  if (!table_dev || !params || !bufs || !folded || nentries <= 0 || G <= 0) return VV_ERR_BAD_ARG;
+  VV_LAUNCH(fold_bn_kernel, dim3(64, nentries, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, params, params_gstride, bufs,
+            bufs_gstride, eps, folded, folded_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
 extern "C" const char* vv_version(void) { return "vecvad_hip 0.1 (gfx950)"; }
 
 extern "C" const char* vv_status_string(int status) {

@@ -247,6 +247,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   __syncthreads();                      // all MFMA-phase LDS reads done: LDS becomes the exchange buffer
   float* ex = lds + (tg * 4) * 16 * 64 + lane;
   float bias = 0.f, s1 = 0.f, s2 = 0.f;
+  const bool relu = (p.pad0 & VV_CONV_RELU) != 0;
   if (xh == 0 && p.bias) bias = p.bias[(int64_t)g * p.bias_gstride + co0 + l31];
   float y4[16][4];
 #pragma unroll
@@ -280,7 +281,8 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         float* o = outg + ((int64_t)(img * H_ + oy) * H_ + ox) * ocs + co0 + l31;
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) {
-          const float v = y4[i][pq] + ex[(pq * 16 + i) * 64] + bias;
+          float v = y4[i][pq] + ex[(pq * 16 + i) * 64] + bias;
+          if (relu) v = fmaxf(v, 0.f);          // VV_CONV_RELU: BatchNorm folded into the filter (eval mode), ReLU here
           o[((pq >> 1) * H_ + (pq & 1)) * ocs] = v;
           s1 += v; s2 = fmaf(v, v, s2);
         }

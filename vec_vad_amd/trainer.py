@@ -134,6 +134,7 @@ class FusedTrainer:
         ts = ([bank.params] if params else []) + ([bank.bufs, bank.nbt] if buffers else [])
         for t in ts:
             dist.broadcast(t, src=src, group=self.group)
+        bank.mark_dirty()
 
     # ---- plan execution with optional per-launch HIP events and a mid-plan callback
     def _run(self, plan, stream, after=None):
@@ -196,6 +197,7 @@ class FusedTrainer:
         stream = bank._stream()
         self._run(ws.fwd[True], stream)
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+        bank.mark_dirty()
         if ws.bwd is None:
             ws.bwd = bank._plan_backward(ws, ws.B)
         if self.overlap:
@@ -259,6 +261,7 @@ class FusedTrainer:
             ws = bank.set_input_cubes(raw_u8, flow, idx)
             self._run(ws.fwd[True], bank._stream())
             bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+            bank.mark_dirty()
             if ws.bwd is None:
                 ws.bwd = bank._plan_backward(ws, ws.B)
             self._run(ws.bwd, bank._stream())
