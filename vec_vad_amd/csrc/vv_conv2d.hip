@@ -436,7 +436,24 @@ conv3x3_n2_split_kernel(const float* __restrict__ src, const int scs, const int 
       if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
       const float4* pa = reinterpret_cast<const float4*>(src + ((int64_t)(img * H + yy) * W + xx) * scs);
       const float4* pw = wq4 + (int64_t)t * C4P * 2;
-      for (int k = sub; k < C4; k += LPP) {
+      // four channel groups per trip, their 12 loads issued before the first multiply-add: the loop is a chain of L2 round trips
+      // (the map is small), one load in flight per lane made it 4x slower
+      int k = sub;
+      for (; k + 3 * LPP < C4; k += 4 * LPP) {
+        float4 v[4], w0[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[u] = pa[k + u * LPP];
+          w0[u] = pw[2 * (k + u * LPP)];
+          w1[u] = pw[2 * (k + u * LPP) + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a0 = fmaf(v[u].w, w0[u].w, fmaf(v[u].z, w0[u].z, fmaf(v[u].y, w0[u].y, fmaf(v[u].x, w0[u].x, a0))));
+          a1 = fmaf(v[u].w, w1[u].w, fmaf(v[u].z, w1[u].z, fmaf(v[u].y, w1[u].y, fmaf(v[u].x, w1[u].x, a1))));
+        }
+      }
+      for (; k < C4; k += LPP) {
         const float4 v = pa[k], w0 = pw[2 * k], w1 = pw[2 * k + 1];
         a0 = fmaf(v.w, w0.w, fmaf(v.z, w0.z, fmaf(v.y, w0.y, fmaf(v.x, w0.x, a0))));
         a1 = fmaf(v.w, w1.w, fmaf(v.z, w1.z, fmaf(v.y, w1.y, fmaf(v.x, w1.x, a1))));
@@ -540,8 +557,11 @@ extern "C" int vv_conv3x3_n2(const float* src, int32_t src_cstride, int32_t B, i
     const int tilesY = (H + 7) / 8, tilesX = (W + 31) / 32;
     VV_LAUNCH(conv3x3_n2_kernel, dim3(B * tilesY * tilesX), dim3(VV_WG), 0, st, src, src_cstride, B, H, W, Cin, wq, C4P, bias,
               slope, out + out_coff, out_cstride, tilesX, tilesY);
-  } else if (npix >= 4096) {
+  } else if (npix >= 20000) {
     VV_LAUNCH(conv3x3_n2_split_kernel<8>, dim3((unsigned)((npix * 8 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,
+              src_cstride, B, H, W, Cin, wq, C4P, bias, slope, out + out_coff, out_cstride);
+  } else if (npix >= 4096) {                // H/8: 7168 pixels x up to 386 channels -- 32 lanes per pixel fill the chip
+    VV_LAUNCH(conv3x3_n2_split_kernel<32>, dim3((unsigned)((npix * 32 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,
               src_cstride, B, H, W, Cin, wq, C4P, bias, slope, out + out_coff, out_cstride);
   } else {
     VV_LAUNCH(conv3x3_n2_split_kernel<64>, dim3((unsigned)((npix * 64 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,

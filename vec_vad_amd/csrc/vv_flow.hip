@@ -94,19 +94,22 @@ correlation_k1_kernel(const float* __restrict__ in1, const float* __restrict__ i
 //
 //   out[y][x][ti*21 + tj] = leaky( 1/C * sum_c f1[y][x][c] * f2[y + 2(ti-10)][x + 2(tj-10)][c] )
 //
-// fp32 VALU kernel (an MFMA Gram-matrix formulation would throw away 78 % of each 32x32 block).  One workgroup = one
-// output row y and DYB of the 21 row displacements; a thread owns two same-parity columns (x, x+2) and all 21 column
-// displacements of one row displacement: 42 accumulators, whose 22-wide window of f2 is shared by both columns.
-// Both maps go through LDS in 32-channel chunks as float4 planes [c4][pos mod 4][pos div 4] (+1 float4 of plane padding):
-// with that split a wave's ds_read_b128 of "position 4j + const" walks consecutive float4 slots (conflict free in the
-// hardware's 16-lane groups) and the staging writes of 8 consecutive channel groups land in 8 different bank quads.
-// Zero padding = LDS slots that are never written.  The next chunk's global loads fly (in registers) under the FMAs.
+// fp32 VALU kernel (an MFMA Gram-matrix formulation would throw away 2/3 - 3/4 of every 16x16 / 32x32 block of the 21-wide band,
+// and the fp32 matrix instruction runs at the vector rate anyway).  One workgroup = one output row y and DYB of the 21 row
+// displacements, one row displacement per 64-lane wave (two per wave at W = 64); a thread owns two same-parity columns (x, x+2)
+// and all 21 column displacements: 42 accumulators whose 22-wide window of f2 is shared by both columns -> 24 ds_read_b128 per
+// 168 multiply-adds.  Both maps go through LDS in 16-channel chunks as float4 planes [c4][pos mod 4][pos div 4] (+1 float4 of
+// plane padding): a wave's ds_read_b128 of "position 4j + const" walks consecutive float4 slots (conflict free in the
+// hardware's 16-lane groups) and the staging writes of the 4 channel groups of one position land in different bank quads.
+// Zero padding = LDS slots that are never written (zero-filled once); a displaced row that lies outside the image is all
+// padding, its wave skips the arithmetic and stores zeros.  58 KB of LDS and <= 128 registers: two workgroups per CU, the next
+// chunk's global loads fly (in registers) under the multiply-adds.  Offsets are arithmetic in (thread, item): no private arrays.
 template <int W_>
-__global__ void __launch_bounds__(VV_WG, 1)
+__global__ void __launch_bounds__(VV_WG, 2)
 correlation_nhwc_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const int cs, const int C,
                         const int H, float* __restrict__ out, const int ocs, const int ocoff, const float slope,
                         const int NG) {
-  constexpr int D = 21, MD = 20, CK = 32, NC4 = CK / 4;
+  constexpr int D = 21, MD = 20, CK = 16, NC4 = CK / 4;
   constexpr int DPW = 128 / W_;                 // row displacements per wave
   constexpr int DYB = 4 * DPW;                  // ... per workgroup
   constexpr int LPD = W_ / 2;                   // lanes per row displacement
@@ -115,12 +118,12 @@ correlation_nhwc_kernel(const float* __restrict__ f1, const float* __restrict__ 
   constexpr int Q1 = (NJ + 15) / 16 * 16;
   constexpr int P2 = 4 * QS + 1, P1 = 4 * Q1 + 1;                 // float4 per channel-group plane (+1: bank shift)
   constexpr int F1SZ = NC4 * P1, F2SZ = NC4 * P2;                 // float4 per tile
-  constexpr int N1 = W_ * NC4, N2 = DYB * W_ * NC4;               // float4 items per chunk
-  constexpr int NIT = (N1 + N2) / VV_WG;
-  static_assert((N1 + N2) % VV_WG == 0 && N1 % VV_WG == 0, "item split");
+  constexpr int PER = W_ * NC4;                                   // float4 items per staged row and chunk
+  constexpr int NIT = (1 + DYB) * PER / VV_WG;
+  static_assert(((1 + DYB) * PER) % VV_WG == 0 && (PER % VV_WG == 0 || VV_WG % PER == 0), "item split");
   extern __shared__ float4 cl[];
-  float4* F1 = cl;
-  float4* F2 = cl + F1SZ;
+  const float4* F1 = cl;
+  const float4* F2 = cl + F1SZ;
 
   const int y = blockIdx.x / NG, grp = blockIdx.x % NG, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,56 +135,102 @@ correlation_nhwc_kernel(const float* __restrict__ f1, const float* __restrict__ 
 
   for (int e = tid; e < F1SZ + DYB * F2SZ; e += VV_WG) cl[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // staging items: [0, N1) the f1 row, then DYB displaced f2 rows; consecutive threads = consecutive channel groups
+  // staging item k of this thread: it = tid + k * 256 -> staged row (k * 256) / PER (0 = f1, 1.. = displaced f2 row), element
+  // rem = tid + (k * 256) % PER of that row: channel group rem % NC4 of column rem / NC4
   float4 r[NIT];
-  int ldsoff[NIT];
-  const float* gsrc[NIT];
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int it = tid + k * VV_WG;
-    const int c4 = it % NC4, x = (it / NC4) % W_, row = it / (NC4 * W_);      // row 0 = f1, 1.. = f2 slot row-1
-    if (row == 0) {
-      ldsoff[k] = c4 * P1 + (x & 3) * Q1 + (x >> 2);
-      gsrc[k] = p1 + ((int64_t)y * W_ + x) * cs + c4 * 4;
-    } else {
-      const int sl = row - 1, t2 = grp * DYB + sl;
-      const int yy = y + 2 * (t2 - MD / 2);
-      const int pos = x + MD;
-      ldsoff[k] = F1SZ + sl * F2SZ + c4 * P2 + (pos & 3) * QS + (pos >> 2);
-      gsrc[k] = (t2 < D && (unsigned)yy < (unsigned)H) ? p2 + ((int64_t)yy * W_ + x) * cs + c4 * 4 : nullptr;
-    }
-  }
+  auto rowvalid = [&](const int row) -> bool {          // uniform over the workgroup
+    if (row == 0) return true;
+    const int t2 = grp * DYB + row - 1;
+    const int yy = y + 2 * (t2 - MD / 2);
+    return t2 < D && (unsigned)yy < (unsigned)H;
+  };
+  // branch-free staging: a displaced row outside the image is loaded from a clamped (valid) address and zeroed by a select when
+  // it is committed -- per-row branches made the compiler re-roll the rows into a loop that indexes r[] dynamically (scratch)
   auto issue = [&](const int c0) {
-#pragma unroll
-    for (int k = 0; k < NIT; ++k)
-      if (gsrc[k]) r[k] = *reinterpret_cast<const float4*>(gsrc[k] + c0);
+    vv_static_for<0, NIT>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int row = (k * VV_WG) / PER;
+      const int rem = tid + (k * VV_WG) % PER;
+      const int c4 = rem % NC4, x = rem / NC4;
+      int yy = row == 0 ? y : y + 2 * (grp * DYB + row - 1 - MD / 2);
+      yy = min(max(yy, 0), H - 1);
+      const float* src = (row == 0 ? p1 : p2) + ((int64_t)yy * W_ + x) * cs + c4 * 4 + c0;
+      r[k] = *reinterpret_cast<const float4*>(src);
+    });
   };
   auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NIT; ++k)
-      if (gsrc[k]) cl[ldsoff[k]] = r[k];
+    vv_static_for<0, NIT>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int row = (k * VV_WG) / PER;
+      const int rem = tid + (k * VV_WG) % PER;
+      const int c4 = rem % NC4, x = rem / NC4;
+      const int pos = x + MD;
+      const int off = row == 0 ? c4 * P1 + (x & 3) * Q1 + (x >> 2)
+                               : F1SZ + (row - 1) * F2SZ + c4 * P2 + (pos & 3) * QS + (pos >> 2);
+      const bool ok = rowvalid(row);
+      float4 v = r[k];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      cl[off] = v;
+    });
   };
 
-  float aa[D], ab[D];
+  v2f aa[D], ab[D];            // .x: channels 0,1 mod 4 pairs ... the two lanes of a packed accumulator are added at the end
 #pragma unroll
-  for (int k = 0; k < D; ++k) { aa[k] = 0.f; ab[k] = 0.f; }
+  for (int k = 0; k < D; ++k) { aa[k] = (v2f){0.f, 0.f}; ab[k] = (v2f){0.f, 0.f}; }
   const float4* q1 = F1 + par * Q1 + j;
   const float4* q2 = F2 + slot * F2SZ + par * QS + j;
+  // does this WAVE have anything but padding to multiply?  (one or two row displacements per wave)
+  bool work = false;
+#pragma unroll
+  for (int d = 0; d < DPW; ++d) work = work || rowvalid(1 + wave * DPW + d);
+#if defined(VV_EXP_CORR) && VV_EXP_CORR == 1
+  work = false;          // experiment: staging only
+#endif
 
   issue(0);
   for (int c0 = 0; c0 < C; c0 += CK) {
     __syncthreads();                       // previous chunk fully consumed (first pass: zero fill done)
     commit();
     __syncthreads();
+#if defined(VV_EXP_CORR) && VV_EXP_CORR == 2
+    if (false)               // experiment: no global loads after the first chunk
+#endif
     if (c0 + CK < C) issue(c0 + CK);
-#pragma unroll 2
-    for (int c4 = 0; c4 < NC4; ++c4) {
-      const float4 va = q1[c4 * P1], vb = q1[c4 * P1 + 2 * Q1];      // columns x = 4j+par and x+2
-#pragma unroll
-      for (int m = 0; m <= D; ++m) {
-        const float4 v = q2[c4 * P2 + 2 * (m & 1) * QS + (m >> 1)];   // f2 position x - 20 + 2m
-        if (m < D) aa[m] = fmaf(va.w, v.w, fmaf(va.z, v.z, fmaf(va.y, v.y, fmaf(va.x, v.x, aa[m]))));
-        if (m > 0) ab[m - 1] = fmaf(vb.w, v.w, fmaf(vb.z, v.z, fmaf(vb.y, v.y, fmaf(vb.x, v.x, ab[m - 1]))));
+    if (work) {
+      // per channel group: 6 window blocks (4, 4, 4, 4, 4, 2 positions) in a software pipeline -- the reads of block g+1 are
+      // issued before the multiply-adds of block g, and a scheduling fence per block keeps the compiler from hoisting the whole
+      // window (88 registers): two blocks (32 registers) are live at any time
+      constexpr int NB = (D + 1 + 3) / 4;
+#pragma unroll 1
+      for (int c4 = 0; c4 < NC4; ++c4) {
+        const float4* w2 = q2 + c4 * P2;
+        const float4 va = q1[c4 * P1], vb = q1[c4 * P1 + 2 * Q1];      // columns x = 4j+par and x+2
+        const v2f valo = {va.x, va.y}, vahi = {va.z, va.w}, vblo = {vb.x, vb.y}, vbhi = {vb.z, vb.w};
+        float4 win[2][4];
+        auto load_block = [&](auto gc) {
+          constexpr int gi = decltype(gc)::value;
+          vv_static_for<0, 4>([&](auto uc) {
+            constexpr int m = gi * 4 + decltype(uc)::value;
+            if constexpr (m <= D) win[gi & 1][m & 3] = w2[2 * (m & 1) * QS + (m >> 1)];      // f2 position x - 20 + 2m
+          });
+        };
+        load_block(std::integral_constant<int, 0>{});
+        vv_static_for<0, NB>([&](auto gc) {
+          constexpr int gi = decltype(gc)::value;
+          if constexpr (gi + 1 < NB) load_block(std::integral_constant<int, gi + 1>{});
+          vv_static_for<0, 4>([&](auto uc) {
+            constexpr int m = gi * 4 + decltype(uc)::value;
+            if constexpr (m <= D) {
+              // packed multiply-adds (v_pk_fma_f32): the kernel is bound by VALU ISSUE (one instruction per 4 cycles and wave,
+              // one or two waves per SIMD), a packed instruction retires two of the four channels per issue slot
+              const float4 v = win[gi & 1][m & 3];
+              const v2f vlo = {v.x, v.y}, vhi = {v.z, v.w};
+              if constexpr (m < D) aa[m] = __builtin_elementwise_fma(vahi, vhi, __builtin_elementwise_fma(valo, vlo, aa[m]));
+              if constexpr (m > 0) ab[m - 1] = __builtin_elementwise_fma(vbhi, vhi, __builtin_elementwise_fma(vblo, vlo, ab[m - 1]));
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
     }
   }
@@ -191,9 +240,9 @@ correlation_nhwc_kernel(const float* __restrict__ f1, const float* __restrict__ 
     float* o = out + ((int64_t)(b * H + y) * W_ + x) * ocs + ocoff + ti * D;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      float v = aa[k] * scale;
+      float v = (aa[k].x + aa[k].y) * scale;
       o[k] = v > 0.f ? v : v * slope;
-      v = ab[k] * scale;
+      v = (ab[k].x + ab[k].y) * scale;
       o[2 * ocs + k] = v > 0.f ? v : v * slope;
     }
   }
@@ -286,9 +335,9 @@ extern "C" int vv_correlation_fwd(const float* in1, const float* in2, float* out
 template <int W_>
 static int launch_corr_nhwc(const float* f1, const float* f2, int cs, int B, int C, int H, float* out, int ocs, int ocoff,
                             float slope, hipStream_t st) {
-  constexpr int DYB = 4 * (128 / W_);
+  constexpr int DYB = 4 * (128 / W_), NC4 = 4;          // 16-channel chunks: the kernel's CK / 4
   constexpr int QS = ((W_ + 40 + 3) / 4 + 15) / 16 * 16, Q1 = (W_ / 4 + 15) / 16 * 16;
-  constexpr size_t bytes = (size_t)(8 * (4 * Q1 + 1) + DYB * 8 * (4 * QS + 1)) * 16;
+  constexpr size_t bytes = (size_t)(NC4 * (4 * Q1 + 1) + DYB * NC4 * (4 * QS + 1)) * 16;
   {   // idempotent and cheap: set on every call rather than remembering it in a static
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(correlation_nhwc_kernel<W_>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -305,7 +354,7 @@ extern "C" int vv_correlation_nhwc(const float* f1, const float* f2, int32_t cst
                                    int32_t W, float* out, int32_t out_cstride, int32_t out_coff, float slope,
                                    vv_stream stream) {
   if (!f1 || !f2 || !out || B <= 0 || H <= 0) return VV_ERR_BAD_ARG;
-  if (C % 32 || cstride % 4 || cstride < C) return VV_ERR_UNSUPPORTED;
+  if (C % 16 || cstride % 4 || cstride < C) return VV_ERR_UNSUPPORTED;
   if (((uintptr_t)f1 | (uintptr_t)f2) & 15) return VV_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (W == 128) return launch_corr_nhwc<128>(f1, f2, cstride, B, C, H, out, out_cstride, out_coff, slope, st);
