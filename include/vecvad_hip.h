@@ -246,7 +246,7 @@ typedef struct vv_outconv_params {
 int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream);
 
 /* backward of the 1x1 conv: dA[p][c] = sum_co dout[p][co] W[co][c]; dW[co][c] = sum_p dout[p][co] act[p][c];
- * db[co] = sum_p dout[p][co].  partial: [G][nblk][132]; reduced by vv_outconv_bwd_reduce. */
+ * db[co] = sum_p dout[p][co].  partial: [G][nblk][4*C + 4]; reduced by vv_outconv_bwd_reduce.  C = features_root: 32 or 64. */
 /* bnpart != NULL: also writes the BatchNorm-backward partial sums of the layer in front of the output conv, [G][B][2][C]
  * (per cube: sum of g = dA * [act > 0], sum of g * xhat; mean / invstd: [G][ab_gstride] like a, b) -- vv_bn_bwd_apply with
  * VV_BNBWD_PARTIALS_PER_CUBE then needs no vv_bn_bwd_reduce pass for that layer. */

@@ -228,6 +228,7 @@ def main():
         'full_nf32_nopad': lambda: case_model('full', 32, False, 4),
         'net4_nf32_rawrange4': lambda: case_model('net4', 32, False, 3, rawRange=4),
         '1raw1of_nf32_nopad': lambda: case_model('1raw1of', 32, False, 3),
+        '1raw1of_nf64_nopad': lambda: case_model('1raw1of', 64, False, 3),      # the class's default features_root (model/unet.py:563)
         'script_net4': lambda: case_script(),
         'script_net4_f240': lambda: case_script(n_test_frames=240, graded=True),
     }

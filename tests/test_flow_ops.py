@@ -52,6 +52,22 @@ def test_correlation_hip_vs_oracle(B, C, H, W, pad, md, s1, s2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,C,H,W,pad,k,md,s1,s2', [(1, 16, 10, 14, 5, 3, 4, 1, 2), (2, 8, 9, 11, 4, 3, 2, 1, 1), (1, 5, 12, 12, 8, 5, 4, 2, 2)])
+def test_correlation_kernel_size_gt1_vs_oracle(B, C, H, W, pad, k, md, s1, s2):
+    """The reference's public signature in full (correlation.py:6-27, correlation_cuda_kernel.cu:79-88): kernel_size > 1 sums the
+    k x k patch around both positions.  FlowNet2 only instantiates kernel_size 1; the general form is the plain kernel."""
+    from vec_vad_amd.flow_ops import Correlation
+    rng = np.random.default_rng(k * 10 + C)
+    a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    ref = F.correlation_fwd(a, b, pad, k, md, s1, s2)
+    out = Correlation(pad_size=pad, kernel_size=k, max_displacement=md, stride1=s1, stride2=s2, corr_multiply=1)(
+        torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.gpu
 def test_resample_and_channelnorm_hip_vs_oracle():
     from vec_vad_amd.flow_ops import Resample2d, ChannelNorm
     rng = np.random.default_rng(2)

@@ -11,17 +11,18 @@ pytestmark = pytest.mark.gpu
 
 CASES = [('net4_nf32_nopad', 'net4', False, 6, None), ('net4_nf32_pad', 'net4', True, 3, None),
          ('full_nf32_nopad', 'full', False, 4, None), ('net4_nf32_rawrange4', 'net4', False, 3, 4),
-         ('1raw1of_nf32_nopad', '1raw1of', False, 3, None)]
+         ('1raw1of_nf32_nopad', '1raw1of', False, 3, None),
+         ('1raw1of_nf64_nopad', '1raw1of', False, 3, None)]      # features_root = 64: the class's default (model/unet.py:563)
 
 
-def _build(kind, padding, rawRange=None, seed=0):
+def _build(kind, padding, rawRange=None, seed=0, nf=32):
     from oracle import unet_oracle as O
     from model.unet import SelfCompleteNet4, SelfCompleteNetFull, SelfCompleteNet1raw1of
     cls = {'net4': SelfCompleteNet4, 'full': SelfCompleteNetFull, '1raw1of': SelfCompleteNet1raw1of}[kind]
     tot_of = {'net4': 1, 'full': 5, '1raw1of': 1}[kind]
-    net = cls(features_root=32, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=rawRange, useFlow=True,
+    net = cls(features_root=nf, tot_raw_num=5, tot_of_num=tot_of, border_mode='predict', rawRange=rawRange, useFlow=True,
               padding=padding)
-    sd = O.seeded_state_dict(kind, nf=32, padding=padding, seed=seed)
+    sd = O.seeded_state_dict(kind, nf=nf, padding=padding, seed=seed)
     net.load_state_dict(sd)
     return net.cuda(), sd, tot_of
 
@@ -36,7 +37,7 @@ def test_library_loaded_and_arch():
 def test_eval_scores_and_outputs(name, kind, padding, n, rawRange):
     from oracle import unet_oracle as O
     g = load_golden(name)
-    net, sd, tot_of = _build(kind, padding, rawRange)
+    net, sd, tot_of = _build(kind, padding, rawRange, nf=64 if 'nf64' in name else 32)
     raw, flow = O.seeded_cubes(n, tot_of, 0)
     x, x_of = O.cubes_to_inputs(raw, flow)
     net.eval()
@@ -68,7 +69,7 @@ def test_three_train_steps_fused(name, kind, padding, n, rawRange):
     from oracle import unet_oracle as O
     from vec_vad_amd.trainer import FusedTrainer
     g = load_golden(name)
-    net, sd, tot_of = _build(kind, padding, rawRange)
+    net, sd, tot_of = _build(kind, padding, rawRange, nf=64 if 'nf64' in name else 32)
     raw, flow = O.seeded_cubes(n, tot_of, 0)
     x, x_of = O.cubes_to_inputs(raw, flow)
     net.train()

@@ -9,7 +9,7 @@ from _util import digest, load_golden, digest_close
 
 CASES = [('net4_nf32_nopad', 'net4', False, 6, None), ('net4_nf32_pad', 'net4', True, 3, None),
          ('full_nf32_nopad', 'full', False, 4, None), ('net4_nf32_rawrange4', 'net4', False, 3, 4),
-         ('1raw1of_nf32_nopad', '1raw1of', False, 3, None)]
+         ('1raw1of_nf32_nopad', '1raw1of', False, 3, None), ('1raw1of_nf64_nopad', '1raw1of', False, 3, None)]
 
 
 @pytest.mark.parametrize('name,kind,padding,n,rawRange', CASES)
@@ -17,7 +17,7 @@ def test_oracle_matches_reference(name, kind, padding, n, rawRange):
     torch.set_num_threads(8)
     g = load_golden(name)
     tot_of = {'net4': 1, 'full': 5, '1raw1of': 1}[kind]
-    sd = O.seeded_state_dict(kind, nf=32, padding=padding, seed=0)
+    sd = O.seeded_state_dict(kind, nf=64 if 'nf64' in name else 32, padding=padding, seed=0)
     spec = O.bank_spec(kind, 5, tot_of, 'predict', rawRange, True)
     raw, flow = O.seeded_cubes(n, tot_of, 0)
     x, x_of = O.cubes_to_inputs(raw, flow)

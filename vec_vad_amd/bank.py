@@ -169,10 +169,12 @@ class UNetBank:
         self.nf, self.tot_raw, self.tot_of, self.padding = nf, tot_raw_num, tot_of_num, padding
         if nf % 32:
             raise L.VecVadHipError('features_root must be a multiple of 32 for the MFMA tiles (got %d)' % nf)
-        if nf != 32:
-            raise L.VecVadHipError('features_root = %d: only nf = 32 (the value of every shipped config.cfg) is implemented -- the '
-                                   'fused 1x1 output conv + loss kernel and the BatchNorm-backward kernels are specialised for it '
-                                   '(C = 32 / C <= 256)' % nf)
+        if nf not in (32, 64):
+            raise L.VecVadHipError('features_root = %d: nf = 32 (the value of every shipped config.cfg) and nf = 64 (the default of '
+                                   'SelfCompleteNet1raw1of, model/unet.py:563) are implemented -- the fused 1x1 output conv + loss '
+                                   'kernels are instantiated for these two widths' % nf)
+        if nf != 32 and os.environ.get('VV_PRECISION', 'fp32').lower() != 'fp32':
+            raise L.VecVadHipError('mixed precision is implemented for features_root = 32 only')
         self.in_ch = RAW_C * (tot_raw_num if padding else tot_raw_num - 1)
         self.lay = BankLayout(nf, self.in_ch)
         self.g0, self.Ga = active if active is not None else (0, self.G)
@@ -533,7 +535,7 @@ class UNetBank:
         nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
         ws.bnpart = f(Ga, max(n * 2 * l.cout for n, l in zip(nblk, lay.convs)))
         ws.bnscr = f(Ga, 2 * lay.cmax)
-        ws.ocpart = f(Ga, B, 132)
+        ws.ocpart = f(Ga, B, 4 * nf + 4)
         ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
         ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin
                               for l in lay.convs if l.mode == L.IN_CAT))

@@ -241,10 +241,10 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
   *reinterpret_cast<float4*>(r1 + (pl * Q4 + q) * 4) = s1;
   *reinterpret_cast<float4*>(r2 + (pl * Q4 + q) * 4) = s2;
   __syncthreads();
-  if (threadIdx.x < C) {
+  for (int ch = threadIdx.x; ch < C; ch += VV_WG) {      // C <= 256: one channel per thread; nf = 64 has 512-channel layers
     float t1 = 0.f, t2 = 0.f;
-    for (int k = 0; k < PL; ++k) { t1 += r1[k * C + threadIdx.x]; t2 += r2[k * C + threadIdx.x]; }
-    float* o = p.partial + ((int64_t)(g * nblk + blk) * 2) * C + threadIdx.x;
+    for (int k = 0; k < PL; ++k) { t1 += r1[k * C + ch]; t2 += r2[k * C + ch]; }
+    float* o = p.partial + ((int64_t)(g * nblk + blk) * 2) * C + ch;
     o[0] = t1;
     o[C] = t2;
   }
@@ -392,14 +392,17 @@ bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ output conv
-// grid (B, G): one block = one cube (HW pixels) of one UNet; 8 lanes per pixel, 4 channels per lane (C = 32).
+// grid (B, G): one block = one cube (HW pixels) of one UNet; CC / 4 lanes per pixel, 4 channels per lane (CC = features_root:
+// 32 in every shipped config.cfg, 64 = the default of SelfCompleteNet1raw1of, model/unet.py:563).
+template <int CC>
 __global__ void __launch_bounds__(VV_WG)
 outconv_fwd_kernel(const vv_outconv_params p) {
+  constexpr int LPP = CC / 4, NPG = VV_WG / LPP;
   __shared__ float red[4];
   const int g = blockIdx.y, cube = blockIdx.x;
-  const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
+  const int tid = threadIdx.x, sub = tid % LPP, pg = tid / LPP;
   const int c = sub * 4;
-  const int C = p.C, oc = p.oc[g];
+  const int C = CC, oc = p.oc[g];
   const int64_t abo = (int64_t)g * p.ab_gstride + c;
   const float4 a4 = *reinterpret_cast<const float4*>(p.a + abo), b4 = *reinterpret_cast<const float4*>(p.b + abo);
   float4 wv[4];
@@ -421,7 +424,7 @@ outconv_fwd_kernel(const vv_outconv_params p) {
   const float* __restrict__ y = p.y + (int64_t)g * p.y_gstride;
   const int64_t MB = (int64_t)p.B * p.HW;
   float sse = 0.f;
-  for (int i = pg; i < p.HW; i += 32) {
+  for (int i = pg; i < p.HW; i += NPG) {
     const int64_t pix = (int64_t)cube * p.HW + i;
     const float4 yq = (p.pad0 & 1) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c))
                                    : *reinterpret_cast<const float4*>(y + pix * C + c);      // pad0 bit 0: y holds bf16 elements
@@ -431,7 +434,8 @@ outconv_fwd_kernel(const vv_outconv_params p) {
     for (int co = 0; co < 4; ++co) {
       float d = v.x * wv[co].x;
       d = fmaf(v.y, wv[co].y, d); d = fmaf(v.z, wv[co].z, d); d = fmaf(v.w, wv[co].w, d);
-      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+#pragma unroll
+      for (int sh_ = 1; sh_ < LPP; sh_ <<= 1) d += __shfl_xor(d, sh_);
       o[co] = d + bias[co];
     }
     if (sub == 0) {
@@ -461,17 +465,20 @@ outconv_fwd_kernel(const vv_outconv_params p) {
   if (tid == 0) p.score[(int64_t)g * p.B + cube] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// backward: grid (B, G); partial [G][B][132]
+// backward: grid (B, G); partial [G][B][4*CC + 4]
+template <int CC>
 __global__ void __launch_bounds__(VV_WG)
-outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restrict__ dout4, const float* __restrict__ y,
+outconv_bwd_kernel(const int B, const int HW, const int C_, const float* __restrict__ dout4, const float* __restrict__ y,
                    const int64_t y_gstride, const float* __restrict__ a, const float* __restrict__ b,
                    const int64_t ab_gstride, const float* __restrict__ w, const int64_t param_gstride,
                    float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial,
                    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ bnpart,
                    const int dA_bf16) {      // flags: bit 0 = dA stored as bf16, bit 1 = y holds bf16 elements
-  __shared__ float sh[32][8 * 16 + 4];
+  constexpr int C = CC, LPP = CC / 4, NPG = VV_WG / LPP, NOUT = 4 * CC + 4;
+  (void)C_;
+  __shared__ float sh[NPG][LPP * 16 + 4];
   const int g = blockIdx.y, cube = blockIdx.x;
-  const int tid = threadIdx.x, sub = tid & 7, pg = tid >> 3;
+  const int tid = threadIdx.x, sub = tid % LPP, pg = tid / LPP;
   const int c = sub * 4;
   const int64_t abo = (int64_t)g * ab_gstride + c;
   const float4 a4 = *reinterpret_cast<const float4*>(a + abo), b4 = *reinterpret_cast<const float4*>(b + abo);
@@ -490,7 +497,7 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
   // g = dA * [act > 0] and of g * xhat per channel), so that layer needs no reduction pass over dA and y
   float4 m4 = make_float4(0, 0, 0, 0), i4 = m4, s1 = m4, s2 = m4;
   if (bnpart) { m4 = *reinterpret_cast<const float4*>(mean + abo); i4 = *reinterpret_cast<const float4*>(invstd + abo); }
-  for (int i = pg; i < HW; i += 32) {
+  for (int i = pg; i < HW; i += NPG) {
     const int64_t pix = (int64_t)cube * HW + i;
     const float4 d = *reinterpret_cast<const float4*>(dout4 + ((int64_t)g * MB + pix) * 4);
     const float4 yv = (dA_bf16 & 2) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(yg) + pix * C + c))
@@ -524,62 +531,64 @@ outconv_bwd_kernel(const int B, const int HW, const int C, const float* __restri
   for (int co = 0; co < 4; ++co) *reinterpret_cast<float4*>(&sh[pg][sub * 16 + co * 4]) = dw[co];
   if (sub == 0) {
 #pragma unroll
-    for (int co = 0; co < 4; ++co) sh[pg][128 + co] = db[co];
+    for (int co = 0; co < 4; ++co) sh[pg][LPP * 16 + co] = db[co];
   }
   __syncthreads();
-  float* out = partial + ((int64_t)g * B + cube) * 132;
-  if (tid < 128) {
-    const int co = tid >> 5, cc = tid & 31;
+  float* out = partial + ((int64_t)g * B + cube) * NOUT;
+  for (int e = tid; e < NOUT; e += VV_WG) {          // [co][cc] weight-gradient sums, then the 4 bias-gradient sums; fixed order
     float s = 0.f;
-    for (int k = 0; k < 32; ++k) s += sh[k][(cc >> 2) * 16 + co * 4 + (cc & 3)];
-    out[co * 32 + cc] = s;
-  } else if (tid < 132) {
-    float s = 0.f;
-    for (int k = 0; k < 32; ++k) s += sh[k][128 + (tid - 128)];
-    out[tid] = s;
+    if (e < 4 * CC) {
+      const int co = e / CC, cc = e % CC;
+      for (int k = 0; k < NPG; ++k) s += sh[k][(cc >> 2) * 16 + co * 4 + (cc & 3)];
+    } else {
+      for (int k = 0; k < NPG; ++k) s += sh[k][LPP * 16 + (e - 4 * CC)];
+    }
+    out[e] = s;
   }
   if (!bnpart) return;
   __syncthreads();
   *reinterpret_cast<float4*>(&sh[pg][sub * 8]) = s1;
   *reinterpret_cast<float4*>(&sh[pg][sub * 8 + 4]) = s2;
   __syncthreads();
-  if (tid < 2 * C) {                       // C = 32: threads 0..31 -> sum g, 32..63 -> sum g*xhat; fixed order over the 32 pixel lanes
-    const int which = tid >> 5, cc = tid & 31;
+  if (tid < 2 * C) {                       // threads [0, C) -> sum g, [C, 2C) -> sum g*xhat; fixed order over the pixel lanes
+    const int which = tid / CC, cc = tid % CC;
     float s = 0.f;
-    for (int k = 0; k < 32; ++k) s += sh[k][(cc >> 2) * 8 + which * 4 + (cc & 3)];
+    for (int k = 0; k < NPG; ++k) s += sh[k][(cc >> 2) * 8 + which * 4 + (cc & 3)];
     bnpart[((int64_t)(g * B + cube) * 2 + which) * C + cc] = s;
   }
 }
 
-// grid (G); 1056 -> 1024 threads: 132 outputs x 7 partial-sum lanes (+ tail), fixed order, fp64
+// grid (G); 1024 threads: NOUT = 4*CC + 4 outputs x NPL partial-sum lanes (7 at CC = 32), fixed order, fp64
+template <int CC>
 __global__ void __launch_bounds__(1024)
-outconv_bwd_reduce_kernel(const int C, const int nblk, const float* __restrict__ partial, const int* __restrict__ oc,
+outconv_bwd_reduce_kernel(const int C_, const int nblk, const float* __restrict__ partial, const int* __restrict__ oc,
                           float* __restrict__ dW, float* __restrict__ db, const int64_t grad_gstride) {
-  constexpr int NPL = 7;                       // 132 * 7 = 924 threads carry a partial sum
-  __shared__ double sh[NPL][132];
+  constexpr int NOUT = 4 * CC + 4, NPL = 1024 / NOUT, C = CC;
+  (void)C_;
+  __shared__ double sh[NPL][NOUT];
   const int g = blockIdx.x, tid = threadIdx.x;
-  const int e = tid % 132, part = tid / 132;
+  const int e = tid % NOUT, part = tid / NOUT;
   if (part < NPL) {
     double s0 = 0.0, s1 = 0.0;
     int k = part;
     for (; k + NPL < nblk; k += 2 * NPL) {
-      s0 += (double)partial[((int64_t)g * nblk + k) * 132 + e];
-      s1 += (double)partial[((int64_t)g * nblk + k + NPL) * 132 + e];
+      s0 += (double)partial[((int64_t)g * nblk + k) * NOUT + e];
+      s1 += (double)partial[((int64_t)g * nblk + k + NPL) * NOUT + e];
     }
-    if (k < nblk) s0 += (double)partial[((int64_t)g * nblk + k) * 132 + e];
+    if (k < nblk) s0 += (double)partial[((int64_t)g * nblk + k) * NOUT + e];
     sh[part][e] = s0 + s1;
   }
   __syncthreads();
-  if (tid >= 132) return;
+  if (tid >= NOUT) return;
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < NPL; ++k) s += sh[k][tid];
   const int n = oc[g];
-  if (tid < 128) {
-    const int co = tid >> 5, cc = tid & 31;
+  if (tid < 4 * CC) {
+    const int co = tid / CC, cc = tid % CC;
     if (co < n) dW[(int64_t)g * grad_gstride + co * C + cc] = (float)s;
-  } else if (tid - 128 < n) {
-    db[(int64_t)g * grad_gstride + (tid - 128)] = (float)s;
+  } else if (tid - 4 * CC < n) {
+    db[(int64_t)g * grad_gstride + (tid - 4 * CC)] = (float)s;
   }
 }
 
@@ -821,7 +830,7 @@ extern "C" int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C) {
 
 extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
   if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial) return VV_ERR_BAD_ARG;
-  if (p->C % 4 || p->C > 256 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
+  if (p->C % 4 || p->C > 1024 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
   const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   if (bn_all16(p)) {
     if (p->dpool)
@@ -863,8 +872,9 @@ extern "C" int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream) {
   if (!p || !p->y || !p->a || !p->b || !p->w || !p->bias || !p->oc || !p->tgt_src || !p->tgt_coff || !p->out4 ||
       !p->score || !p->tgt0)
     return VV_ERR_BAD_ARG;
-  if (p->C != 32) return VV_ERR_UNSUPPORTED;
-  VV_LAUNCH(outconv_fwd_kernel, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
+  if (p->C == 32) VV_LAUNCH(outconv_fwd_kernel<32>, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
+  else if (p->C == 64) VV_LAUNCH(outconv_fwd_kernel<64>, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
+  else return VV_ERR_UNSUPPORTED;      /* features_root 32 (every shipped config) or 64 (SelfCompleteNet1raw1of's default) */
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -877,9 +887,13 @@ extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const
                               const float* mean, const float* invstd, float* bnpart, int32_t dA_bf16, vv_stream stream) {
   if (!dout4 || !y || !a || !b || !w || !dA || !partial) return VV_ERR_BAD_ARG;
   if (bnpart && (!mean || !invstd)) return VV_ERR_BAD_ARG;
-  if (C != 32) return VV_ERR_UNSUPPORTED;
-  VV_LAUNCH(outconv_bwd_kernel, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
-                     a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart, dA_bf16);
+  if (C == 32)
+    VV_LAUNCH(outconv_bwd_kernel<32>, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
+              a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart, dA_bf16);
+  else if (C == 64)
+    VV_LAUNCH(outconv_bwd_kernel<64>, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
+              a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart, dA_bf16);
+  else return VV_ERR_UNSUPPORTED;
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -887,8 +901,9 @@ extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const
 extern "C" int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
                                      float* dW, float* db, int64_t grad_gstride, vv_stream stream) {
   if (!partial || !oc || !dW || !db) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(outconv_bwd_reduce_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, C, nblk, partial, oc, dW,
-                     db, grad_gstride);
+  if (C == 32) VV_LAUNCH(outconv_bwd_reduce_kernel<32>, dim3(G), dim3(1024), 0, (hipStream_t)stream, C, nblk, partial, oc, dW, db, grad_gstride);
+  else if (C == 64) VV_LAUNCH(outconv_bwd_reduce_kernel<64>, dim3(G), dim3(1024), 0, (hipStream_t)stream, C, nblk, partial, oc, dW, db, grad_gstride);
+  else return VV_ERR_UNSUPPORTED;
   VV_CHECK_LAUNCH();
   return VV_OK;
 }

@@ -294,6 +294,38 @@ channelnorm_kernel(const int64_t npix, const float* __restrict__ in, float* __re
   out[e] = sqrtf(r);
 }
 
+// Correlation with kernel_size > 1 (correlation_cuda_kernel.cu:34-106 in full generality: the k x k patch sum around both
+// positions).  FlowNet2 never uses it (FlowNetC.py:24-30 has kernel_size 1), so this is the plain form: one thread per output
+// element, NCHW, zero padding by predicate; consecutive threads = consecutive x.
+__global__ void __launch_bounds__(VV_WG)
+correlation_generic_kernel(const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, const int B,
+                           const int C, const int H, const int W, const int oC, const int oH, const int oW, const int pad,
+                           const int ksz, const int md, const int s1, const int s2) {
+  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  const int64_t n = (int64_t)B * oC * oH * oW;
+  if (e >= n) return;
+  const int ox = (int)(e % oW);
+  const int oy = (int)((e / oW) % oH);
+  const int tc = (int)((e / ((int64_t)oW * oH)) % oC);
+  const int b = (int)(e / ((int64_t)oW * oH * oC));
+  const int kr = (ksz - 1) / 2, dr = md / s2, D = 2 * dr + 1;
+  const int tj = tc / D - dr, ti = tc % D - dr;
+  const int y1 = oy * s1 + md + kr - pad, x1 = ox * s1 + md + kr - pad;      // un-padded coordinates of the patch centres
+  const int y2 = y1 + tj * s2, x2 = x1 + ti * s2;
+  const int64_t HW = (int64_t)H * W;
+  float acc = 0.f;
+  for (int j = -kr; j <= kr; ++j)
+    for (int i = -kr; i <= kr; ++i) {
+      const int ya = y1 + j, xa = x1 + i, yb = y2 + j, xb = x2 + i;
+      if ((unsigned)ya >= (unsigned)H || (unsigned)xa >= (unsigned)W || (unsigned)yb >= (unsigned)H || (unsigned)xb >= (unsigned)W)
+        continue;                                                             // one factor is zero padding
+      const float* pa = in1 + (int64_t)b * C * HW + (int64_t)ya * W + xa;
+      const float* pb = in2 + (int64_t)b * C * HW + (int64_t)yb * W + xb;
+      for (int c = 0; c < C; ++c) acc = fmaf(pa[c * HW], pb[c * HW], acc);
+    }
+  out[e] = acc / (float)(ksz * ksz * C);
+}
+
 }  // namespace
 
 extern "C" int vv_correlation_out_shape(int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
@@ -314,10 +346,17 @@ extern "C" int vv_correlation_fwd(const float* in1, const float* in2, float* out
                                   int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
                                   int32_t stride1, int32_t stride2, int32_t corr_type_multiply, vv_stream stream) {
   if (!in1 || !in2 || !out) return VV_ERR_BAD_ARG;
-  if (kernel_size != 1 || corr_type_multiply != 1) return VV_ERR_UNSUPPORTED;   // FlowNetC.py:24-30 uses exactly this
+  if (corr_type_multiply != 1 || kernel_size < 1 || kernel_size % 2 == 0) return VV_ERR_UNSUPPORTED;   // the reference's kernel multiplies
   int oC, oH, oW;
   int rc = vv_correlation_out_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oC, &oH, &oW);
   if (rc) return rc;
+  if (kernel_size > 1) {            // general patch correlation: the plain kernel (FlowNet2 itself only uses kernel_size 1)
+    const int64_t n = (int64_t)B * oC * oH * oW;
+    VV_LAUNCH(correlation_generic_kernel, dim3((unsigned)((n + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, (hipStream_t)stream, in1, in2, out,
+              B, C, H, W, oC, oH, oW, pad_size, kernel_size, max_displacement, stride1, stride2);
+    VV_CHECK_LAUNCH();
+    return VV_OK;
+  }
   const int dr = max_displacement / stride2;
   if (2 * dr + 1 > 24) return VV_ERR_UNSUPPORTED;
   const int span = (CORR_XT - 1) * stride1 + 2 * dr * stride2 + 1;
