@@ -478,3 +478,41 @@ def test_eval_fold_matches_unfolded_path_and_tracks_updates(monkeypatch):
     rs, os_ = O.score_pass(sd, O.bank_spec('net4'), x, x_of, 37)
     np.testing.assert_allclose(a[0][0].cpu().numpy(), rs, rtol=1e-3)
     np.testing.assert_allclose(a[0][1].cpu().numpy(), os_, rtol=1e-3)
+
+
+def test_useflow_false_matches_oracle():
+    """useFlow=False (config.cfg `useFlow`, model/unet.py:74,161,244-267; train.py:389-392: loss = loss_raw alone, no lambda):
+    the bank has the five raw UNets only, forward returns empty flow lists like the reference, a fused train step and the
+    eval-mode scores agree with the oracle."""
+    from oracle import unet_oracle as O
+    from model.unet import SelfCompleteNet4
+    from vec_vad_amd.trainer import FusedTrainer
+    net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=False,
+                           padding=False)
+    sd = O.seeded_state_dict('net4', nf=32, useFlow=False, padding=False, seed=0)
+    net.load_state_dict(sd)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())          # no *_of modules are registered
+    net = net.cuda()
+    raw, flow = O.seeded_cubes(5, 1, 2)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    spec = O.bank_spec('net4', 5, 1, 'predict', None, False)
+    net.eval()
+    with torch.no_grad():
+        of_o, raw_o, of_t, raw_t = net(x.cuda(), x_of.cuda())
+    assert of_o == [] and of_t == [] and list(raw_o.shape) == [5, 15, 32, 32]
+    rs, _ = O.score_pass(sd, spec, x, x_of, 5, useFlow=False)
+    np.testing.assert_allclose(((raw_t - raw_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), rs, rtol=1e-3)
+    net.train()
+    tr = FusedTrainer(net, lambda_raw=0.5)          # lambda_raw must NOT enter the loss without flow (train.py:391-392)
+    ws = tr.step_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), torch.arange(5, device='cuda'))
+    l_raw, l_of = tr.losses(ws)
+    assert l_of is None
+    sdo = {k: v.clone() for k, v in sd.items()}
+    opt = O.AdamState(O.param_names(sdo))
+    lr_, _, gref = O.train_step(sdo, spec, x, x_of, opt, useFlow=False)
+    assert abs(float(l_raw) - lr_) <= 1e-3 * lr_
+    net.eval()
+    r, o = tr.score_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda())
+    assert o is None
+    rs2, _ = O.score_pass(sdo, spec, x, x_of, 5, useFlow=False)
+    np.testing.assert_allclose(r.cpu().numpy(), rs2, rtol=1e-3)
