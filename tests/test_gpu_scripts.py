@@ -116,7 +116,7 @@ def test_calc_optical_flow_driver(tmp_path, monkeypatch):
                                    border_mode='hard')
     torch.manual_seed(0)
     net = COF.FlowNet2().cuda().eval()
-    COF.calc_optical_flow(ds, flownet2=net, log=lambda *a: None)
+    COF.calc_optical_flow(ds, flownet2=net, log=lambda *a: None, pairs_per_launch=1)
     order = [('Train001', 0), ('Train001', 1), ('Train001', 2), ('Train002', 0), ('Train002', 1)]
     # (first, second) frame matched for each index: border frames use the first two of the clipped context
     pairs = [(0, 0), (1, 2), (1, 2), (3, 3), (3, 4)]
@@ -131,6 +131,13 @@ def test_calc_optical_flow_driver(tmp_path, monkeypatch):
         ref = R.resize_linear(np.ascontiguousarray(flow), (W, H))
         assert np.array_equal(got, ref), idx
     assert np.isfinite(got).all()
+    # several frames per launch (the default): same files, same flow up to fp32 round-off (split-K choices depend on the batch)
+    one = {idx: np.load(os.path.join('optical_flow', 'UCSDped2', 'Train', v, '%03d.npy' % (k + 1))) for idx, (v, k) in enumerate(order)}
+    COF.calc_optical_flow(ds, flownet2=net, log=lambda *a: None, of_root_dir='./optical_flow_b', pairs_per_launch=3)
+    for idx, (v, k) in enumerate(order):
+        got = np.load(os.path.join('optical_flow_b', 'UCSDped2', 'Train', v, '%03d.npy' % (k + 1)))
+        scale = max(1e-6, float(np.abs(one[idx]).max()))
+        assert got.shape == one[idx].shape and float(np.abs(got - one[idx]).max()) <= 1e-4 * scale, idx
 
 
 def _synthetic_ped2_tree(rng, n_train=(4, 3), n_test=(4,)):
