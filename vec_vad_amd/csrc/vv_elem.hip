@@ -424,10 +424,15 @@ outconv_fwd_kernel(const vv_outconv_params p) {
   const float* __restrict__ y = p.y + (int64_t)g * p.y_gstride;
   const int64_t MB = (int64_t)p.B * p.HW;
   float sse = 0.f;
-  for (int i = pg; i < p.HW; i += NPG) {
+  // four pixel groups per trip, their loads issued before the first shuffle: one load in flight per lane made the kernel a chain of
+  // HBM round trips (the stores inside the body keep the compiler from hoisting the loads itself)
+  auto ldy = [&](const int i) -> float4 {
     const int64_t pix = (int64_t)cube * p.HW + i;
-    const float4 yq = (p.pad0 & 1) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c))
-                                   : *reinterpret_cast<const float4*>(y + pix * C + c);      // pad0 bit 0: y holds bf16 elements
+    return (p.pad0 & 1) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c))
+                        : *reinterpret_cast<const float4*>(y + pix * C + c);      // pad0 bit 0: y holds bf16 elements
+  };
+  auto body = [&](const int i, const float4 yq) {
+    const int64_t pix = (int64_t)cube * p.HW + i;
     const float4 v = vv_act4(yq, a4, b4);
     float o[4];
 #pragma unroll
@@ -456,6 +461,15 @@ outconv_fwd_kernel(const vv_outconv_params p) {
         *reinterpret_cast<float4*>(p.dout4 + ((int64_t)g * MB + pix) * 4) = dv;
       }
     }
+  };
+  for (int i0 = pg; i0 < p.HW; i0 += 4 * NPG) {
+    float4 yq4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NPG < p.HW) yq4[u] = ldy(i0 + u * NPG);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NPG < p.HW) body(i0 + u * NPG, yq4[u]);
   }
   // block reduce sse (only sub==0 lanes hold data): wave reduce then 4 waves
 #pragma unroll
@@ -497,11 +511,15 @@ outconv_bwd_kernel(const int B, const int HW, const int C_, const float* __restr
   // g = dA * [act > 0] and of g * xhat per channel), so that layer needs no reduction pass over dA and y
   float4 m4 = make_float4(0, 0, 0, 0), i4 = m4, s1 = m4, s2 = m4;
   if (bnpart) { m4 = *reinterpret_cast<const float4*>(mean + abo); i4 = *reinterpret_cast<const float4*>(invstd + abo); }
-  for (int i = pg; i < HW; i += NPG) {
+  // four pixel groups per trip with their loads up front (see outconv_fwd_kernel)
+  auto ldd = [&](const int i) -> float4 { return *reinterpret_cast<const float4*>(dout4 + ((int64_t)g * MB + (int64_t)cube * HW + i) * 4); };
+  auto ldy = [&](const int i) -> float4 {
     const int64_t pix = (int64_t)cube * HW + i;
-    const float4 d = *reinterpret_cast<const float4*>(dout4 + ((int64_t)g * MB + pix) * 4);
-    const float4 yv = (dA_bf16 & 2) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(yg) + pix * C + c))
-                                    : *reinterpret_cast<const float4*>(yg + pix * C + c);
+    return (dA_bf16 & 2) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(yg) + pix * C + c))
+                         : *reinterpret_cast<const float4*>(yg + pix * C + c);
+  };
+  auto body = [&](const int i, const float4 d, const float4 yv) {
+    const int64_t pix = (int64_t)cube * HW + i;
     const float4 v = vv_act4(yv, a4, b4);
     const float dd[4] = {d.x, d.y, d.z, d.w};
     float4 o = make_float4(0, 0, 0, 0);
@@ -526,6 +544,15 @@ outconv_bwd_kernel(const int B, const int HW, const int C_, const float* __restr
       s2.x = fmaf(gq.x, (yv.x - m4.x) * i4.x, s2.x); s2.y = fmaf(gq.y, (yv.y - m4.y) * i4.y, s2.y);
       s2.z = fmaf(gq.z, (yv.z - m4.z) * i4.z, s2.z); s2.w = fmaf(gq.w, (yv.w - m4.w) * i4.w, s2.w);
     }
+  };
+  for (int i0 = pg; i0 < HW; i0 += 4 * NPG) {
+    float4 d4[4], y4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NPG < HW) { d4[u] = ldd(i0 + u * NPG); y4[u] = ldy(i0 + u * NPG); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NPG < HW) body(i0 + u * NPG, d4[u], y4[u]);
   }
 #pragma unroll
   for (int co = 0; co < 4; ++co) *reinterpret_cast<float4*>(&sh[pg][sub * 16 + co * 4]) = dw[co];
@@ -769,19 +796,21 @@ pool_act_kernel(const int64_t n4, const int C, const int H2, const int W2, const
 __global__ void __launch_bounds__(VV_WG)
 cube_erase_kernel(const int64_t npix, const int Cc, const int CP, const float* __restrict__ cube, const int* __restrict__ chmap,
                   float* __restrict__ out, const int64_t out_gstride, const int out16) {
+  // one thread per float4 of the output (CP / 4 threads per pixel): a wave writes 1 KB contiguous; the 3-4 source channels of a
+  // group come through L1 (the pixel's 60 bytes are read by its CP / 4 neighbours)
   const int g = blockIdx.y;
-  const int64_t e = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  const int Q = CP >> 2;
+  const int64_t t = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
+  const int64_t e = t / Q;
+  const int k = (int)(t % Q) * 4;
   if (e >= npix) return;
   const float* q = cube + e * Cc;
-  float* o = out + (int64_t)g * out_gstride + e * CP;
   const int* m = chmap + (int64_t)g * CP;
-  for (int k = 0; k < CP; k += 4) {
-    float4 v;
-    const int m0 = m[k], m1 = m[k + 1], m2 = m[k + 2], m3 = m[k + 3];
-    v.x = m0 >= 0 ? q[m0] : 0.f; v.y = m1 >= 0 ? q[m1] : 0.f; v.z = m2 >= 0 ? q[m2] : 0.f; v.w = m3 >= 0 ? q[m3] : 0.f;
-    if (out16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out + (int64_t)g * out_gstride) + e * CP + k) = vv_pack_bf16x4(v);
-    else *reinterpret_cast<float4*>(o + k) = v;
-  }
+  const int m0 = m[k], m1 = m[k + 1], m2 = m[k + 2], m3 = m[k + 3];
+  float4 v;
+  v.x = m0 >= 0 ? q[m0] : 0.f; v.y = m1 >= 0 ? q[m1] : 0.f; v.z = m2 >= 0 ? q[m2] : 0.f; v.w = m3 >= 0 ? q[m3] : 0.f;
+  if (out16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out + (int64_t)g * out_gstride) + e * CP + k) = vv_pack_bf16x4(v);
+  else *reinterpret_cast<float4*>(out + (int64_t)g * out_gstride + e * CP + k) = v;
 }
 
 inline int nblocks(int64_t n, int cap = 1 << 20) {
@@ -989,7 +1018,7 @@ extern "C" int vv_pool_act(int32_t G, int32_t B, int32_t H2, int32_t W2, int32_t
 extern "C" int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, const float* cube, const int32_t* chmap,
                              float* out, int64_t out_gstride, int32_t out_bf16, vv_stream stream) {
   if (!cube || !chmap || !out || CP % 4) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(cube_erase_kernel, dim3(nblocks(npix), G), dim3(VV_WG), 0, (hipStream_t)stream, npix, Cc, CP, cube, chmap, out,
+  VV_LAUNCH(cube_erase_kernel, dim3(nblocks(npix * (CP / 4)), G), dim3(VV_WG), 0, (hipStream_t)stream, npix, Cc, CP, cube, chmap, out,
             out_gstride, out_bf16);
   VV_CHECK_LAUNCH();
   return VV_OK;
