@@ -224,3 +224,90 @@ def test_rccl_world1_bucketed_step_bitwise_equal_to_no_group():
     assert backend == 'nccl' and s == 4.0
     assert outs[0][1] == 0 and outs[1][1] == 6 and outs[2][1] == 6        # 3 buckets x 2 steps went through RCCL
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], outs[2][0])
+
+
+def _worker_uneven(rank, world, port, q):
+    """The last, uneven global batch of an epoch under torchrun (train.py:373 keeps it; DataParallel scatters ceil(n/world)
+    chunks): 5 cubes -> 3 + 2, then 1 cube -> 1 + 0."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import unet_oracle as O
+    from model.unet import SelfCompleteNet4
+    from vec_vad_amd.trainer import FusedTrainer
+    torch.cuda.set_device(0)
+    net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=True,
+                           padding=False)
+    net.load_state_dict(O.seeded_state_dict('net4', nf=32, padding=False, seed=0))
+    net = net.cuda().train()
+    raw, flow = O.seeded_cubes(6, 1, 31)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    tr = FusedTrainer(net, process_group=dist.group.WORLD)
+    out = {}
+    per = 3                                             # ceil(5 / 2)
+    idx = torch.arange(5, device='cuda')[rank * per:(rank + 1) * per]
+    ws = tr.step_cubes_uneven(rawd, flowd, idx, 5)
+    out['grads5'] = (tr.bank.grads / world).cpu().numpy()
+    out['ws5'] = ws is not None
+    idx = torch.arange(5, 6, device='cuda')[rank:rank + 1]          # 1 cube: rank 0 has it, rank 1 has none
+    ws = tr.step_cubes_uneven(rawd, flowd, idx, 1)
+    out['ws1'] = ws is not None
+    out['params'] = tr.bank.params.cpu().numpy()
+    torch.cuda.synchronize()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_global_batch_is_the_global_mean_gradient():
+    import torch.multiprocessing as mp
+    from oracle import unet_oracle as O
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31900 + (os.getpid() % 1000)
+    ps = [ctx.Process(target=_worker_uneven, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(120)
+    assert res[0]['ws5'] and res[1]['ws5'] and res[0]['ws1'] and not res[1]['ws1']
+    assert np.array_equal(res[0]['grads5'], res[1]['grads5']) and np.array_equal(res[0]['params'], res[1]['params'])
+    assert np.isfinite(res[0]['params']).all()
+    # oracle: per-shard train-mode forward / backward (own BatchNorm statistics), gradients weighted by B_r / N
+    torch.set_num_threads(8)
+    spec = O.bank_spec('net4')
+    raw, flow = O.seeded_cubes(6, 1, 31)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    sd0 = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
+    names = O.param_names(sd0)
+    tot = {n: torch.zeros_like(sd0[n]) for n in names}
+    for lo, hi in ((0, 3), (3, 5)):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for n in names:
+            sd[n].requires_grad_(True)
+        of_o, raw_o, of_t, raw_t = O.bank_forward(sd, spec, x[lo:hi], x_of[lo:hi], True, False)
+        loss, _, _ = O.train_loss(of_o, raw_o, of_t, raw_t)
+        loss.backward()
+        for n in names:
+            tot[n] += sd[n].grad * ((hi - lo) / 5.0)
+    # map the flat HIP gradient buffer back to names through a bank built in this process
+    from model.unet import SelfCompleteNet4
+    net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=True,
+                           padding=False).cuda()
+    bank = net.bank()
+    by_id = {id(p): (g, key) for (g, key, p) in net._param_index}
+    flat = torch.from_numpy(res[0]['grads5'])
+    num = den = 0.0
+    for name, p in net.named_parameters():
+        if name.endswith('.0.bias') or name.endswith('.3.bias'):
+            continue
+        g, key = by_id[id(p)]
+        off, _ = bank.lay.p[key]
+        got = flat[g, off:off + p.numel()].view(p.shape).double()
+        num += float(((got - tot[name].double()) ** 2).sum())
+        den += float((tot[name].double() ** 2).sum())
+    assert num <= (2e-2 ** 2) * den, (num, den)          # 3- and 2-cube train-mode BatchNorm: tie flips dominate (cf. the small-batch tests)
