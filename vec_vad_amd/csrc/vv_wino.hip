@@ -8,68 +8,71 @@
 // Cout): 16 MFMA-K steps per 4 output pixels instead of 36 for the direct form (2.25x fewer matrix-core cycles).  All in fp32;
 // the transforms only add / subtract and halve, so the result differs from the direct convolution by a few ulp.
 //
-// One workgroup = 256 threads = 4 waves = 64 tiles (256 output pixels) x 32 output channels of one UNet, two workgroups
-// per CU (<= 256 registers per lane) so that one's staging / epilogue phases run under the other's MFMAs.
-//   wave = (tile group tg = 0..1 of 32 tiles) x (xi half xh): its 8 GEMMs (xi in {2xh, 2xh+1}, nu = 0..3) live in 128
-//   accumulator registers; lane l owns tile l&31, channel half l>>5 (A operand) / output channel l&31 (B operand, result).
-//   Input halo tile [NI][HH][HW][8+4] and the chunk's transformed filter panel [16][2][32] float4 go
-//   global -> registers -> LDS one 8-channel chunk ahead (the producer's BatchNorm+ReLU is applied on the way in, like in
-//   vv_conv.hip); odd and even columns are stored in separate planes so that lanes walking tile columns read consecutive
-//   slots.  V is built in registers from 8 patch reads per xi (row transform, then column transform) under the MFMAs.
-//   Epilogue: each wave applies A^T . A to its xi half, the halves meet in LDS, then bias, NHWC store and the BatchNorm
-//   sum / sum-of-squares partials exactly like the direct kernel.
+// One workgroup = 256 threads = 4 waves = 32 tiles (128 output pixels) x 32 output channels of one UNet; wave = xi (0..3), its
+// four GEMMs (nu = 0..3) live in 64 accumulator registers, so three workgroups fit a CU (<= 168 registers per lane) and a SIMD
+// has a third wave to run while two wait.  Lane l owns tile l&31, channel half l>>5 (A operand) / output channel l&31 (B
+// operand, result).
+//   No two waves of a workgroup use the same filter taps, so the transformed filter never touches LDS: each lane loads its four
+//   float4 per 8-channel chunk straight from the packed panel (L2-resident), one chunk ahead, into the registers the previous
+//   chunk's MFMAs have just released.
+//   The input halo tile [NI][HH][HW][8+4] goes global -> registers -> LDS one 8-channel chunk ahead (the producer's
+//   BatchNorm+ReLU is applied on the way in, like in vv_conv.hip); odd and even columns are stored in separate planes so that
+//   lanes walking tile columns read consecutive slots.  V is built in registers from 8 patch reads (row transform, then column
+//   transform).
+//   Epilogue: each wave applies the column half of A^T . A to its xi; the four waves meet in LDS and each finishes 8 tiles:
+//   bias, NHWC buffer stores (wave-uniform offsets in scalar registers) and the BatchNorm sum / sum-of-squares partials like the
+//   direct kernel.
+// History (profiles/README.md, round 2): the first form held two xi per wave (128 accumulators, 64 tiles, filter panel staged
+// through LDS, two workgroups per CU); this one is 11 % faster over the 27 launches of a Net4 step.
+#include <type_traits>
 #include "vv_common.h"
-// VV_EXP (compile-time, default 0): elimination switches used to find where the time goes (profiles/README.md, round 2) -- every
-// value other than 0 computes WRONG results: 1 = no MFMAs, 2 = no input transform, 3 = LDS commit of the first chunk only,
-// 4 = global loads of the first chunk only, 5 = no barriers.
-#ifndef VV_EXP
-#define VV_EXP 0
+// VV_EXPM (compile-time bit mask, default 0): elimination switches used to find where the time goes (profiles/README.md) --
+// every value other than 0 computes WRONG results: 1 no MFMAs, 2 no halo loads, 4 no tap reloads, 8 no output stores,
+// 32 no LDS commit.
+#ifndef VV_EXPM
+#define VV_EXPM 0
 #endif
-
 namespace {
 
-constexpr int NTG = 2;                 // tile groups (of 32 tiles) per workgroup
-constexpr int WN = NTG * 2 * 64;       // threads per workgroup: (tile group) x (xi half) waves
-constexpr int WT = NTG * 32;           // tiles per workgroup
+constexpr int WN = 256;                // threads per workgroup: one wave per xi
+constexpr int WT = 32;                 // tiles per workgroup
+constexpr int SB_MASK = 0x386;         // may cross a scheduling barrier: VALU, SALU, LDS -- not MFMA, not VMEM
 
 template <int H_>
 struct WGeo {
   static constexpr int TPI = H_ / 2;                       // tiles per image side
   static constexpr int TP = TPI * TPI;                     // tiles per image
-  static constexpr int TPW = TP < WT ? TP : WT;          // tiles of one image handled by one workgroup
-  static constexpr int NI = WT / TPW;                     // images per workgroup
+  static constexpr int TPW = TP < WT ? TP : WT;            // tiles of one image handled by one workgroup
+  static constexpr int NI = WT / TPW;                      // images per workgroup
   static constexpr int PARTS = TP / TPW;                   // workgroups per image
   static constexpr int TROWS = TPW / TPI;                  // tile rows per part
   static constexpr int HH = 2 * TROWS + 2, HW = H_ + 2;
 };
 
 template <int H_>
-__global__ void __launch_bounds__(WN, 2)
+__global__ void __launch_bounds__(WN, 3)
 wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = WGeo<H_>;
   constexpr int TPI = G_::TPI, TPW = G_::TPW, NI = G_::NI, PARTS = G_::PARTS, HH = G_::HH, HW = G_::HW, HWH = HW / 2;
   constexpr int CK = 8, S = CK + 4, S4 = S / 4, Q = CK / 4;
   constexpr int A4 = NI * HH * HW * S4;
-  constexpr int B4 = 16 * 2 * 32;                          // [xi*4+nu][half][co] float4
   constexpr int NITEMS = NI * HH * HW * Q;
   constexpr int NIT = (NITEMS + WN - 1) / WN;
-  constexpr int NBT = B4 / WN;
-  constexpr int EX4 = NTG * 4 * 16 * 64 / 4;               // epilogue exchange: [tg][2x2][16 regs][64 lanes] floats
-  constexpr int LDS4 = (A4 + B4) > EX4 ? (A4 + B4) : EX4;
-  static_assert(B4 % WN == 0 && WN % Q == 0, "staging geometry");
-  __shared__ float4 lds4[LDS4];
+  constexpr int EX4 = 4 * 16 * 64 / 2;                     // epilogue exchange: [wave][16 regs][64 lanes] float2
+  constexpr int L4 = A4 > EX4 ? A4 : EX4;
+  static_assert(WN % Q == 0, "one channel group per thread");
+  __shared__ float4 lds4[L4 + 64];                        // + [2][4 waves][32] BatchNorm partials
   float* lds = reinterpret_cast<float*>(lds4);
   const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
-  const v4f* ldsB = reinterpret_cast<const v4f*>(lds4) + A4;
 
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
-  const int pt = w % NT; w /= NT;
-  const int nn = w % NN;
-  const int g = w / NN;
+  const int nn = w % NN; w /= NN;      // the N tiles of one pixel tile are neighbours in launch order: they share the halo in L2
+  const int pt = w % NT;
+  const int g = w / NT;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int tg = wave >> 1, xh = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img0 = (pt / PARTS) * NI, part = pt % PARTS;
   const int y0 = part * (2 * G_::TROWS) - 1;               // conv-input row of halo row 0 (column origin is -1)
   const VVSrc s = vv_make_src(p, g, H_, H_);
@@ -77,47 +80,33 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   const int co0 = nn * 32;
   const float* __restrict__ wg = p.w + (int64_t)g * p.w_gstride;
 
-  // ---- staging set-up (once per workgroup)
+  // ---- halo staging set-up (as in wino_conv_kernel)
   float4 r[NIT];
-  int pix[NIT];          // source pixel offset relative to the tile origin, < 0: never valid
-  short hyv[NIT], imv[NIT];
-  int slot[NIT];         // destination float4 index in LDS
+  int slot[NIT];
+  unsigned valid = 0;
+  unsigned voff[NIT];
+  int pixv[NIT];
+  const int tile = (img0 * H_ + y0) * H_ - 1;
+  const int q4 = (tid % Q) * 4;
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
     const int it = tid + k * WN;
     const int q = it % Q, hp = it / Q;
     const int hx = hp % HW, t = hp / HW;
-    hyv[k] = (short)(t % HH);
-    imv[k] = (short)(t / HH);
-    const int x = hx - 1;
-    const bool ok = (NITEMS % WN == 0 || it < NITEMS) && (unsigned)x < (unsigned)H_;
-    pix[k] = ok ? (imv[k] * H_ + hyv[k]) * H_ + hx : -(1 << 30);
-    slot[k] = (NITEMS % WN == 0 || it < NITEMS) ? ((imv[k] * HH + hyv[k]) * HW + (hx & 1) * HWH + (hx >> 1)) * S4 + q : -1;
-  }
-  unsigned boff[NBT];
-  float4 rb[NBT];
-#pragma unroll
-  for (int k = 0; k < NBT; ++k) {
-    const int it = tid + k * WN;
-    const int col = it & 31, row = it >> 5;                // row = xinu*2 + half
-    boff[k] = (unsigned)((((row >> 1) * KQ) * 2 + (row & 1)) * Cout + co0 + col) * 16u;
+    const int hy = t % HH, im = t / HH;
+    const bool inr = NITEMS % WN == 0 || it < NITEMS;
+    const int y = y0 + hy;
+    const bool ok = inr && (unsigned)(hx - 1) < (unsigned)H_ && (unsigned)y < (unsigned)H_ && (img0 + im) < s.B;
+    valid |= ok ? (1u << k) : 0u;
+    pixv[k] = (im * H_ + hy) * H_ + hx;
+    slot[k] = inr ? ((im * HH + hy) * HW + (hx & 1) * HWH + (hx >> 1)) * S4 + q : -1;
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned bvo = (unsigned)(half * Cout + co0 + l31) * 16u;                // this lane inside a [2][Cout] float4 slab
+  const int bnu = KQ * 2 * Cout * 16;                                            // bytes between nu slabs
+  const int bxi = xi * 4 * bnu;
   float4 sa, sb;
   bool act = false;
-  // Everything about an item that does not depend on the chunk is computed ONCE: its validity (image row / image / column inside
-  // the tensor) and its byte offset inside the source tensor; a chunk only moves the scalar offset of the buffer load.  A
-  // concat input (VV_IN_CAT) switches to its second tensor at csplit: the offsets are rebuilt there (once per workgroup).
-  unsigned valid = 0;
-  unsigned voff[NIT];
-  const int tile = (img0 * H_ + y0) * H_ - 1;
-  const int q4 = (tid % Q) * 4;
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int y = y0 + hyv[k];
-    const bool ok = (unsigned)y < (unsigned)H_ && (img0 + imv[k]) < s.B && pix[k] >= 0;
-    valid |= ok ? (1u << k) : 0u;
-  }
   __amdgpu_buffer_rsrc_t rs;
   int cur_second = -1, soff0 = 0;
   auto set_source = [&](const bool second) {
@@ -127,7 +116,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     soff0 = second ? -s.csplit * 4 : 0;
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
-      voff[k] = ((valid >> k) & 1u) ? (unsigned)((tile + pix[k]) * cs + q4) * 4u : 0x80000000u;
+      voff[k] = ((valid >> k) & 1u) ? (unsigned)((tile + pixv[k]) * cs + q4) * 4u : 0x80000000u;
     cur_second = second ? 1 : 0;
   };
   auto issue = [&](const int c0) {
@@ -139,171 +128,177 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
     const int second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit));
     if (second != cur_second) set_source(second != 0);
+#if !(VV_EXPM & 2)
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[k], c0 * 4 + soff0, 0);
       r[k] = make_float4(v.x, v.y, v.z, v.w);
     }
-    const int so = (c0 >> 3) * 2 * Cout * 16;
-#pragma unroll
-    for (int k = 0; k < NBT; ++k) {
-      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rsW, boff[k], so, 0);
-      rb[k] = make_float4(v.x, v.y, v.z, v.w);
-    }
+#endif
   };
-  auto commit = [&](const int bo) {                        // bo: float4 offset of the destination staging buffer
+  auto commit = [&]() {
+#if (VV_EXPM & 32)
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
-      if (NITEMS % WN == 0 || k < NIT - 1 || slot[k] >= 0) {      // only the last item of a ragged item count can be void
+      if (NITEMS % WN == 0 || k < NIT - 1 || slot[k] >= 0) {
         float4 v = r[k];
         if (act && ((valid >> k) & 1u)) v = vv_act4(v, sa, sb);
-        lds4[bo + slot[k]] = v;
+        lds4[slot[k]] = v;
       }
-#pragma unroll
-    for (int k = 0; k < NBT; ++k) lds4[bo + A4 + tid + k * WN] = rb[k];
+  };
+  auto load_u = [&](const int c0, const int n) -> v4f {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsW, bvo, bxi + n * bnu + (c0 >> 3) * 2 * Cout * 16, 0);
   };
 
   // ---- this lane's tile and its patch origin in LDS
-  const int tt = tg * 32 + l31;
-  const int tim = tt / TPW, trem = tt % TPW;
+  const int tim = l31 / TPW, trem = l31 % TPW;
   const int tyl = trem / TPI, tx = trem % TPI;
-  // patch pixel (a, b): halo row 2*tyl + a, halo column 2*tx + b -> plane (b & 1), slot tx + (b >> 1)
   const int pbase = ((tim * HH + 2 * tyl) * HW + tx) * S4 + half;
-  auto patch = [&](const int bo, const int a, const int b) -> v4f {
-    return ldsA[bo + pbase + (a * HW + (b & 1) * HWH + (b >> 1)) * S4];
+  auto patch = [&](const int a, const int b) -> v4f {
+    return ldsA[pbase + (a * HW + (b & 1) * HWH + (b >> 1)) * S4];
   };
+  // B^T rows: xi 0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3   ->   R = d[a1] + sg * d[a2]
+  const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+  const float sg = xi == 1 ? 1.f : -1.f;
 
-  v16f acc[2][4];
+  v16f acc[4];
+  v4f u[4];
+  // Order of the memory instructions (loads return in order, one counter): the halo loads of the NEXT chunk are issued at the
+  // start of a chunk, before this chunk's tap loads; each tap load goes out right after the four MFMAs that read the registers
+  // it overwrites, one chunk ahead of its use.  sched_barrier keeps the compiler from sinking the loads to their first use
+  // (left alone it does: one L2 round trip per chunk with nothing else in flight); VALU / SALU / LDS instructions may cross.
+  const int klast = CinP - CK;
+  auto compute = [&](const int c0, const auto first, const auto more) {
+    const int kn = c0 + CK;
+    const int knext = kn < klast ? kn : klast;             // the last chunk re-reads its own taps (unused)
+    // (compile-time: a run-time branch around the loads makes the wait-count pass assume the shorter queue on both sides)
+    if constexpr (decltype(more)::value) issue(kn);
+    v4f R[4];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+    for (int b = 0; b < 4; ++b) {
+      const v4f d1 = patch(a1, b), d2 = patch(a2, b);
+      R[b] = d1 + sg * d2;
+    }
+    v4f V[4];
+    V[0] = R[0] - R[2];
+    V[1] = R[1] + R[2];
+    V[2] = R[2] - R[1];
+    V[3] = R[1] - R[3];
+    __builtin_amdgcn_sched_barrier(SB_MASK);
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < 4; ++n) {
+#if (VV_EXPM & 1)
+      if (decltype(first)::value)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[x][n][i] = 0.f;
-
-  auto compute = [&](const int bo) {
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      // B^T rows: xi 0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3   ->   R = d[a1] + sg * d[a2]   (wave-uniform a1, a2, sg)
-      const int xi = 2 * xh + x;
-      const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
-      const float sg = xi == 1 ? 1.f : -1.f;
-      v4f R[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-#if VV_EXP == 2
-        R[b] = patch(bo, a1, b);
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+      acc[n][0] += V[n].x * u[n].x + V[n].y * u[n].y + V[n].z * u[n].z + V[n].w * u[n].w;
 #else
-        const v4f d1 = patch(bo, a1, b), d2 = patch(bo, a2, b);
-        R[b] = d1 + sg * d2;
-#endif
+      if constexpr (decltype(first)::value) {   // the accumulators start from the instruction's inline-constant 0
+        const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[n].x, z, 0, 0, 0);
+      } else {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[n].x, acc[n], 0, 0, 0);
       }
-      v4f V[4];
-#if VV_EXP == 2
-      V[0] = R[0]; V[1] = R[1]; V[2] = R[2]; V[3] = R[3];
-#else
-      V[0] = R[0] - R[2];
-      V[1] = R[1] + R[2];
-      V[2] = R[2] - R[1];
-      V[3] = R[1] - R[3];
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[n].y, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[n].z, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[n].w, acc[n], 0, 0, 0);
 #endif
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const v4f u = ldsB[bo + ((xi * 4 + n) * 2 + half) * 32 + l31];
-#if VV_EXP == 1
-        acc[x][n][0] += V[n].x * u.x + V[n].y * u.y + V[n].z * u.z + V[n].w * u.w;
-#else
-        acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u.x, acc[x][n], 0, 0, 0);
-        acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u.y, acc[x][n], 0, 0, 0);
-        acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u.z, acc[x][n], 0, 0, 0);
-        acc[x][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u.w, acc[x][n], 0, 0, 0);
+#if !(VV_EXPM & 4)
+      u[n] = load_u(knext, n);
 #endif
-      }
+      __builtin_amdgcn_sched_barrier(SB_MASK);
     }
   };
 
   issue(0);
-  for (int c0 = 0; c0 < CinP; c0 += CK) {
-#if VV_EXP != 5
-    if (c0) __syncthreads();            // every wave finished reading the previous chunk
-#endif
-#if VV_EXP == 3
-    if (c0 == 0)
-#endif
-    commit(0);
-#if VV_EXP != 5
+#pragma unroll
+  for (int n = 0; n < 4; ++n) u[n] = load_u(0, n);
+  commit();
+  __syncthreads();
+  const std::true_type yes{};
+  const std::false_type no{};
+  if (CK >= CinP) {
+    compute(0, yes, no);
+  } else {
+    compute(0, yes, yes);
+    int c0 = CK;
+    for (; c0 + CK < CinP; c0 += CK) {
+      __syncthreads();                  // every wave finished reading the previous chunk
+      commit();
+      __syncthreads();
+      compute(c0, no, yes);
+    }
     __syncthreads();
-#endif
-#if VV_EXP == 4
-    if (false)
-#endif
-    if (c0 + CK < CinP) issue(c0 + CK);
-    compute(0);
+    commit();
+    __syncthreads();
+    compute(c0, no, no);
   }
 
-  // ---- epilogue.  Output transform of this wave's xi half:  T[x][q] = sum_nu M[x][nu] A[nu][q],  A^T = [1 1 1 0; 0 1 -1 -1]
-  //      xh = 0 (xi 0,1): Y[0][q] = T[0][q] + T[1][q],  Y[1][q] = T[1][q]
-  //      xh = 1 (xi 2,3): Y[0][q] = T[0][q],            Y[1][q] = -T[0][q] - T[1][q]        (T indexed by local x)
+  // ---- epilogue.  Columns in registers:  T[0] = M0 + M1 + M2,  T[1] = M1 - M2 - M3  (M = this wave's xi, indexed by nu);
+  //      rows across the four waves through LDS:  Y[0] = T(xi0) + T(xi1) + T(xi2),  Y[1] = T(xi1) - T(xi2) - T(xi3).
+  //      Wave w finishes accumulator registers 4w .. 4w+3 = tiles 8w .. 8w+7 (both rows): 16 buffer stores per wave.
   __syncthreads();                      // all MFMA-phase LDS reads done: LDS becomes the exchange buffer
-  float* ex = lds + (tg * 4) * 16 * 64 + lane;
-  float bias = 0.f, s1 = 0.f, s2 = 0.f;
-  const bool relu = (p.pad0 & VV_CONV_RELU) != 0;
-  if (xh == 0 && p.bias) bias = p.bias[(int64_t)g * p.bias_gstride + co0 + l31];
-  float y4[16][4];
+  v2f* ex2 = reinterpret_cast<v2f*>(lds) + lane;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const float t00 = acc[0][0][i] + acc[0][1][i] + acc[0][2][i], t01 = acc[0][1][i] - acc[0][2][i] - acc[0][3][i];
-    const float t10 = acc[1][0][i] + acc[1][1][i] + acc[1][2][i], t11 = acc[1][1][i] - acc[1][2][i] - acc[1][3][i];
-    if (xh == 0) {
-      y4[i][0] = t00 + t10; y4[i][1] = t01 + t11; y4[i][2] = t10; y4[i][3] = t11;
-    } else {
-      y4[i][0] = t00; y4[i][1] = t01; y4[i][2] = -t00 - t10; y4[i][3] = -t01 - t11;
-    }
-  }
-  if (xh == 1) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-      for (int pq = 0; pq < 4; ++pq) ex[(pq * 16 + i) * 64] = y4[i][pq];
+    const v2f t = {acc[0][i] + acc[1][i] + acc[2][i], acc[1][i] - acc[2][i] - acc[3][i]};
+    ex2[(xi * 16 + i) * 64] = t;
   }
   __syncthreads();
-  float* __restrict__ outg = p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff;
+  const float bias = p.bias ? p.bias[(int64_t)g * p.bias_gstride + co0 + l31] : 0.f;
+  const float lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();     // VV_CONV_RELU: BatchNorm folded into the filter (eval)
+  constexpr int LP = TPI > 4 ? 8 : (TPI == 4 ? 2 * H_ : H_ * H_);        // pixels between the two lane halves (tile + 4)
   const int ocs = p.out.cstride;
-  if (xh == 0) {
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+      p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff, 0, 0x7FFFFFFF, 0x00020000);
+  const int vo = (half * LP * ocs + co0 + l31) * 4;
+  const v2f* exw = ex2 + xi * 4 * 64;
+  v2f s12 = {0.f, 0.f}, q12 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;       // tile index inside the wave's group of 32
-      const int t2 = tg * 32 + row;
-      const int im = t2 / TPW, rem = t2 % TPW;
-      const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
-      const int img = img0 + im;
-      if (img < p.B) {
-        float* o = outg + ((int64_t)(img * H_ + oy) * H_ + ox) * ocs + co0 + l31;
-#pragma unroll
-        for (int pq = 0; pq < 4; ++pq) {
-          float v = y4[i][pq] + ex[(pq * 16 + i) * 64] + bias;
-          if (relu) v = fmaxf(v, 0.f);          // VV_CONV_RELU: BatchNorm folded into the filter (eval mode), ReLU here
-          o[((pq >> 1) * H_ + (pq & 1)) * ocs] = v;
-          s1 += v; s2 = fmaf(v, v, s2);
-        }
+  for (int j = 0; j < 4; ++j) {
+    const int t2 = xi * 8 + j;                                   // wave-uniform part of the tile index
+    const int im = t2 / TPW, rem = t2 % TPW;
+    const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
+    const int img = img0 + im + (TPW == 4 ? half : 0);
+    if (img < p.B) {
+      const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
+      v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
+      ya = __builtin_elementwise_max(ya, (v2f){lo, lo});
+      yb = __builtin_elementwise_max(yb, (v2f){lo, lo});
+      const int so = (((img0 + im) * H_ + oy) * H_ + ox) * ocs * 4;
+      const float a0 = ya[0], a1v = ya[1], b0 = yb[0], b1 = yb[1];
+#if (VV_EXPM & 8)
+      if (a0 + a1v + b0 + b1 == 123.456f)
+#endif
+      {
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0), rsO, vo, so, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a1v), rsO, vo, so + ocs * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b0), rsO, vo, so + H_ * ocs * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b1), rsO, vo, so + (H_ + 1) * ocs * 4, 0);
       }
+      s12 += ya + yb;
+      q12 = __builtin_elementwise_fma(ya, ya, q12);
+      q12 = __builtin_elementwise_fma(yb, yb, q12);
     }
   }
   if (p.stats) {
-    __syncthreads();
+    float s1 = s12.x + s12.y, s2 = q12.x + q12.y;
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
-    if (xh == 0 && half == 0) {
-      lds[tg * 32 + l31] = s1;
-      lds[NTG * 32 + tg * 32 + l31] = s2;
+    float* sp = lds + L4 * 4;
+    if (half == 0) {
+      sp[xi * 32 + l31] = s1;
+      sp[(4 + xi) * 32 + l31] = s2;
     }
     __syncthreads();
     if (tid < 32) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < NTG; ++k) {
-        t1 += lds[k * 32 + tid];
-        t2 += lds[NTG * 32 + k * 32 + tid];
+      for (int k = 0; k < 4; ++k) {
+        t1 += sp[k * 32 + tid];
+        t2 += sp[(4 + k) * 32 + tid];
       }
       float* st = p.stats + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
       st[0] = t1;
