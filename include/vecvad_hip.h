@@ -129,7 +129,8 @@ typedef struct vv_wgrad_params {
   vv_view src1; int32_t csplit;
   int32_t pad0;      /* flags: bit 8 (256) = Winograd F(2x2,3x3) form for VV_CONV3 (dU = sum_tiles V^T dM, dg = G^T dU G; same
                         tiles, k-split and slabs, 2.25x fewer MFMA cycles, a few ulp from the direct form; 4 waves x 16 GEMMs on the 32^2 /
-                        16^2 levels, 8 waves x 8 GEMMs below), bit 9 (512) = force the eight-wave form; low bits: bring-up */
+                        16^2 levels, 8 waves x 8 GEMMs below), bit 9 (512) = force the eight-wave form, bit 10 (1024) = one xi row per wave (4 waves x 4
+                        GEMMs, three workgroups per CU: pick ksplit for 768 workgroup slots; needs W == H in {32,16,8,4}); low bits: bring-up */
   const int32_t* chmap;
   vv_view dy;        /* gradient wrt the conv output (CONV3: HxW; CONVT: 2Hx2W) */
   float* partial;    /* [G][nslab][9][32][32] with nslab = (CinP/32... see vv_wgrad_nslab) */

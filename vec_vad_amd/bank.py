@@ -232,7 +232,9 @@ class UNetBank:
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
-        self.wgrad_flag = int(os.environ.get('VV_WGRAD_FLAG', '256'))     # 256: Winograd (variant per level), 512: eight-wave form
+        # Winograd weight-gradient kernel: 1024 one xi per wave (three workgroups per CU), 256 four / eight waves (one per CU,
+        # variant per level), 512 eight-wave form
+        self.wgrad_flag = int(os.environ.get('VV_WGRAD_FLAG', '1024'))
         direct = [(k, v) for k, v in lay.pk.items() if not (self.wino and k[0] == 'c')]
         ents = (L.PackEntry * len(direct))()
         mx = 0
@@ -545,7 +547,10 @@ class UNetBank:
         for l in lay.convs:
             nci, nco = (l.cinp + 31) // 32, l.cout // 32
             nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
-            ks = _pick_ksplit(Ga * nci * nco, nt)
+            if self.wino_wgrad and self.wgrad_flag == 1024 and not self.cflag:
+                ks = _pick_ksplit(Ga * nci * nco, nt, ncu=768, max_wg=3072)      # three workgroups per CU
+            else:
+                ks = _pick_ksplit(Ga * nci * nco, nt)
             wplan['c%d' % l.idx] = (ks, nci * nco * ks)
             if self.cflag and self.bf16_wgrad:
                 # bf16 weight gradient: HBM bound, one workgroup (up to 512 registers per lane) per CU

@@ -59,6 +59,14 @@ __device__ __forceinline__ float4 vv_max4(float4 p, float4 q) {
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+// (x.lo + y.hi, x.lo - y.hi) in ONE v_pk_add_f32 (operand-half selection + sign on the high result); the compiler needs three
+// instructions for the same expression.  The result must not feed an MFMA within the next two issue slots (the compiler does
+// not see the VALU -> MFMA operand hazard through inline asm): every call site has several instructions in between.
+__device__ __forceinline__ v2f vv_pk_lo_pm_hi(const v2f x, const v2f y) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 
 // 4 floats -> 4 bf16 (round to nearest even), packed in channel order
 __device__ __forceinline__ uint2 vv_pack_bf16x4(float4 v) {

@@ -289,8 +289,12 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
   };
 
-  // operand rows: V[xi][nu] / M[xi][nu] of the k-step in flight; row xi of the NEXT step overwrites row xi of this one
-  float V[4][4], M[4][4], dq[2][2];
+  // operand rows: V[xi][nu] / M[xi][nu] of the k-step in flight; row xi of the NEXT step overwrites row xi of this one.  Kept as
+  // register pairs so that the transforms are packed-fp32 instructions (two results each):
+  //   V03 = (V0, V3), V12 = (V1, V2),  T = (t0, t1) = (M0, -M3), M12 = (M1, M2).
+  // Signs that would cost an instruction are folded into the epilogue: the accumulators hold  s(xi) s(nu) dU  with
+  // s(3) = -1 (row xi = 3 uses +dY[1][.] instead of -dY[1][.], column nu = 3 uses +t1 instead of -t1).
+  v2f V03[4], V12[4], T[4], M12[4], dq0, dq1;
   const float *pA, *pB;                 // patch origin / dy origin of the step whose rows are being generated
   auto step_addr = [&](const float* tA, const float* tB, const int j) {
     const int tt = wave * TPWV + 2 * j + half;
@@ -300,43 +304,39 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     pB = tB + ((im * TH + 2 * tyl) * TW + 2 * txl) * 32 + l31;
   };
   auto read_dy = [&]() {
-    dq[0][0] = pB[0]; dq[0][1] = pB[32];
-    dq[1][0] = pB[TW * 32]; dq[1][1] = pB[TW * 32 + 32];
+    dq0 = (v2f){pB[0], pB[32]};
+    dq1 = (v2f){pB[TW * 32], pB[TW * 32 + 32]};
   };
   // Row xi of V = B^T d B and of dM = A dY A^T is produced in two stages one MFMA group apart: read_row issues its 8 patch
   // reads into pr[], xform_row (a group later, the reads have landed) does the arithmetic.
   //   B^T rows: d0-d2, d1+d2, d2-d1, d1-d3          A rows: (1,0) (1,1) (1,-1) (0,-1)
-  float pr[8];
+  v2f pr[4];                            // [patch row a1 | a2][columns 01 | 23]
   auto read_row = [&](auto XI, auto HALF) {             // HALF 0: patch row a1, HALF 1: patch row a2
     constexpr int xi = XI.value;
     constexpr int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
     constexpr int a = HALF.value ? a2 : a1;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) pr[HALF.value * 4 + b] = pA[(a * AHW + b) * 32];
+    pr[HALF.value * 2 + 0] = (v2f){pA[(a * AHW + 0) * 32], pA[(a * AHW + 1) * 32]};
+    pr[HALF.value * 2 + 1] = (v2f){pA[(a * AHW + 2) * 32], pA[(a * AHW + 3) * 32]};
   };
   auto xform_row = [&](auto XI) {
     constexpr int xi = XI.value;
-    float r[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) r[b] = xi == 1 ? pr[b] + pr[4 + b] : pr[b] - pr[4 + b];
-    V[xi][0] = r[0] - r[2];
-    V[xi][1] = r[1] + r[2];
-    V[xi][2] = r[2] - r[1];
-    V[xi][3] = r[1] - r[3];
-    float t0, t1;                       // T[xi][q] = sum_p A[xi][p] dY[p][q]
-    if constexpr (xi == 0) { t0 = dq[0][0]; t1 = dq[0][1]; }
-    else if constexpr (xi == 1) { t0 = dq[0][0] + dq[1][0]; t1 = dq[0][1] + dq[1][1]; }
-    else if constexpr (xi == 2) { t0 = dq[0][0] - dq[1][0]; t1 = dq[0][1] - dq[1][1]; }
-    else { t0 = -dq[1][0]; t1 = -dq[1][1]; }
-    M[xi][0] = t0;
-    M[xi][1] = t0 + t1;
-    M[xi][2] = t0 - t1;
-    M[xi][3] = -t1;
+    const v2f r01 = xi == 1 ? pr[0] + pr[2] : pr[0] - pr[2];
+    const v2f r23 = xi == 1 ? pr[1] + pr[3] : pr[1] - pr[3];
+    V03[xi] = r01 - r23;                                // (r0 - r2, r1 - r3)
+    V12[xi] = vv_pk_lo_pm_hi(r23, r01);                 // (r2 + r1, r2 - r1)
+    v2f t;                                              // T[xi][q] = sum_p A[xi][p] dY[p][q]   (xi = 3: sign folded)
+    if constexpr (xi == 0) t = dq0;
+    else if constexpr (xi == 1) t = dq0 + dq1;
+    else if constexpr (xi == 2) t = dq0 - dq1;
+    else t = dq1;
+    T[xi] = t;
+    M12[xi] = vv_pk_lo_pm_hi(t, t);                     // (t0 + t1, t0 - t1)
   };
   auto gen_row = [&](auto XI) {                         // both stages back to back (start of a staged tile only)
     read_row(XI, std::integral_constant<int, 0>{});
     read_row(XI, std::integral_constant<int, 1>{});
     xform_row(XI);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   begin_tile(ks, true);
@@ -366,7 +366,9 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
       constexpr bool more = j + 1 < NKS;
       vv_static_for<0, 16>([&](auto SS) {
         constexpr int sl = SS.value, grp = sl >> 2, nu = sl & 3, slot = j * 16 + sl;
-        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[grp][nu], M[grp][nu], acc[sl], 0, 0, 0);
+        const float va = nu == 0 ? V03[grp].x : (nu == 1 ? V12[grp].x : (nu == 2 ? V12[grp].y : V03[grp].y));
+        const float mb = nu == 0 ? T[grp].x : (nu == 1 ? M12[grp].x : (nu == 2 ? M12[grp].y : T[grp].y));
+        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, mb, acc[sl], 0, 0, 0);
         // under group g: the row whose reads were issued one group earlier is transformed -- row 3 of this step (g = 0) or
         // row g-1 of the next step -- into registers consumed at least one group ago; then the reads of the following row.
         constexpr int rowa = grp == 0 ? 3 : grp - 1, rowb = grp;         // rowb: row of step j+1 whose reads are issued
@@ -396,7 +398,8 @@ wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     float c[3][4];                          // G^T dU  (rows)
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
-      const float u0 = acc[0 * 4 + nu][i], u1 = acc[1 * 4 + nu][i], u2 = acc[2 * 4 + nu][i], u3 = acc[3 * 4 + nu][i];
+      const float sn = nu == 3 ? -1.f : 1.f;            // folded signs (see the operand rows above)
+      const float u0 = sn * acc[0 * 4 + nu][i], u1 = sn * acc[1 * 4 + nu][i], u2 = sn * acc[2 * 4 + nu][i], u3 = -sn * acc[3 * 4 + nu][i];
       c[0][nu] = u0 + 0.5f * (u1 + u2);
       c[1][nu] = 0.5f * (u1 - u2);
       c[2][nu] = u3 + 0.5f * (u1 + u2);
@@ -624,6 +627,256 @@ wgrad_wino8_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-xi-per-wave form of the Winograd weight gradient: 256 threads, wave = xi.  A wave keeps the 4 GEMMs (nu = 0..3) of its
+// xi row in 64 accumulator registers and walks ALL 2x2 tiles of a staged unit, so three workgroups share a CU (<= 168
+// registers per lane, <= 53 KB of LDS) and every SIMD has three independent instruction streams: operand reads, transforms
+// and barrier waits of one run under the MFMAs of the others (the four- and eight-wave forms above have one / two).
+//   staged unit = 64 pixels (16 tiles = 8 k-steps of a tile pair) of full image width: UH rows x W x UNI images; the k-split
+//   tile (TH x W x NI, what vv_wgrad_ntiles counts) is a run of (TH / UH) * (NI / UNI) units.  Two LDS buffers per workgroup;
+//   the loads of the next unit go out under the first MFMAs of this one, their LDS writes under the last ones.
+//   Operands of k-step j+1 are built under the MFMAs of step j into the other of two register sets: 6 ds_read2_b32, 8 packed
+//   VALU instructions per 4 MFMAs.  Signs that would cost an instruction are folded into the epilogue (see the four-wave form).
+//   Epilogue: each wave folds its columns (dU G), the four xi rows meet in LDS, wave w finishes accumulator rows 4w..4w+3 of
+//   all 9 taps (G^T .) and writes them to the workgroup's slab -- the layout vv_wgrad_reduce expects.
+template <int TH, int TW, int NI, int UH, int UNI>
+__global__ void __launch_bounds__(256, 3)
+wgrad_wino3_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+  constexpr int NTH = 256, W_ = TW;
+  constexpr int AHH = UH + 2, AHW = W_ + 2;
+  constexpr int ASZ = UNI * AHH * AHW * 32, BSZ = UNI * UH * W_ * 32, USZ = ASZ + BSZ;      // floats
+  static_assert(UNI * UH * W_ == 64, "a staged unit is 64 pixels");
+  constexpr int RB = TH / UH, UPT = RB * (NI / UNI);                       // row blocks / units per k-split tile
+  constexpr int TXT = W_ / 2, TYT = UH / 2, TPI = TXT * TYT;               // 2x2 tiles per image of a unit
+  constexpr int NKS = 8;                                                   // k-steps (tile pairs) per unit
+  constexpr int EXF = 4 * 3 * 16 * 64;                                     // epilogue exchange [xi][b][16 regs][64 lanes]
+  constexpr int LSZ = 2 * USZ > EXF ? 2 * USZ : EXF;
+  static_assert(LSZ * 4 * 3 <= 160 * 1024, "three workgroups per CU");
+  constexpr int NIA = UNI * AHH * AHW * 8, NIB = 64 * 8;                   // float4 items
+  constexpr int NPA = (NIA + NTH - 1) / NTH, NPB = NIB / NTH, NP = NPA + NPB;
+  constexpr int NSLOT = NKS * 4, C0 = NSLOT - NP - 1;
+  static_assert(C0 >= NP + 8, "not enough MFMA slots between load issue and commit");
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr bool ROWDYN = RB > 1;        // units that are not whole images: top / bottom halo row validity changes per unit
+  __shared__ float lds[LSZ];
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int KS = p.ksplit;
+  const int ks = w % KS; w /= KS;
+  const int cot = w % NCO; w /= NCO;
+  const int cit = w % NCI;
+  const int g = w / NCI;
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H;
+  const int tpi = H / TH;                                                  // k-split tiles per image (full width)
+
+  // ---- sources: layer input (re-materialised: BatchNorm+ReLU / concat) and dy
+  const VVSrc sa = vv_make_src(p, g, H, W_);
+  const int q8 = tid & 7, cA = cit * 32 + q8 * 4, cB = cot * 32 + q8 * 4;
+  const bool cok = cA < p.CinP;
+  const bool act = (sa.mode == VV_IN_ACT) || (sa.mode == VV_IN_CAT && cA < sa.csplit);
+  float4 sca = make_float4(1.f, 1.f, 1.f, 1.f), scb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act && cok) {
+    sca = *reinterpret_cast<const float4*>(sa.a + cA);
+    scb = *reinterpret_cast<const float4*>(sa.b + cA);
+  }
+  const bool second = __builtin_amdgcn_readfirstlane((int)((sa.mode == VV_IN_CAT) && cit * 32 >= sa.csplit)) != 0;
+  const float* baseA = second ? sa.p1 + sa.co1 - sa.csplit : sa.p0 + sa.co0;
+  const int csA = second ? sa.cs1 : sa.cs0;
+  const float* baseB = p.dy.ptr + (int64_t)g * p.dy.gstride + p.dy.coff;
+  const int csB = p.dy.cstride;
+
+  // ---- staging items (once per workgroup): byte offset inside the source relative to the unit's origin pixel, LDS slot
+  unsigned voffA[NPA], voffB[NPB];
+  int slotA[NPA];
+  unsigned topm = 0, botm = 0;           // items in the top / bottom halo row (ROWDYN)
+  int imA[NPA];                          // image of the item inside the unit (UNI > 1)
+#pragma unroll
+  for (int k = 0; k < NPA; ++k) {
+    const int it = tid + k * NTH;
+    const int hp = it >> 3;
+    const int hx = hp % AHW, t = hp / AHW;
+    const int hy = t % AHH, im = t / AHH;
+    bool ok = (NIA % NTH == 0 || it < NIA) && cok && (unsigned)(hx - 1) < (unsigned)W_;
+    if (!ROWDYN) ok = ok && hy != 0 && hy != AHH - 1;                      // whole images: the halo rows are padding
+    topm |= (hy == 0) ? (1u << k) : 0u;
+    botm |= (hy == AHH - 1) ? (1u << k) : 0u;
+    imA[k] = im;
+    voffA[k] = ok ? (unsigned)(((im * H + hy) * W_ + hx) * csA + cA) * 4u : OOB;
+    slotA[k] = (NIA % NTH == 0 || it < NIA) ? hp * 32 + q8 * 4 : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < NPB; ++k) {
+    const int px = (tid + k * NTH) >> 3;                                   // pixel of the unit: [im][y][x]
+    const int im = px / (UH * W_), rem = px % (UH * W_);
+    voffB[k] = (unsigned)((im * H * W_ + rem) * csB + cB) * 4u;
+  }
+
+  // ---- unit walk: k-split tiles ks, ks + KS, ... < NT, UPT units each
+  int pt_n = ks, u_n = 0;                // the unit whose loads are issued next
+  float4 r[NP];
+  unsigned validA = 0;                   // of the unit in r[] (commit applies the activation to real pixels only)
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  unsigned kill = 0;
+  bool liveB[NPB];
+  auto begin_unit = [&]() {              // scalar part of the next unit's addresses; afterwards pt_n / u_n point one further
+    const bool live = pt_n < NT;
+    const int pt = live ? pt_n : ks;
+    const int img0 = (pt / tpi) * NI + (u_n / RB) * UNI;
+    const int uy0 = (pt % tpi) * TH + (u_n % RB) * UH;
+    // origin pixel of the halo tile: (img0, uy0 - 1, -1); may lie before the tensor (top row of image 0): 64-bit base
+    const int64_t oa = ((int64_t)(img0 * H + uy0 - 1) * W_ - 1) * csA;
+    const int64_t ob = ((int64_t)(img0 * H + uy0) * W_) * csB;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseA + oa), 0, 0x7FFFFFFF, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(baseB + ob), 0, 0x7FFFFFFF, 0x00020000);
+    const bool img_ok = live && img0 < p.B;                                // UNI == 1: the whole unit
+    kill = img_ok ? 0u : 0xFFFFFFFFu;
+    if (ROWDYN) {
+      if (uy0 == 0) kill |= topm;
+      if (uy0 + UH == H) kill |= botm;
+    }
+    if (UNI > 1) {
+#pragma unroll
+      for (int k = 0; k < NPA; ++k)
+        if (img0 + imA[k] >= p.B) kill |= 1u << k;
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+      const int im = ((tid + k * NTH) >> 3) / (UH * W_);
+      liveB[k] = live && img0 + im < p.B;
+    }
+    validA = 0;
+    if (++u_n == UPT) { u_n = 0; pt_n += KS; }
+  };
+  auto load_piece = [&](auto K) {
+    constexpr int k = K.value;
+    if constexpr (k < NPA) {
+      const bool ok = !((kill >> k) & 1u) && voffA[k] != OOB;
+      validA |= ok ? (1u << k) : 0u;
+      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? voffA[k] : OOB, 0, 0);
+      r[k] = make_float4(v.x, v.y, v.z, v.w);
+    } else {
+      const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rsB, liveB[k - NPA] ? voffB[k - NPA] : OOB, 0, 0);
+      r[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  auto commit_piece = [&](auto K, float* buf) {
+    constexpr int k = K.value;
+    if constexpr (k < NPA) {
+      if (NIA % NTH == 0 || k < NPA - 1 || slotA[k] >= 0) {
+        float4 v = r[k];
+        if (act && ((validA >> k) & 1u)) v = vv_act4(v, sca, scb);
+        *reinterpret_cast<float4*>(buf + slotA[k]) = v;
+      }
+    } else {
+      *reinterpret_cast<float4*>(buf + ASZ + ((tid + (k - NPA) * NTH) >> 3) * 32 + q8 * 4) = r[k];
+    }
+  };
+
+  // ---- operands.  B^T row xi: d[a1] + sg d[a2];  A row xi: c0 dY[0][.] + c1 dY[1][.]  (xi = 3: +dY[1] instead of -dY[1], folded)
+  const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+  const float sg = xi == 1 ? 1.f : -1.f;
+  const float c0 = xi == 3 ? 0.f : 1.f, c1 = xi == 0 ? 0.f : (xi == 2 ? -1.f : 1.f);
+  const int ao1 = a1 * AHW * 32, ao2 = a2 * AHW * 32;
+  // lane origin inside a unit buffer: tile pair j -> tiles 2j + half; TXT is even, so `half` only moves one tile column
+  const int laneA = half * 64 + l31, laneB = ASZ + half * 64 + l31;
+  v2f V03[2], V12[2], T[2], M12[2];      // two register sets: step j+1 is built while the MFMAs of step j run
+  v2f pa01, pa23, pb01, pb23, dq0, dq1;
+  auto read_step = [&](const float* ub, auto J) {
+    constexpr int j = J.value;
+    constexpr int tt = 2 * j;
+    constexpr int im = tt / TPI, rem = tt % TPI, tyl = rem / TXT, txl = rem % TXT;
+    const float* pA = ub + laneA + ((im * AHH + 2 * tyl) * AHW + 2 * txl) * 32;
+    const float* pB = ub + laneB + ((im * UH + 2 * tyl) * W_ + 2 * txl) * 32;
+    pa01 = (v2f){pA[ao1], pA[ao1 + 32]};
+    pa23 = (v2f){pA[ao1 + 64], pA[ao1 + 96]};
+    pb01 = (v2f){pA[ao2], pA[ao2 + 32]};
+    pb23 = (v2f){pA[ao2 + 64], pA[ao2 + 96]};
+    dq0 = (v2f){pB[0], pB[32]};
+    dq1 = (v2f){pB[W_ * 32], pB[W_ * 32 + 32]};
+  };
+  auto xform_step = [&](auto SET) {
+    constexpr int st = SET.value;
+    const v2f r01 = __builtin_elementwise_fma((v2f){sg, sg}, pb01, pa01);
+    const v2f r23 = __builtin_elementwise_fma((v2f){sg, sg}, pb23, pa23);
+    V03[st] = r01 - r23;                                // (r0 - r2, r1 - r3)
+    V12[st] = vv_pk_lo_pm_hi(r23, r01);                 // (r2 + r1, r2 - r1)
+    const v2f t = __builtin_elementwise_fma((v2f){c1, c1}, dq1, c0 * dq0);
+    T[st] = t;                                          // (M0, -M3)
+    M12[st] = vv_pk_lo_pm_hi(t, t);                     // (t0 + t1, t0 - t1)
+  };
+
+  v16f acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+  // ---- first unit
+  begin_unit();
+  vv_static_for<0, NP>([&](auto K) { load_piece(K); });
+  vv_static_for<0, NP>([&](auto K) { commit_piece(K, lds); });
+  __syncthreads();
+  const int nunits = ((NT - ks + KS - 1) / KS) * UPT;
+  int cur = 0;
+  for (int un = 0; un < nunits; ++un) {
+    const float* ub = lds + cur * USZ;
+    float* nb = lds + (cur ^ 1) * USZ;
+    begin_unit();                        // the next unit (an unmapped one after the last: loads return zeros, harmless)
+    read_step(ub, std::integral_constant<int, 0>{});
+    xform_step(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    vv_static_for<0, NKS>([&](auto JJ) {
+      constexpr int j = JJ.value, st = j & 1;
+      constexpr bool more = j + 1 < NKS;
+      vv_static_for<0, 4>([&](auto NN) {
+        constexpr int nu = NN.value, slot = j * 4 + nu;
+        const float va = nu == 0 ? V03[st].x : (nu == 1 ? V12[st].x : (nu == 2 ? V12[st].y : V03[st].y));
+        const float mb = nu == 0 ? T[st].x : (nu == 1 ? M12[st].x : (nu == 2 ? M12[st].y : T[st].y));
+        acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, mb, acc[nu], 0, 0, 0);
+        if constexpr (more && nu == 0) read_step(ub, std::integral_constant<int, j + 1>{});
+        if constexpr (more && nu == 2) xform_step(std::integral_constant<int, st ^ 1>{});
+        if constexpr (slot < NP) load_piece(std::integral_constant<int, slot>{});
+        else if constexpr (slot >= C0 && slot < C0 + NP) commit_piece(std::integral_constant<int, slot - C0>{}, nb);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    __syncthreads();                     // next buffer complete, current buffer no longer read
+    cur ^= 1;
+  }
+
+  // ---- epilogue.  dg = G^T dU G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1].  acc[nu] = s(xi) s(nu) dU[xi][nu], s(3) = -1.
+  const float sx = xi == 3 ? -1.f : 1.f;
+  float* ex = lds + lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float u0 = acc[0][i], u1 = acc[1][i], u2 = acc[2][i], u3 = -acc[3][i];
+    const float hs = 0.5f * (u1 + u2);
+    ex[((xi * 3 + 0) * 16 + i) * 64] = sx * (u0 + hs);
+    ex[((xi * 3 + 1) * 16 + i) * 64] = sx * (0.5f * (u1 - u2));
+    ex[((xi * 3 + 2) * 16 + i) * 64] = sx * (u3 + hs);
+  }
+  __syncthreads();
+  float* out = p.partial + (int64_t)g * p.partial_gstride + ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = xi * 4 + j;
+    const int row = j + 8 * xi + 4 * half;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float d0 = ex[((0 * 3 + b) * 16 + i) * 64], d1 = ex[((1 * 3 + b) * 16 + i) * 64];
+      const float d2 = ex[((2 * 3 + b) * 16 + i) * 64], d3 = ex[((3 * 3 + b) * 16 + i) * 64];
+      const float hs = 0.5f * (d1 + d2);
+      out[(0 * 3 + b) * 1024 + row * 32 + l31] = d0 + hs;
+      out[(1 * 3 + b) * 1024 + row * 32 + l31] = 0.5f * (d1 - d2);
+      out[(2 * 3 + b) * 1024 + row * 32 + l31] = d3 + hs;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(VV_WG)
 wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO, const int nslab,
                     const float* __restrict__ partial, const int64_t partial_gstride, float* __restrict__ grad,
@@ -691,6 +944,18 @@ int launch_ww8(const vv_wgrad_params* p, hipStream_t st) {
   return VV_OK;
 }
 
+template <int TH, int TW, int NI, int UH, int UNI>
+int launch_ww3(const vv_wgrad_params* p, hipStream_t st) {
+  if (p->W != TW) return VV_ERR_UNSUPPORTED;
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  const int total = p->G * NCI * NCO * p->ksplit;
+  const int nper = (total + 7) / 8;
+  VV_LAUNCH((wgrad_wino3_kernel<TH, TW, NI, UH, UNI>), dim3(nper * 8), dim3(256), 0, st, *p, NT, NCI, NCO, total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
 template <int TH, int TW, int NI, int KIND>
 int launch_w(const vv_wgrad_params* p, hipStream_t st) {
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
@@ -717,6 +982,15 @@ extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
   if (p->kind == VV_CONV3 && (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE))
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
+  if (p->kind == VV_CONV3 && (p->pad0 & 1024)) {          // Winograd form, one xi per wave, three workgroups per CU
+    switch (p->H) {
+      case 32: return launch_ww3<8, 32, 1, 2, 1>(p, st);
+      case 16: return launch_ww3<16, 16, 1, 4, 1>(p, st);
+      case 8: return launch_ww3<8, 8, 2, 8, 1>(p, st);
+      case 4: return launch_ww3<4, 4, 8, 4, 4>(p, st);
+    }
+    return VV_ERR_UNSUPPORTED;
+  }
   if (p->kind == VV_CONV3 && (p->pad0 & 512)) {           // Winograd form, eight waves (two per SIMD)
     switch (p->H) {
       case 32: return launch_ww8<8, 32, 1>(p, st);
