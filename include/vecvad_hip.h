@@ -107,6 +107,14 @@ typedef struct vv_conv_params {
   int64_t bias_gstride;
   vv_view out;       /* output */
   float* stats;      /* NULL or [G][ntiles][2][Cout] partial sums (sum, sum of squares) over valid pixels */
+  /* vv_conv_wino only, data-gradient launches: the first reduction pass of the BatchNorm backward that consumes this output
+   * (vv_bn_bwd_reduce) done in the epilogue.  out = dA of the producing layer's activation relu(a z + b); with z that layer's
+   * conv output [G][B*H*W][Cout] (pixel stride Cout) the kernel also leaves  sum dz, sum dz * xhat  per pixel tile, dz = dA [a z + b > 0],
+   * xhat = (z - mean) invstd, in bn_partial [G][ntiles][2][Cout] -- the layout vv_bn_bwd_apply reads with VV_BNBWD_PARTIALS_PER_TILE.
+   * a / b / mean / invstd: [G][Cout] each, group stride bn_gstride.  bn_partial == NULL: off. */
+  const float* bn_z; int64_t bn_z_gstride;
+  const float* bn_a; const float* bn_b; const float* bn_mean; const float* bn_invstd; int64_t bn_gstride;
+  float* bn_partial;
 } vv_conv_params;
 
 int vv_conv_mfma(const vv_conv_params* p, vv_stream stream);
@@ -128,9 +136,8 @@ typedef struct vv_wgrad_params {
   vv_view src0; const float* a; const float* b; int64_t ab_gstride;
   vv_view src1; int32_t csplit;
   int32_t pad0;      /* flags: bit 8 (256) = Winograd F(2x2,3x3) form for VV_CONV3 (dU = sum_tiles V^T dM, dg = G^T dU G; same
-                        tiles, k-split and slabs, 2.25x fewer MFMA cycles, a few ulp from the direct form; 4 waves x 16 GEMMs on the 32^2 /
-                        16^2 levels, 8 waves x 8 GEMMs below), bit 9 (512) = force the eight-wave form, bit 10 (1024) = one xi row per wave (4 waves x 4
-                        GEMMs, three workgroups per CU: pick ksplit for 768 workgroup slots; needs W == H in {32,16,8,4}); low bits: bring-up */
+                        tiles, k-split and slabs, 2.25x fewer MFMA cycles, a few ulp from the direct form; W == H in {32,16,8,4};
+                        three workgroups per CU: pick ksplit for 768 workgroup slots); low bits: bring-up */
   const int32_t* chmap;
   vv_view dy;        /* gradient wrt the conv output (CONV3: HxW; CONVT: 2Hx2W) */
   float* partial;    /* [G][nslab][9][32][32] with nslab = (CinP/32... see vv_wgrad_nslab) */
@@ -210,6 +217,8 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
 #define VV_BNBWD_PARTIALS_PER_CUBE 2   /* vv_bn_bwd_apply: `partial` holds [G][B][2][C] written by vv_outconv_bwd */
 #define VV_BNBWD_Y_BF16 8              /* y holds bf16 elements (VV_CONV_OUT_BF16 on the forward launch) */
 #define VV_BNBWD_DA_BF16 4             /* dA (and dpool) hold bf16 elements (VV_CONV_OUT_BF16 / vv_outconv_bwd dA_bf16) */
+#define VV_BNBWD_PARTIALS_PER_TILE 16  /* vv_bn_bwd_apply: `partial` holds [G][vv_wino_ntiles(B,H)][2][C] written by the data-gradient
+                                          launch that produced dA (vv_conv_params.bn_partial): no vv_bn_bwd_reduce pass for that layer */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
   int32_t flags;

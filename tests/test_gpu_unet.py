@@ -252,6 +252,34 @@ def test_side_stream_weight_grad_is_bitwise_identical():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_bn_backward_sums_fused_into_data_gradient(monkeypatch):
+    """The first reduction pass of a layer's BatchNorm backward (sum dz, sum dz * xhat) runs in the epilogue of the Winograd
+    data-gradient launch that produces dA (vv_conv_params.bn_partial, VV_BNBWD_PARTIALS_PER_TILE) where that launch is the only
+    producer; VV_FUSE_BN_SUMS=0 keeps the separate vv_bn_bwd_reduce pass.  Same sums in another order: one step's gradients agree
+    to fp32 round-off (measured 2.2e-6 of a tensor's norm at worst, bar 1e-5); ragged batch (partial pixel tiles on the 8x8 / 4x4 levels)."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    raw, flow = O.seeded_cubes(37, 1, 11)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    grads = []
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('VV_FUSE_BN_SUMS', fuse)
+        net, _, _ = _build('net4', False)
+        net.train()
+        tr = FusedTrainer(net)
+        assert tr.bank.fuse_bn_sums == (fuse == '1')
+        tr.step_cubes(rawd, flowd, torch.arange(37, device='cuda'))
+        torch.cuda.synchronize()
+        grads.append(tr.bank.grads.clone())
+    lay = tr.bank.lay
+    worst = 0.0
+    for key, (off, shape) in lay.p.items():
+        n = int(torch.tensor(shape).prod())
+        a, b = grads[0][:, off:off + n].double(), grads[1][:, off:off + n].double()
+        worst = max(worst, ((a - b).norm() / a.norm().clamp_min(1e-30)).item())
+    assert 0.0 < worst <= 1e-5, worst          # > 0: the two paths really are different code
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_two_stream_schedules_have_every_dependency(monkeypatch, precision):
     """The two-stream schedules again, with one stream stalled before each of its launches (FusedTrainer.debug_delay): the other
@@ -415,7 +443,7 @@ def test_winograd_weight_gradient_matches_direct(H, Cin, Cout, B):
     nt = lib.vv_wgrad_ntiles(L.CONV3, B, H, H)
     ks = max(1, min(nt, 3))
     outs = []
-    for flag in (0, 256, 512):
+    for flag in (0, 256):
         part = torch.zeros(G, nci * nco * ks * 9 * 1024, device='cuda')
         grad = torch.zeros(G, Cout * Cin * 9, device='cuda')
         wp = L.WgradParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, Cin, Cout, ks, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(),

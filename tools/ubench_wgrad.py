@@ -14,8 +14,8 @@ from vec_vad_amd.bank import _pick_ksplit
 lib = L.lib()
 G, B = 6, int(os.environ.get('UB_B', '256'))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-WFLAG = int(os.environ.get('UB_WFLAG', '256'))        # 256 four / eight waves, 512 eight waves, 1024 one xi per wave
-NCU = int(os.environ.get('UB_NCU', '256'))             # workgroup slots the k-split heuristic fills
+WFLAG = 256                                            # vv_wgrad_params.pad0 bit 8: Winograd form
+NCU = int(os.environ.get('UB_NCU', '768'))             # workgroup slots the k-split heuristic fills (three workgroups per CU)
 st = torch.cuda.current_stream().cuda_stream
 LAYERS = [(32, 16, 32, 1, 'conv0'), (32, 32, 32, 2, 'conv1/13'), (32, 64, 32, 1, 'conv12'), (16, 32, 64, 1, 'conv2'), (16, 64, 64, 2, 'conv3/11'),
           (16, 128, 64, 1, 'conv10'), (8, 64, 128, 1, 'conv4'), (8, 128, 128, 2, 'conv5/9'), (8, 256, 128, 1, 'conv8'), (4, 128, 256, 1, 'conv6'),

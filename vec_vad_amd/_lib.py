@@ -27,6 +27,7 @@ CONV_OUT_BF16 = 8       # VV_CONV_OUT_BF16
 CONV_ALLSRC_BF16 = 16   # VV_CONV_ALLSRC_BF16
 CONV_RELU = 32          # VV_CONV_RELU: eval mode, BatchNorm folded into the filter, ReLU in the epilogue
 BNBWD_Y_BF16 = 8
+BNBWD_PARTIALS_PER_TILE = 16   # partial sums left by the data-gradient launch (ConvParams.bn_partial)
 WGRAD_X_BF16 = 2
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 
@@ -41,7 +42,9 @@ class ConvParams(C.Structure):
                 ('src0', View), ('a', c_vp), ('b', c_vp), ('ab_gstride', c_i64),
                 ('src1', View), ('csplit', c_i32), ('pad0', c_i32), ('chmap', c_vp),
                 ('w', c_vp), ('w_gstride', c_i64), ('bias', c_vp), ('bias_gstride', c_i64),
-                ('out', View), ('stats', c_vp)]
+                ('out', View), ('stats', c_vp),
+                ('bn_z', c_vp), ('bn_z_gstride', c_i64), ('bn_a', c_vp), ('bn_b', c_vp), ('bn_mean', c_vp), ('bn_invstd', c_vp),
+                ('bn_gstride', c_i64), ('bn_partial', c_vp)]
 
 
 class WgradParams(C.Structure):

@@ -232,9 +232,9 @@ class UNetBank:
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
-        # Winograd weight-gradient kernel: 1024 one xi per wave (three workgroups per CU), 256 four / eight waves (one per CU,
-        # variant per level), 512 eight-wave form
-        self.wgrad_flag = int(os.environ.get('VV_WGRAD_FLAG', '1024'))
+        self.wgrad_flag = 256                  # vv_wgrad_params.pad0 bit 8: Winograd form of the 3x3 weight gradient
+        # first reduction pass of the BatchNorm backward inside the data-gradient launch that produces dA (where it is the only producer)
+        self.fuse_bn_sums = os.environ.get('VV_FUSE_BN_SUMS', '1') != '0'
         direct = [(k, v) for k, v in lay.pk.items() if not (self.wino and k[0] == 'c')]
         ents = (L.PackEntry * len(direct))()
         mx = 0
@@ -535,7 +535,7 @@ class UNetBank:
         ws.dz2 = [f(Ga, B * HWp * nf), f(Ga, B * HWp * nf)]   # dy of consecutive layers alternate (weight-grad runs on a side stream)
         ws.dz = ws.dz2[0]
         nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
-        ws.bnpart = f(Ga, max(n * 2 * l.cout for n, l in zip(nblk, lay.convs)))
+        ws.bnpart = f(Ga, max(max(n, lib.vv_wino_ntiles(B, l.H)) * 2 * l.cout for n, l in zip(nblk, lay.convs)))
         ws.bnscr = f(Ga, 2 * lay.cmax)
         ws.ocpart = f(Ga, B, 4 * nf + 4)
         ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
@@ -547,7 +547,7 @@ class UNetBank:
         for l in lay.convs:
             nci, nco = (l.cinp + 31) // 32, l.cout // 32
             nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
-            if self.wino_wgrad and self.wgrad_flag == 1024 and not self.cflag:
+            if self.wino_wgrad and not self.cflag:
                 ks = _pick_ksplit(Ga * nci * nco, nt, ncu=768, max_wg=3072)      # three workgroups per CU
             else:
                 ks = _pick_ksplit(Ga * nci * nco, nt)
@@ -609,6 +609,22 @@ class UNetBank:
 
         order = [l.idx for l in reversed(lay.convs)]            # backward visiting order: 13, 12, ..., 0
 
+        def fused_producer(l):
+            """Index of the layer whose BatchNorm-backward sums the data-gradient launch of conv layer l can leave behind
+            (vv_conv_params.bn_partial): l reads relu(bn(y_j)) of the layer right before it and nobody else consumes that activation
+            (no pooling / skip / transposed-conv consumer), so dA_j is exactly this launch's output.  fp32 Winograd path only."""
+            if not (self.wino and not self.cflag and self.fuse_bn_sums) or l.mode != L.IN_ACT or l.idx == 0:
+                return None
+            j = l.src
+            if j != l.idx - 1 or j == last.idx:
+                return None
+            if any(sidx == j for (sidx, _, _, _) in lay.convT) or any(m.mode == L.IN_CAT and m.skip == j for m in lay.convs) \
+                    or any(m.mode == L.IN_POOL and m.src == j for m in lay.convs):
+                return None
+            return j
+
+        fused = {fused_producer(l) for l in lay.convs} - {None}
+
         def conv_bwd(l):
             i = l.idx
             y = ws.y[i]
@@ -622,17 +638,19 @@ class UNetBank:
             reuse_wait = ('wdone%d' % order[pos - 2],) if pos >= 2 else ()
             dA, dpool, dpg = dA_for(l)
             from_outconv = i == last.idx           # its partial sums were written by vv_outconv_bwd
+            from_dgrad = i in fused                # ... by the data-gradient launch of layer i + 1
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
                                (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0) |
+                               (L.BNBWD_PARTIALS_PER_TILE if from_dgrad else 0) |
                                (L.BNBWD_DA_BF16 if self.da16 else 0) | (L.BNBWD_Y_BF16 if self.y16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
             P.keep.append(bp)
-            if not from_outconv:
+            if not (from_outconv or from_dgrad):
                 P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i, wait=reuse_wait)
             P.add(lib.vv_bn_bwd_apply, (C.byref(bp), pbase + 4 * lay.p['c%d.g' % i][0], U, gbase + 4 * lay.p['c%d.g' % i][0],
                                         gbase + 4 * lay.p['c%d.beta' % i][0], U, ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
-                  record='dy%d' % i, wait=reuse_wait if from_outconv else ())
+                  record='dy%d' % i, wait=reuse_wait if (from_outconv or from_dgrad) else ())
             # data gradient
             if i > 0:
                 Dl = ws.D[i]
@@ -644,6 +662,13 @@ class UNetBank:
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
                                   ws.dstats.data_ptr() if l.mode == L.IN_CAT else None)
+                j = fused_producer(l)
+                if j is not None:                  # the first pass of layer j's BatchNorm backward rides on this launch's epilogue
+                    yj = ws.y[j]
+                    cp.bn_z, cp.bn_z_gstride = yj.data_ptr(), yj.stride(0)
+                    cp.bn_a, cp.bn_b = self._p(ws.ab[0, j]), self._p(ws.ab[1, j])
+                    cp.bn_mean, cp.bn_invstd = self._p(ws.ab[2, j]), self._p(ws.ab[3, j])
+                    cp.bn_gstride, cp.bn_partial = abg, ws.bnpart.data_ptr()
                 P.keep.append(cp)
                 # paired schedule: the MFMA data-gradient runs alone (the side stream has drained) ...
                 P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i,

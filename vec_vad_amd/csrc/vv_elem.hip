@@ -878,7 +878,10 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
                                float* dbeta, int64_t grad_gstride, float* scratch, vv_stream stream) {
   if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial || !gamma || !dgamma || !dbeta || !scratch) return VV_ERR_BAD_ARG;
   // VV_BNBWD_PARTIALS_PER_CUBE: the partials were left by vv_outconv_bwd (one block per cube), not by vv_bn_bwd_reduce
-  const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B : vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  // VV_BNBWD_PARTIALS_PER_TILE: ... by the Winograd data-gradient launch that produced dA (one block per pixel tile)
+  const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B
+                   : (p->flags & VV_BNBWD_PARTIALS_PER_TILE) ? vv_wino_ntiles(p->B, p->H) : vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  if (nblk <= 0) return VV_ERR_BAD_ARG;
   const int nblk_apply = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   const int64_t M = (int64_t)p->B * p->H * p->W;
   VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(32 * VV_NP), 0, (hipStream_t)stream, p->C, nblk, (double)M,

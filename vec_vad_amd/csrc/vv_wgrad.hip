@@ -230,418 +230,25 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
 //     dU[xi,nu][ci][co] = sum over 2x2 output tiles of  V[xi,nu][tile][ci] * dM[xi,nu][tile][co],     dg = G^T dU G
 // with V = B^T d B (the forward's input transform of the 4x4 input patch) and dM = A dY A^T (the 2x2 output gradients of the
 // tile): 16 multiply-adds per tile (4 pixels) and (ci, co) pair instead of 36 -- 2.25x fewer MFMA cycles than the direct form
-// above.  Same workgroup / staging structure (32 ci x 32 co x k-split, 4 waves over the tiles of each staged pixel tile, two
-// LDS buffers, staging of the next tile interleaved into the MFMA stream), but the GEMM-K index is the 2x2 tile: lanes 0-31
-// take tile 2j, lanes 32-63 tile 2j+1, lane&31 = channel, so both operands are built per lane from ds_read_b32 (conflict
-// free: consecutive lanes = consecutive channels): one xi row of V (8 patch reads, 8 adds) and of dM (<= 5 ops) per group
-// of 4 MFMAs, written into the registers of the row that was consumed one group earlier.  The 16 accumulators (256
-// registers) are folded to the 9 filter taps in the epilogue (dg = G^T dU G is linear, so it commutes with the k-split
-// sum) and leave through the same slab / vv_wgrad_reduce path as the direct kernel.
-template <int TH, int TW, int NI>
-__global__ void __launch_bounds__(VV_WG, 1)
-wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
-  constexpr int AHH = TH + 2, AHW = TW + 2;
-  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * TH * TW * 32, TSZ = ASZ + BSZ;
-  static_assert(2 * TSZ * 4 <= 160 * 1024, "two LDS buffers");
-  constexpr int TXT = TW / 2, TYT = TH / 2, TPI = TXT * TYT;       // 2x2 tiles per image inside a staged pixel tile
-  constexpr int NTL = NI * TPI;                                    // tiles per staged pixel tile
-  constexpr int TPWV = NTL / 4;                                    // per wave
-  constexpr int NKS = TPWV / 2;                                    // k-steps (tile pairs) per wave and staged tile
-  static_assert(NTL % 8 == 0, "tile pairs per wave");
-  __shared__ float lds[2 * TSZ];
-
-  int w = vv_xcd_remap(blockIdx.x, nper);
-  if (w >= total) return;
-  const int KS = p.ksplit;
-  const int ks = w % KS; w /= KS;
-  const int cot = w % NCO; w /= NCO;
-  const int cit = w % NCI;
-  const int g = w / NCI;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int H = p.H, W = p.W;
-  const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
-
-  const VVSrc sa = vv_make_src(p, g, H, W);
-  VVSrc sb;
-  sb.p0 = p.dy.ptr + (int64_t)g * p.dy.gstride; sb.cs0 = p.dy.cstride; sb.co0 = p.dy.coff;
-  sb.a = sb.b = nullptr; sb.p1 = nullptr; sb.cs1 = sb.co1 = 0; sb.chmap = nullptr; sb.csplit = 0;
-  sb.mode = VV_IN_PLAIN; sb.SH = H; sb.SW = W; sb.B = p.B;
-
-  v16f acc[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  VVStagerB<NI, AHH, AHW, 32, 32> stA;
-  VVStagerB<NI, TH, TW, 32, 32> stB;
-  stA.init(sa, -1, tid);
-  stB.init(sb, 0, tid);
-  constexpr int NPA = decltype(stA)::NIT, NPB = decltype(stB)::NIT, NP = NPA + NPB;
-  constexpr int NSLOT = NKS * 16, C0 = NSLOT - NP - 4;
-  static_assert(C0 >= NP, "not enough MFMA slots between load issue and commit");
-  auto begin_tile = [&](const int pt, const bool live) {
-    const int img0 = (pt / tpi) * NI;
-    const int trem = pt % tpi;
-    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
-    stA.begin(sa, img0, ty0 - 1, tx0 - 1, cit * 32, tid, p.CinP, live);
-    stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
-  };
-
-  // operand rows: V[xi][nu] / M[xi][nu] of the k-step in flight; row xi of the NEXT step overwrites row xi of this one.  Kept as
-  // register pairs so that the transforms are packed-fp32 instructions (two results each):
-  //   V03 = (V0, V3), V12 = (V1, V2),  T = (t0, t1) = (M0, -M3), M12 = (M1, M2).
-  // Signs that would cost an instruction are folded into the epilogue: the accumulators hold  s(xi) s(nu) dU  with
-  // s(3) = -1 (row xi = 3 uses +dY[1][.] instead of -dY[1][.], column nu = 3 uses +t1 instead of -t1).
-  v2f V03[4], V12[4], T[4], M12[4], dq0, dq1;
-  const float *pA, *pB;                 // patch origin / dy origin of the step whose rows are being generated
-  auto step_addr = [&](const float* tA, const float* tB, const int j) {
-    const int tt = wave * TPWV + 2 * j + half;
-    const int im = tt / TPI, rem = tt % TPI;
-    const int tyl = rem / TXT, txl = rem % TXT;
-    pA = tA + ((im * AHH + 2 * tyl) * AHW + 2 * txl) * 32 + l31;
-    pB = tB + ((im * TH + 2 * tyl) * TW + 2 * txl) * 32 + l31;
-  };
-  auto read_dy = [&]() {
-    dq0 = (v2f){pB[0], pB[32]};
-    dq1 = (v2f){pB[TW * 32], pB[TW * 32 + 32]};
-  };
-  // Row xi of V = B^T d B and of dM = A dY A^T is produced in two stages one MFMA group apart: read_row issues its 8 patch
-  // reads into pr[], xform_row (a group later, the reads have landed) does the arithmetic.
-  //   B^T rows: d0-d2, d1+d2, d2-d1, d1-d3          A rows: (1,0) (1,1) (1,-1) (0,-1)
-  v2f pr[4];                            // [patch row a1 | a2][columns 01 | 23]
-  auto read_row = [&](auto XI, auto HALF) {             // HALF 0: patch row a1, HALF 1: patch row a2
-    constexpr int xi = XI.value;
-    constexpr int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
-    constexpr int a = HALF.value ? a2 : a1;
-    pr[HALF.value * 2 + 0] = (v2f){pA[(a * AHW + 0) * 32], pA[(a * AHW + 1) * 32]};
-    pr[HALF.value * 2 + 1] = (v2f){pA[(a * AHW + 2) * 32], pA[(a * AHW + 3) * 32]};
-  };
-  auto xform_row = [&](auto XI) {
-    constexpr int xi = XI.value;
-    const v2f r01 = xi == 1 ? pr[0] + pr[2] : pr[0] - pr[2];
-    const v2f r23 = xi == 1 ? pr[1] + pr[3] : pr[1] - pr[3];
-    V03[xi] = r01 - r23;                                // (r0 - r2, r1 - r3)
-    V12[xi] = vv_pk_lo_pm_hi(r23, r01);                 // (r2 + r1, r2 - r1)
-    v2f t;                                              // T[xi][q] = sum_p A[xi][p] dY[p][q]   (xi = 3: sign folded)
-    if constexpr (xi == 0) t = dq0;
-    else if constexpr (xi == 1) t = dq0 + dq1;
-    else if constexpr (xi == 2) t = dq0 - dq1;
-    else t = dq1;
-    T[xi] = t;
-    M12[xi] = vv_pk_lo_pm_hi(t, t);                     // (t0 + t1, t0 - t1)
-  };
-  auto gen_row = [&](auto XI) {                         // both stages back to back (start of a staged tile only)
-    read_row(XI, std::integral_constant<int, 0>{});
-    read_row(XI, std::integral_constant<int, 1>{});
-    xform_row(XI);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  begin_tile(ks, true);
-  vv_static_for<0, NPA>([&](auto K) { stA.template load_piece<K.value>(sa, -1, tid); });
-  vv_static_for<0, NPB>([&](auto K) { stB.template load_piece<K.value>(sb, 0, tid); });
-  vv_static_for<0, NPA>([&](auto K) { stA.template commit_piece<K.value>(lds, tid); });
-  vv_static_for<0, NPB>([&](auto K) { stB.template commit_piece<K.value>(lds + ASZ, tid); });
-  __syncthreads();
-  int cur = 0;
-  for (int pt = ks; pt < NT; pt += KS) {
-    const float* tA = lds + cur * TSZ;
-    const float* tB = tA + ASZ;
-    float* nA = lds + (cur ^ 1) * TSZ;
-    float* nB = nA + ASZ;
-    const bool live = pt + KS < NT;
-    begin_tile(live ? pt + KS : ks, live);
-    // rows 0..2 of the first step, and the reads of its row 3 (transformed under the first MFMA group)
-    step_addr(tA, tB, 0);
-    read_dy();
-    gen_row(std::integral_constant<int, 0>{});
-    gen_row(std::integral_constant<int, 1>{});
-    gen_row(std::integral_constant<int, 2>{});
-    read_row(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-    read_row(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
-    vv_static_for<0, NKS>([&](auto JJ) {
-      constexpr int j = JJ.value;
-      constexpr bool more = j + 1 < NKS;
-      vv_static_for<0, 16>([&](auto SS) {
-        constexpr int sl = SS.value, grp = sl >> 2, nu = sl & 3, slot = j * 16 + sl;
-        const float va = nu == 0 ? V03[grp].x : (nu == 1 ? V12[grp].x : (nu == 2 ? V12[grp].y : V03[grp].y));
-        const float mb = nu == 0 ? T[grp].x : (nu == 1 ? M12[grp].x : (nu == 2 ? M12[grp].y : T[grp].y));
-        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, mb, acc[sl], 0, 0, 0);
-        // under group g: the row whose reads were issued one group earlier is transformed -- row 3 of this step (g = 0) or
-        // row g-1 of the next step -- into registers consumed at least one group ago; then the reads of the following row.
-        constexpr int rowa = grp == 0 ? 3 : grp - 1, rowb = grp;         // rowb: row of step j+1 whose reads are issued
-        if constexpr (nu == 0 && (grp == 0 || more)) xform_row(std::integral_constant<int, rowa>{});
-        if constexpr (more) {
-          if constexpr (nu == 1) {
-            if constexpr (grp == 0) { step_addr(tA, tB, j + 1); read_dy(); }
-            read_row(std::integral_constant<int, rowb>{}, std::integral_constant<int, 0>{});
-          }
-          if constexpr (nu == 2) read_row(std::integral_constant<int, rowb>{}, std::integral_constant<int, 1>{});
-        }
-        if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
-        else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
-        else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
-        else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-    __syncthreads();                        // next buffer complete, current buffer no longer read
-    cur ^= 1;
-  }
-
-  // ---- epilogue: dg = G^T dU G per (ci, co),  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]; then the direct kernel's slab path
-  v16f tap[9];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float c[3][4];                          // G^T dU  (rows)
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const float sn = nu == 3 ? -1.f : 1.f;            // folded signs (see the operand rows above)
-      const float u0 = sn * acc[0 * 4 + nu][i], u1 = sn * acc[1 * 4 + nu][i], u2 = sn * acc[2 * 4 + nu][i], u3 = -sn * acc[3 * 4 + nu][i];
-      c[0][nu] = u0 + 0.5f * (u1 + u2);
-      c[1][nu] = 0.5f * (u1 - u2);
-      c[2][nu] = u3 + 0.5f * (u1 + u2);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      tap[a * 3 + 0][i] = c[a][0] + 0.5f * (c[a][1] + c[a][2]);
-      tap[a * 3 + 1][i] = 0.5f * (c[a][1] - c[a][2]);
-      tap[a * 3 + 2][i] = c[a][3] + 0.5f * (c[a][1] + c[a][2]);
-    }
-  }
-  static_assert(2 * TSZ >= 9 * 1024, "LDS too small for the slab");
-  __syncthreads();
-  for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-          float* q = lds + t * 1024 + row * 32 + l31;
-          *q = wv ? *q + tap[t][i] : tap[t][i];
-        }
-    }
-    __syncthreads();
-  }
-  float4* out = reinterpret_cast<float4*>(p.partial + (int64_t)g * p.partial_gstride +
-                                          ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024));
-  const float4* l4 = reinterpret_cast<const float4*>(lds);
-#pragma unroll
-  for (int j = 0; j < 9; ++j) out[tid + j * VV_WG] = l4[tid + j * VV_WG];
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Eight-wave form of the Winograd weight gradient: 512 threads, wave = (K quarter kq of the staged tile's 2x2 tiles) x
-// (xi half xh).  A wave keeps only the 8 GEMMs of its xi half (128 accumulator registers, <= 256 registers per lane), so
-// two waves share every SIMD and one's operand arithmetic / barrier waits run under the other's MFMAs -- the four-wave
-// form above has nobody to hide them (measured MFMA utilisation 0.5 even with the staging switched off).
-template <int TH, int TW, int NI>
-__global__ void __launch_bounds__(512, 1)
-wgrad_wino8_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
-  constexpr int NTH = 512;
-  constexpr int AHH = TH + 2, AHW = TW + 2;
-  constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * TH * TW * 32, TSZ = ASZ + BSZ;
-  static_assert(2 * TSZ * 4 <= 160 * 1024, "two LDS buffers");
-  constexpr int TXT = TW / 2, TYT = TH / 2, TPI = TXT * TYT;       // 2x2 tiles per image inside a staged pixel tile
-  constexpr int NTL = NI * TPI;                                    // tiles per staged pixel tile
-  constexpr int TPWV = NTL / 4;                                    // per K quarter
-  constexpr int NKS = TPWV / 2;                                    // k-steps (tile pairs) per wave and staged tile
-  static_assert(NTL % 8 == 0, "tile pairs per wave");
-  constexpr int LSZ = 2 * TSZ > 4 * 9 * 1024 ? 2 * TSZ : 4 * 9 * 1024;      // epilogue: one tap slab per K quarter
-  __shared__ float lds[LSZ];
-
-  int w = vv_xcd_remap(blockIdx.x, nper);
-  if (w >= total) return;
-  const int KS = p.ksplit;
-  const int ks = w % KS; w /= KS;
-  const int cot = w % NCO; w /= NCO;
-  const int cit = w % NCI;
-  const int g = w / NCI;
-
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: everything derived from it lives in SGPRs
-  const int kq = wave >> 1, xh = wave & 1;
-  const int H = p.H, W = p.W;
-  const int tilesX = W / TW, tilesY = H / TH, tpi = tilesX * tilesY;
-
-  const VVSrc sa = vv_make_src(p, g, H, W);
-  VVSrc sb;
-  sb.p0 = p.dy.ptr + (int64_t)g * p.dy.gstride; sb.cs0 = p.dy.cstride; sb.co0 = p.dy.coff;
-  sb.a = sb.b = nullptr; sb.p1 = nullptr; sb.cs1 = sb.co1 = 0; sb.chmap = nullptr; sb.csplit = 0;
-  sb.mode = VV_IN_PLAIN; sb.SH = H; sb.SW = W; sb.B = p.B;
-
-  v16f acc[2][4];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[x][n][i] = 0.f;
-
-  VVStagerB<NI, AHH, AHW, 32, 32, NTH> stA;
-  VVStagerB<NI, TH, TW, 32, 32, NTH> stB;
-  stA.init(sa, -1, tid);
-  stB.init(sb, 0, tid);
-  constexpr int NPA = decltype(stA)::NIT, NPB = decltype(stB)::NIT, NP = NPA + NPB;
-  constexpr int NSLOT = NKS * 8, C0 = NSLOT - NP - 2;
-  static_assert(C0 >= NP, "not enough MFMA slots between load issue and commit");
-  auto begin_tile = [&](const int pt, const bool live) {
-    const int img0 = (pt / tpi) * NI;
-    const int trem = pt % tpi;
-    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
-    stA.begin(sa, img0, ty0 - 1, tx0 - 1, cit * 32, tid, p.CinP, live);
-    stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
-  };
-
-  // this wave's two xi rows (x = 0, 1 -> xi = 2 xh + x):   B^T row xi: d[a1] + sg d[a2]      A row xi: (c0, c1)
-  //   xi 0: d0 - d2, (1, 0)     1: d1 + d2, (1, 1)     2: d2 - d1, (1, -1)     3: d1 - d3, (0, -1)
-  int ao1[2], ao2[2];
-  float sg[2], c0[2], c1[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int xi = 2 * xh + x;
-    const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
-    ao1[x] = a1 * AHW * 32;
-    ao2[x] = a2 * AHW * 32;
-    sg[x] = xi == 1 ? 1.f : -1.f;
-    c0[x] = xi == 3 ? 0.f : 1.f;
-    c1[x] = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
-  }
-  float V[2][4], M[2][4], dq[2][2], pr[8];
-  const float *pA, *pB;
-  auto step_addr = [&](const float* tA, const float* tB, const int j) {
-    const int tt = kq * TPWV + 2 * j + half;
-    const int im = tt / TPI, rem = tt % TPI;
-    const int tyl = rem / TXT, txl = rem % TXT;
-    pA = tA + ((im * AHH + 2 * tyl) * AHW + 2 * txl) * 32 + l31;
-    pB = tB + ((im * TH + 2 * tyl) * TW + 2 * txl) * 32 + l31;
-  };
-  auto read_dy = [&]() {
-    dq[0][0] = pB[0]; dq[0][1] = pB[32];
-    dq[1][0] = pB[TW * 32]; dq[1][1] = pB[TW * 32 + 32];
-  };
-  auto read_row = [&](const int x) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { pr[b] = pA[ao1[x] + b * 32]; pr[4 + b] = pA[ao2[x] + b * 32]; }
-  };
-  auto xform_row = [&](const int x) {
-    float r[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) r[b] = fmaf(sg[x], pr[4 + b], pr[b]);
-    V[x][0] = r[0] - r[2];
-    V[x][1] = r[1] + r[2];
-    V[x][2] = r[2] - r[1];
-    V[x][3] = r[1] - r[3];
-    const float t0 = fmaf(c1[x], dq[1][0], c0[x] * dq[0][0]), t1 = fmaf(c1[x], dq[1][1], c0[x] * dq[0][1]);
-    M[x][0] = t0;
-    M[x][1] = t0 + t1;
-    M[x][2] = t0 - t1;
-    M[x][3] = -t1;
-  };
-
-  begin_tile(ks, true);
-  vv_static_for<0, NPA>([&](auto K) { stA.template load_piece<K.value>(sa, -1, tid); });
-  vv_static_for<0, NPB>([&](auto K) { stB.template load_piece<K.value>(sb, 0, tid); });
-  vv_static_for<0, NPA>([&](auto K) { stA.template commit_piece<K.value>(lds, tid); });
-  vv_static_for<0, NPB>([&](auto K) { stB.template commit_piece<K.value>(lds + ASZ, tid); });
-  __syncthreads();
-  int cur = 0;
-  for (int pt = ks; pt < NT; pt += KS) {
-    const float* tA = lds + cur * TSZ;
-    const float* tB = tA + ASZ;
-    float* nA = lds + (cur ^ 1) * TSZ;
-    float* nB = nA + ASZ;
-    const bool live = pt + KS < NT;
-    begin_tile(live ? pt + KS : ks, live);
-    // first step of the staged tile: row 0 directly, reads of row 1 (transformed under the first MFMA group)
-    step_addr(tA, tB, 0);
-    read_dy();
-    read_row(0);
-    xform_row(0);
-    read_row(1);
-    vv_static_for<0, NKS>([&](auto JJ) {
-      constexpr int j = JJ.value;
-      constexpr bool more = j + 1 < NKS;
-      vv_static_for<0, 8>([&](auto SS) {
-        constexpr int sl = SS.value, x = sl >> 2, nu = sl & 3, slot = j * 8 + sl;
-        acc[x][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[x][nu], M[x][nu], acc[x][nu], 0, 0, 0);
-        // under group 0: row 1 of this step is transformed (reads issued one group earlier), then the reads of row 0 of the
-        // next step; under group 1: row 0 of the next step is transformed, then the reads of its row 1
-        if constexpr (x == 0) {
-          if constexpr (nu == 0) xform_row(1);
-          if constexpr (nu == 1 && more) { step_addr(tA, tB, j + 1); read_row(0); }
-        } else if constexpr (more) {
-          if constexpr (nu == 0) { read_dy(); }
-          if constexpr (nu == 1) { xform_row(0); read_row(1); }
-        }
-        if constexpr (slot < NPA) stA.template load_piece<slot>(sa, -1, tid);
-        else if constexpr (slot < NP) stB.template load_piece<slot - NPA>(sb, 0, tid);
-        else if constexpr (slot >= C0 && slot < C0 + NPA) stA.template commit_piece<slot - C0>(nA, tid);
-        else if constexpr (slot >= C0 + NPA && slot < C0 + NP) stB.template commit_piece<slot - C0 - NPA>(nB, tid);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-    __syncthreads();                        // next buffer complete, current buffer no longer read
-    cur ^= 1;
-  }
-
-  // ---- epilogue.  dg = G^T dU G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]: each wave folds ITS xi half into 9 tap partials
-  // (linear), xi halves meet in LDS (one slab per K quarter), then the four slabs are summed in fixed order into the
-  // workgroup's global slab -- the layout vv_wgrad_reduce expects.
-  __syncthreads();
-  float* slab = lds + kq * 9 * 1024;
-  // G^T[a][xi] for this wave's rows xi = 2xh, 2xh+1:   xh = 0: (1, .5) (0, .5) (0, .5)      xh = 1: (.5, 0) (-.5, 0) (.5, 1)
-  const float ga[3][2] = {{xh ? 0.5f : 1.f, xh ? 0.f : 0.5f}, {xh ? -0.5f : 0.f, xh ? 0.f : 0.5f}, {xh ? 0.5f : 0.f, xh ? 1.f : 0.5f}};
-  for (int ph = 1; ph >= 0; --ph) {         // xi half 1 writes, barrier, xi half 0 adds
-    if (xh == ph) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-        float* q = slab + row * 32 + l31;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          float c[4];
-#pragma unroll
-          for (int nu = 0; nu < 4; ++nu) c[nu] = ga[a][0] * acc[0][nu][i] + ga[a][1] * acc[1][nu][i];
-          const float h = 0.5f * (c[1] + c[2]);
-          const float t0 = c[0] + h, t1 = 0.5f * (c[1] - c[2]), t2 = c[3] + h;
-          if (ph) { q[(a * 3 + 0) * 1024] = t0; q[(a * 3 + 1) * 1024] = t1; q[(a * 3 + 2) * 1024] = t2; }
-          else { q[(a * 3 + 0) * 1024] += t0; q[(a * 3 + 1) * 1024] += t1; q[(a * 3 + 2) * 1024] += t2; }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  float4* out = reinterpret_cast<float4*>(p.partial + (int64_t)g * p.partial_gstride +
-                                          ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024));
-  const float4* l4 = reinterpret_cast<const float4*>(lds);
-  for (int e = tid; e < 9 * 256; e += NTH) {
-    const float4 s0 = l4[e], s1 = l4[9 * 256 + e], s2 = l4[2 * 9 * 256 + e], s3 = l4[3 * 9 * 256 + e];
-    float4 r;
-    r.x = (s0.x + s1.x) + (s2.x + s3.x); r.y = (s0.y + s1.y) + (s2.y + s3.y);
-    r.z = (s0.z + s1.z) + (s2.z + s3.z); r.w = (s0.w + s1.w) + (s2.w + s3.w);
-    out[e] = r;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// One-xi-per-wave form of the Winograd weight gradient: 256 threads, wave = xi.  A wave keeps the 4 GEMMs (nu = 0..3) of its
-// xi row in 64 accumulator registers and walks ALL 2x2 tiles of a staged unit, so three workgroups share a CU (<= 168
-// registers per lane, <= 53 KB of LDS) and every SIMD has three independent instruction streams: operand reads, transforms
-// and barrier waits of one run under the MFMAs of the others (the four- and eight-wave forms above have one / two).
+// above.  Same (32 ci x 32 co x k-split) workgroups and slabs, but the GEMM-K index is the 2x2 tile: lanes 0-31 take tile 2j,
+// lanes 32-63 tile 2j+1, lane&31 = channel, so both operands are built per lane from ds_read_b32 (conflict free: consecutive
+// lanes = consecutive channels).
+// 256 threads, wave = xi.  A wave keeps the 4 GEMMs (nu = 0..3) of its xi row in 64 accumulator registers and walks ALL 2x2
+// tiles of a staged unit, so three workgroups share a CU (<= 168 registers per lane, <= 53 KB of LDS) and every SIMD has three
+// independent instruction streams: operand reads, transforms and barrier waits of one run under the MFMAs of the others.
+// (Round 1 / 2 history, profiles/README.md: forms with all 16 GEMMs per wave -- 256 accumulators, one wave per SIMD -- and with
+// 8 GEMMs per wave -- two per SIMD -- ran at 0.37-0.49 of the fp32 MFMA peak; this one at 0.50-0.61.)
 //   staged unit = 64 pixels (16 tiles = 8 k-steps of a tile pair) of full image width: UH rows x W x UNI images; the k-split
 //   tile (TH x W x NI, what vv_wgrad_ntiles counts) is a run of (TH / UH) * (NI / UNI) units.  Two LDS buffers per workgroup;
 //   the loads of the next unit go out under the first MFMAs of this one, their LDS writes under the last ones.
 //   Operands of k-step j+1 are built under the MFMAs of step j into the other of two register sets: 6 ds_read2_b32, 8 packed
-//   VALU instructions per 4 MFMAs.  Signs that would cost an instruction are folded into the epilogue (see the four-wave form).
+//   VALU instructions per 4 MFMAs.  Signs that would cost an instruction are folded into the epilogue: row xi = 3 uses +dY[1][.]
+//   instead of -dY[1][.], column nu = 3 uses +t1 instead of -t1, so acc[nu] = s(xi) s(nu) dU[xi][nu] with s(3) = -1.
 //   Epilogue: each wave folds its columns (dU G), the four xi rows meet in LDS, wave w finishes accumulator rows 4w..4w+3 of
 //   all 9 taps (G^T .) and writes them to the workgroup's slab -- the layout vv_wgrad_reduce expects.
 template <int TH, int TW, int NI, int UH, int UNI>
 __global__ void __launch_bounds__(256, 3)
-wgrad_wino3_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+wgrad_wino_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
   constexpr int NTH = 256, W_ = TW;
   constexpr int AHH = UH + 2, AHW = W_ + 2;
   constexpr int ASZ = UNI * AHH * AHW * 32, BSZ = UNI * UH * W_ * 32, USZ = ASZ + BSZ;      // floats
@@ -922,36 +529,14 @@ inline bool wgeo(int kind, int H, int W, WGeo* t) {
   return false;
 }
 
-template <int TH, int TW, int NI>
-int launch_ww(const vv_wgrad_params* p, hipStream_t st) {
-  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
-  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
-  const int total = p->G * NCI * NCO * p->ksplit;
-  const int nper = (total + 7) / 8;
-  VV_LAUNCH((wgrad_wino_kernel<TH, TW, NI>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
-  VV_CHECK_LAUNCH();
-  return VV_OK;
-}
-
-template <int TH, int TW, int NI>
-int launch_ww8(const vv_wgrad_params* p, hipStream_t st) {
-  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
-  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
-  const int total = p->G * NCI * NCO * p->ksplit;
-  const int nper = (total + 7) / 8;
-  VV_LAUNCH((wgrad_wino8_kernel<TH, TW, NI>), dim3(nper * 8), dim3(512), 0, st, *p, NT, NCI, NCO, total, nper);
-  VV_CHECK_LAUNCH();
-  return VV_OK;
-}
-
 template <int TH, int TW, int NI, int UH, int UNI>
-int launch_ww3(const vv_wgrad_params* p, hipStream_t st) {
+int launch_ww(const vv_wgrad_params* p, hipStream_t st) {
   if (p->W != TW) return VV_ERR_UNSUPPORTED;
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
   const int total = p->G * NCI * NCO * p->ksplit;
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((wgrad_wino3_kernel<TH, TW, NI, UH, UNI>), dim3(nper * 8), dim3(256), 0, st, *p, NT, NCI, NCO, total, nper);
+  VV_LAUNCH((wgrad_wino_kernel<TH, TW, NI, UH, UNI>), dim3(nper * 8), dim3(256), 0, st, *p, NT, NCI, NCO, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -982,32 +567,12 @@ extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
   if (p->kind == VV_CONV3 && (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE))
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
-  if (p->kind == VV_CONV3 && (p->pad0 & 1024)) {          // Winograd form, one xi per wave, three workgroups per CU
+  if (p->kind == VV_CONV3 && (p->pad0 & 256)) {           // Winograd F(2x2,3x3) form (same k-split tiles, same slabs)
     switch (p->H) {
-      case 32: return launch_ww3<8, 32, 1, 2, 1>(p, st);
-      case 16: return launch_ww3<16, 16, 1, 4, 1>(p, st);
-      case 8: return launch_ww3<8, 8, 2, 8, 1>(p, st);
-      case 4: return launch_ww3<4, 4, 8, 4, 4>(p, st);
-    }
-    return VV_ERR_UNSUPPORTED;
-  }
-  if (p->kind == VV_CONV3 && (p->pad0 & 512)) {           // Winograd form, eight waves (two per SIMD)
-    switch (p->H) {
-      case 32: return launch_ww8<8, 32, 1>(p, st);
-      case 16: return launch_ww8<16, 16, 1>(p, st);
-      case 8: return launch_ww8<8, 8, 2>(p, st);
-      case 4: return launch_ww8<4, 4, 8>(p, st);
-    }
-    return VV_ERR_UNSUPPORTED;
-  }
-  if (p->kind == VV_CONV3 && (p->pad0 & 256)) {           // Winograd F(2x2,3x3) form (same tiles, same slabs)
-    // measured per level at B = 256: four waves x 16 GEMMs win on the 32^2 / 16^2 levels (few, long staged tiles), eight
-    // waves x 8 GEMMs (two waves per SIMD) on the 8^2 / 4^2 levels (-10 %)
-    switch (p->H) {
-      case 32: return launch_ww<8, 32, 1>(p, st);
-      case 16: return launch_ww<16, 16, 1>(p, st);
-      case 8: return launch_ww8<8, 8, 2>(p, st);
-      case 4: return launch_ww8<4, 4, 8>(p, st);
+      case 32: return launch_ww<8, 32, 1, 2, 1>(p, st);
+      case 16: return launch_ww<16, 16, 1, 4, 1>(p, st);
+      case 8: return launch_ww<8, 8, 2, 8, 1>(p, st);
+      case 4: return launch_ww<4, 4, 8, 4, 4>(p, st);
     }
     return VV_ERR_UNSUPPORTED;
   }

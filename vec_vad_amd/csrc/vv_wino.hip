@@ -246,10 +246,40 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     const v2f t = {acc[0][i] + acc[1][i] + acc[2][i], acc[1][i] - acc[2][i] - acc[3][i]};
     ex2[(xi * 16 + i) * 64] = t;
   }
+  constexpr int LP = TPI > 4 ? 8 : (TPI == 4 ? 2 * H_ : H_ * H_);        // pixels between the two lane halves (tile + 4)
+  // Fused first pass of the consumer's BatchNorm backward (vv_conv_params.bn_partial): this wave's 16 values of z go out now and
+  // land while the four xi rows meet in LDS.
+  const bool bnf = p.bn_partial != nullptr;
+  float zq[4][4];
+  float bna = 0.f, bnb = 0.f, bni = 0.f, bnm = 0.f;
+  bool jok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t2 = xi * 8 + j;
+    jok[j] = img0 + t2 / TPW + (TPW == 4 ? half : 0) < p.B;
+  }
+  if (bnf) {
+    const int64_t bo = (int64_t)g * p.bn_gstride + co0 + l31;
+    bna = p.bn_a[bo]; bnb = p.bn_b[bo]; bni = p.bn_invstd[bo];
+    bnm = -p.bn_mean[bo] * bni;                                            // xhat = z invstd - mean invstd
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bn_z + (int64_t)g * p.bn_z_gstride), 0, 0x7FFFFFFF, 0x00020000);
+    const int vz = (half * LP * Cout + co0 + l31) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t2 = xi * 8 + j;
+      const int im = t2 / TPW, rem = t2 % TPW;
+      const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
+      const int so = (((img0 + im) * H_ + oy) * H_ + ox) * Cout * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        zq[j][q] = jok[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, vz, so + ((q >> 1) * H_ + (q & 1)) * Cout * 4, 0))
+                          : 0.f;
+    }
+  }
   __syncthreads();
   const float bias = p.bias ? p.bias[(int64_t)g * p.bias_gstride + co0 + l31] : 0.f;
   const float lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();     // VV_CONV_RELU: BatchNorm folded into the filter (eval)
-  constexpr int LP = TPI > 4 ? 8 : (TPI == 4 ? 2 * H_ : H_ * H_);        // pixels between the two lane halves (tile + 4)
   const int ocs = p.out.cstride;
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
       p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff, 0, 0x7FFFFFFF, 0x00020000);
@@ -261,8 +291,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     const int t2 = xi * 8 + j;                                   // wave-uniform part of the tile index
     const int im = t2 / TPW, rem = t2 % TPW;
     const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
-    const int img = img0 + im + (TPW == 4 ? half : 0);
-    if (img < p.B) {
+    if (jok[j]) {
       const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
       v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
       ya = __builtin_elementwise_max(ya, (v2f){lo, lo});
@@ -278,12 +307,23 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b0), rsO, vo, so + H_ * ocs * 4, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b1), rsO, vo, so + (H_ + 1) * ocs * 4, 0);
       }
-      s12 += ya + yb;
-      q12 = __builtin_elementwise_fma(ya, ya, q12);
-      q12 = __builtin_elementwise_fma(yb, yb, q12);
+      if (bnf) {
+        // dz = dA [a z + b > 0];  partial sums of dz and dz * xhat  (bn_bwd_reduce_kernel<.., 0>, fused)
+        const v2f za = {zq[j][0], zq[j][1]}, zb = {zq[j][2], zq[j][3]};
+        const v2f pa = bna * za + bnb, pb = bna * zb + bnb;
+        const v2f da = {pa.x > 0.f ? ya.x : 0.f, pa.y > 0.f ? ya.y : 0.f}, db = {pb.x > 0.f ? yb.x : 0.f, pb.y > 0.f ? yb.y : 0.f};
+        s12 += da + db;
+        q12 = __builtin_elementwise_fma(da, bni * za + bnm, q12);
+        q12 = __builtin_elementwise_fma(db, bni * zb + bnm, q12);
+      } else {
+        s12 += ya + yb;
+        q12 = __builtin_elementwise_fma(ya, ya, q12);
+        q12 = __builtin_elementwise_fma(yb, yb, q12);
+      }
     }
   }
-  if (p.stats) {
+  float* const sout = bnf ? p.bn_partial : p.stats;
+  if (sout) {
     float s1 = s12.x + s12.y, s2 = q12.x + q12.y;
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
@@ -300,7 +340,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         t1 += sp[k * 32 + tid];
         t2 += sp[(4 + k) * 32 + tid];
       }
-      float* st = p.stats + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
+      float* st = sout + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
       st[0] = t1;
       st[Cout] = t2;
     }
@@ -390,6 +430,7 @@ extern "C" int vv_conv_wino(const vv_conv_params* p, vv_stream stream) {
   if (!p || !p->src0.ptr || !p->w || !p->out.ptr) return VV_ERR_BAD_ARG;
   if (p->G <= 0 || p->B <= 0 || p->kind != VV_CONV3 || p->H != p->W) return VV_ERR_BAD_ARG;
   if (p->Cout % 32 || p->CinP % 8) return VV_ERR_UNSUPPORTED;
+  if (p->bn_partial && (p->stats || !p->bn_z || !p->bn_a || !p->bn_b || !p->bn_mean || !p->bn_invstd)) return VV_ERR_BAD_ARG;
   if (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
