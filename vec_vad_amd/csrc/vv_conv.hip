@@ -15,6 +15,17 @@
 // through the Winograd kernel in vv_wino.hip (VV_WINOGRAD=0 brings them back here); the transposed convolution always
 // runs here -- forward with all four output-parity phases in one workgroup, data gradient as a stride-2 gather.
 #include "vv_common.h"
+// steps of distance between an LDS fragment read and its MFMAs in the bf16 kernels (measured on BASELINE config 4: 1 -> 41.1 k
+// cubes/s, 2 -> 40.5 k, 3 -> 38.6 k: the ring costs registers, and the kernels are bound by LDS bandwidth, not by its latency)
+// VV_EXPC (compile-time bit mask, default 0): elimination switches (every non-zero value computes WRONG results): 1 no MFMAs,
+// 2 global loads of the first chunk only, 4 LDS commit of the first chunk only, 8 no output stores, 16 no LDS fragment reads
+// after the first step of a chunk.
+#ifndef VV_EXPC
+#define VV_EXPC 0
+#endif
+#ifndef VV_PD_BF
+#define VV_PD_BF 1
+#endif
 
 namespace {
 
@@ -49,7 +60,10 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr int BROWS = 9 * KGC * 2;    // weight panel rows of one chunk: [tap][kg][half]
   constexpr int B4 = BROWS * TN;
   constexpr int NBT = (B4 + VV_WG - 1) / VV_WG;
-  __shared__ float4 lds4[A4 + B4];
+  // bf16 output tile of the epilogue: [128 MR pixels][TN + 8] bf16 (16 B of padding per row), aliases the staging buffers
+  constexpr int ORS = TN + 8, OUT4 = (BF && KIND != VV_CONVT_FWD) ? (128 * MR * ORS * 2 + 15) / 16 : 0;
+  constexpr int LDS4 = (A4 + B4) > OUT4 ? (A4 + B4) : OUT4;
+  __shared__ float4 lds4[LDS4];
   float* lds = reinterpret_cast<float*>(lds4);
   const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
   const v4f* ldsB = reinterpret_cast<const v4f*>(lds4) + A4;
@@ -142,8 +156,14 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   issue(0);
   for (int c0 = 0; c0 < CinP; c0 += CK) {
     if (c0) __syncthreads();            // every wave finished reading the previous chunk
+#if (VV_EXPC & 4)
+    if (c0 == 0)
+#endif
     commit();
     __syncthreads();
+#if (VV_EXPC & 2)
+    if (false)
+#endif
     if (c0 + CK < CinP) issue(c0 + CK);
 
     {
@@ -151,29 +171,34 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       // runs: one ds_read_b128 after each group of 4 MFMAs (pinned with sched_barrier), never a block of LDS issue
       // slots in front of the matrix pipe and never a read that is waited on right after it was issued.
       constexpr int NIT = 9 * KGC;
-      v4f fa[2][MR], fb[2][NR];
+      // Fragment ring: step it + PD is read from LDS while step it runs (PD = 1: two register sets).
+      constexpr int PDW = VV_PD_BF;
+      constexpr int PD = BF ? (NIT > PDW ? PDW : NIT - 1) : 1, RING = PD + 1;
+      v4f fa[RING][MR], fb[RING][NR];
       auto rdA = [&](const int it, const int m) -> v4f {
         const int tap = it / KGC, kg = it % KGC;
         // transposed conv: oy = 2*iy - 1 + ky  ->  ky = 1: iy = r (even rows), ky = 2: iy = r, ky = 0: iy = r + 1 (odd rows)
         const int dy = KIND == VV_CONVT_FWD ? (tap / 3 == 0) : tap / 3, dx = KIND == VV_CONVT_FWD ? (tap % 3 == 0) : tap % 3;
-        v4f v = ldsA[abase[m] + (dy * HW + dx) * S4 + kg * 2];
-        asm volatile("" : "+v"(v));
-        return v;
+        return ldsA[abase[m] + (dy * HW + dx) * S4 + kg * 2];
       };
       auto rdB = [&](const int it, const int n) -> v4f {
         const int tap = it / KGC, kg = it % KGC;
-        v4f v = ldsB[((tap * KGC + kg) * 2 + half) * TN + n * 32 + l31];
-        asm volatile("" : "+v"(v));
-        return v;
+        return ldsB[((tap * KGC + kg) * 2 + half) * TN + n * 32 + l31];
       };
+      // (the reads are pinned between the MFMA groups by sched_barrier alone: an `asm volatile("" : "+v"(v))` on the loaded value
+      //  also pins them but makes the compiler wait for the data right there -- one exposed LDS round trip per read)
 #pragma unroll
-      for (int m = 0; m < MR; ++m) fa[0][m] = rdA(0, m);
+      for (int s = 0; s < PD; ++s) {
 #pragma unroll
-      for (int n = 0; n < NR; ++n) fb[0][n] = rdB(0, n);
+        for (int m = 0; m < MR; ++m) fa[s][m] = rdA(s, m);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) fb[s][n] = rdB(s, n);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int cur = it & 1, nxt = cur ^ 1;
-        int piece = 0;                       // pieces of the next step's fragments: A[0..MR), then B[0..NR)
+        const int cur = it % RING, nxt = (it + PD) % RING;
+        int piece = 0;                       // pieces of step it + PD's fragments: A[0..MR), then B[0..NR)
         const int tapc = it / KGC;
         const int phc = ((tapc / 3 != 1) ? 2 : 0) + ((tapc % 3 != 1) ? 1 : 0);   // output phase of this tap (transposed conv)
 #pragma unroll
@@ -181,6 +206,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             const int an = KIND == VV_CONVT_FWD ? phc : n;
+#if (VV_EXPC & 1)
+            acc[m][an][0] += fa[cur][m].x * fb[cur][n].x;
+#else
             if constexpr (BF) {
               acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fa[cur][m]),
                                                                    __builtin_bit_cast(v8bf, fb[cur][n]), acc[m][an], 0, 0, 0);
@@ -190,12 +218,16 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
               acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][an], 0, 0, 0);
               acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][an], 0, 0, 0);
             }
-            if (it + 1 < NIT) {
+#endif
+#if (VV_EXPC & 16)
+            if (false)
+#endif
+            if (it + PD < NIT) {
               const int last = (m == MR - 1 && n == NR - 1);
               // spread MR+NR reads over MR*NR MFMA groups (the last group takes whatever is left)
               do {
-                if (piece < MR) fa[nxt][piece] = rdA(it + 1, piece);
-                else if (piece < MR + NR) fb[nxt][piece - MR] = rdB(it + 1, piece - MR);
+                if (piece < MR) fa[nxt][piece] = rdA(it + PD, piece);
+                else if (piece < MR + NR) fb[nxt][piece - MR] = rdB(it + PD, piece - MR);
                 ++piece;
               } while (last && piece < MR + NR);
             }
@@ -219,6 +251,51 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     bias[n] = p.bias ? p.bias[(int64_t)g * p.bias_gstride + co0 + n * 32 + l31] : 0.f;
     s1[n] = 0.f; s2[n] = 0.f;
   }
+  bool tile_out = false;
+  if constexpr (BF && KIND != VV_CONVT_FWD) tile_out = o16;
+  if (tile_out) {
+    if constexpr (BF && KIND != VV_CONVT_FWD) {
+      // bf16 outputs: 2-byte stores straight from the accumulator layout (lane = channel) are 128 B per instruction and cost a
+      // third of the kernel (elimination run, profiles/README.md).  The tile goes through LDS instead and leaves as 16-byte
+      // items (8 channels) per lane: 8x fewer store instructions, whole 64-byte runs per pixel.
+      __syncthreads();                    // every wave is done with the staging buffers
+      unsigned short* lo = reinterpret_cast<unsigned short*>(lds4);
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+          const int pp = wave * (32 * MR) + m * 32 + row;
+          const bool ok = img0 + pp / (TH * TW) < p.B;
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            float v = acc[m][n][i] + bias[n];
+            if (p.pad0 & VV_CONV_RELU) v = fmaxf(v, 0.f);
+            const __bf16 hv = (__bf16)v;
+            lo[pp * ORS + n * 32 + l31] = __builtin_bit_cast(unsigned short, hv);
+            v = ok ? (float)hv : 0.f;
+            s1[n] += v; s2[n] = fmaf(v, v, s2[n]);
+          }
+        }
+      __syncthreads();
+      constexpr int QN = TN / 8, NOUT = 128 * MR * QN / VV_WG;
+      static_assert((128 * MR * QN) % VV_WG == 0, "output items per thread");
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) {
+        const int it = tid + k * VV_WG;
+        const int q = it % QN, pp = it / QN;
+        const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+        const int img = img0 + im;
+#if (VV_EXPC & 8)
+        if (acc[0][0][0] == 123.456f)
+#endif
+        if (img < p.B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(lo + pp * ORS + q * 8);
+          *reinterpret_cast<uint4*>(outh + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs + co0 + q * 8) = v;
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -227,6 +304,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const int pp = wave * (32 * MR) + m * 32 + row;
       const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
       const int img = img0 + im;
+#if (VV_EXPC & 8)
+      if (acc[m][0][i] == 123.456f)
+#endif
       if (img < p.B) {
         if constexpr (KIND == VV_CONVT_FWD) {
           const int64_t e = ((int64_t)(img * OH + 2 * (ty0 + r)) * OW + 2 * (tx0 + c)) * ocs + co0 + l31;
@@ -255,6 +335,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       }
     }
 
+  }
   if (p.stats) {
     __syncthreads();
 #pragma unroll

@@ -137,12 +137,12 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
     constexpr int NIT = NTAP * KGC;
     auto rdA = [&](const int it, const int m) -> v4f {
       v4f v = ldsA[abase[m] + aofft[it / KGC] + (it % KGC) * 2];
-      asm volatile("" : "+v"(v));
+      // (pinned by the sched_barrier of its MFMA group; an asm "+v"(v) here would force an lgkmcnt(0) wait right behind the read)
       return v;
     };
     auto rdB = [&](const int it, const int n) -> v4f {
       v4f v = ldsB[(it * 2 + half) * TN + n * 32 + l31];
-      asm volatile("" : "+v"(v));
+      // (pinned by the sched_barrier of its MFMA group; an asm "+v"(v) here would force an lgkmcnt(0) wait right behind the read)
       return v;
     };
     if (cbeg < cend) issue(cbeg);
@@ -192,7 +192,7 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
     auto rdA = [&](const int st, const int m) -> v4f {
       const int t = st / KGC, kg = st % KGC;
       v4f v = ldsA[abase[m] + ((t / R) * HW + (t % R)) * S4 + kg * 2];
-      asm volatile("" : "+v"(v));
+      // (pinned by the sched_barrier of its MFMA group; an asm "+v"(v) here would force an lgkmcnt(0) wait right behind the read)
       return v;
     };
     if (cbeg < cend) stA.prefetch(s, img, oy0, ox0, cbeg, tid, p.src.cstride);
