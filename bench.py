@@ -199,6 +199,10 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
              'accounting': 'achieved / frac = multiply-adds the matrix cores execute (x16/36 of the direct convolution for the '
                            'Winograd form, K padded to the MFMA granule); algorithmic_tflops = SURVEY 8(d) direct-convolution FLOP / time',
              'algorithmic_tflops': f_alg / t / 1e12, 'effective_vs_direct': f_alg / f_exe}
+        if bank.wino and getattr(bank, 'fuse_bn_sums', False):
+            r['also_in_these_launches'] = ('the data-gradient launches whose output has a single consumer (7 of 13 per step) also do the '
+                                           'first reduction pass of that BatchNorm backward in their epilogue (z read + two sums per value); '
+                                           'VV_FUSE_BN_SUMS=0 times the bare convolutions (frac +0.013, step +0.15 ms)')
     else:
         r = {'bound': 'hbm',
              'kernel': 'conv_mfma_kernel<..., BF=true>: 3x3 implicit GEMM, bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation, '
