@@ -391,6 +391,75 @@ def test_winograd_conv_matches_direct_conv(H, Cin, Cout, B):
             torch.testing.assert_close(stats[0], stats[1], rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize('H,C0,C1,Cout,B', [(32, 32, 32, 32, 3), (8, 128, 128, 128, 5), (4, 128, 128, 256, 9)])
+def test_winograd_conv_concat_input_and_fused_bn_sums(H, C0, C1, Cout, B):
+    """Two more launch forms of vv_conv_wino at kernel level: (1) a concat input (VV_IN_CAT: channels [0, C0) = BatchNorm+ReLU of
+    src0, [C0, C0+C1) = src1 as it is -- the decoder's first conv, model/unet.py:57-60) against the direct kernel; (2) a data-gradient
+    launch that also leaves the BatchNorm-backward partial sums of its consumer (vv_conv_params.bn_partial): sum dz and sum dz * xhat
+    with dz = dA [a z + b > 0] against a float64 evaluation on the launch's own output."""
+    import ctypes as C
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H * 77 + Cout)
+    st = torch.cuda.current_stream().cuda_stream
+    Cin = C0 + C1
+    x0 = torch.randn(G, B * H * H, C0, generator=g).cuda()
+    x1 = torch.randn(G, B * H * H, C1, generator=g).cuda()
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    U = Cout * Cin * 9
+
+    def pack(fn, mode, K, N, taps):
+        ent = (L.PackEntry * 1)(L.PackEntry(0, 0, mode, K, K, N))
+        tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()
+        out = torch.zeros(G, taps * K * N, device='cuda')
+        L.check(fn(tab.data_ptr(), 1, G, w.data_ptr(), U, out.data_ptr(), out.stride(0), (9 if taps == 9 else 1) * K * N, st), 'pack')
+        return out
+
+    # (1) concat input, forward panel
+    outs = []
+    for fn, pk in ((lib.vv_conv_mfma, pack(lib.vv_pack_weights, 0, Cin, Cout, 9)), (lib.vv_conv_wino, pack(lib.vv_pack_wino, 0, Cin, Cout, 16))):
+        y = torch.full((G, B * H * H, Cout), 3.0, device='cuda')
+        cp = L.ConvParams(L.CONV3, L.IN_CAT, G, B, H, H, Cin, Cin, Cout, L.view(x0, C0, 0, x0.stride(0)), a.data_ptr(), b.data_ptr(), Cin,
+                          L.view(x1, C1, 0, x1.stride(0)), C0, 0, None, pk.data_ptr(), pk.stride(0), None, 0, L.view(y, Cout, 0, y.stride(0)), None)
+        L.check(fn(C.byref(cp), st), 'conv cat')
+        outs.append(y)
+    scale = outs[0].abs().max().item()
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale
+    ref = torch.cat([torch.relu(x0 * a[:, None, :C0] + b[:, None, :C0]), x1], 2)      # what the kernel must have convolved
+    yr = torch.nn.functional.conv2d(ref[0].view(B, H, H, Cin).permute(0, 3, 1, 2).double(), w[0].double(), padding=1)
+    assert (yr.permute(0, 2, 3, 1).reshape(B * H * H, Cout) - outs[1][0].double()).abs().max().item() <= 1e-4 * scale
+
+    # (2) data gradient Cout -> Cin of the same filter with the fused BatchNorm-backward sums of the Cin-channel producer
+    dy = torch.randn(G, B * H * H, Cout, generator=g).cuda()
+    z = torch.randn(G, B * H * H, Cin, generator=g).cuda()
+    mean = (torch.randn(G, Cin, generator=g) * 0.1).cuda()
+    invstd = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    pk = pack(lib.vv_pack_wino, 1, Cout, Cin, 16)
+    nt = lib.vv_wino_ntiles(B, H)
+    dA = torch.zeros(G, B * H * H, Cin, device='cuda')
+    part = torch.full((G, nt, 2, Cin), 7.0, device='cuda')
+    cp = L.ConvParams(L.CONV3, L.IN_PLAIN, G, B, H, H, Cout, Cout, Cin, L.view(dy, Cout, 0, dy.stride(0)), None, None, 0, L.NULL_VIEW, 0, 0,
+                      None, pk.data_ptr(), pk.stride(0), None, 0, L.view(dA, Cin, 0, dA.stride(0)), None,
+                      z.data_ptr(), z.stride(0), a.data_ptr(), b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cin, part.data_ptr())
+    L.check(lib.vv_conv_wino(C.byref(cp), st), 'dgrad + bn sums')
+    bare = torch.zeros_like(dA)
+    cp2 = L.ConvParams(L.CONV3, L.IN_PLAIN, G, B, H, H, Cout, Cout, Cin, L.view(dy, Cout, 0, dy.stride(0)), None, None, 0, L.NULL_VIEW, 0, 0,
+                       None, pk.data_ptr(), pk.stride(0), None, 0, L.view(bare, Cin, 0, bare.stride(0)), None)
+    L.check(lib.vv_conv_wino(C.byref(cp2), st), 'dgrad')
+    assert torch.equal(dA, bare)                                   # the fused sums do not touch the output
+    d = dA.double() * ((a[:, None] * z + b[:, None]) > 0)
+    xh = (z.double() - mean[:, None].double()) * invstd[:, None].double()
+    s = part.double().sum(1)
+    torch.testing.assert_close(s[:, 0], d.sum(1), rtol=1e-4, atol=1e-3 * d.abs().sum(1).max().item() / (B * H * H) ** 0.5)
+    torch.testing.assert_close(s[:, 1], (d * xh).sum(1), rtol=1e-4, atol=1e-3 * (d * xh).abs().sum(1).max().item() / (B * H * H) ** 0.5)
+    # a stats pointer and bn_partial together are refused
+    cp.stats = part.data_ptr()
+    assert lib.vv_conv_wino(C.byref(cp), st) != 0
+
+
 def test_full_bank_b512_linearity_and_determinism():
     """BASELINE config 4 size (SelfCompleteNetFull = 10 UNets, B = 512, fp32): size-independent properties of the whole
     backward pass -- it is linear in d(loss)/d(out) (doubling dout doubles every gradient bit for bit: scaling by 2 is exact
