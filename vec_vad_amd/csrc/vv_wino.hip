@@ -431,6 +431,12 @@ extern "C" int vv_conv_wino(const vv_conv_params* p, vv_stream stream) {
   if (p->G <= 0 || p->B <= 0 || p->kind != VV_CONV3 || p->H != p->W) return VV_ERR_BAD_ARG;
   if (p->Cout % 32 || p->CinP % 8) return VV_ERR_UNSUPPORTED;
   if (p->bn_partial && (p->stats || !p->bn_z || !p->bn_a || !p->bn_b || !p->bn_mean || !p->bn_invstd)) return VV_ERR_BAD_ARG;
+  {
+    // the epilogue addresses one UNet's output (and z) with 32-bit byte offsets
+    const int64_t px = (int64_t)p->B * p->H * p->W * 4;
+    const int64_t cs = p->out.cstride > p->Cout ? p->out.cstride : p->Cout;
+    if (px * cs >= (1ll << 31)) return VV_ERR_UNSUPPORTED;
+  }
   if (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
