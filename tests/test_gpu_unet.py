@@ -460,6 +460,85 @@ def test_winograd_conv_concat_input_and_fused_bn_sums(H, C0, C1, Cout, B):
     assert lib.vv_conv_wino(C.byref(cp), st) != 0
 
 
+def test_winograd_kernels_random_sweep():
+    """Seeded sweep over launch shapes the parametrised tests above do not enumerate: vv_conv_wino (forward / data-gradient panel,
+    plain / BatchNorm+ReLU / concat input, every level, ragged batches) against vv_conv_mfma, and vv_wgrad_mfma's Winograd form
+    against the direct form for k-splits from 1 to more workgroups than pixel tiles (workgroups without a tile write a zero slab)."""
+    import ctypes as C
+    import random
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rnd = random.Random(1234)
+    G = 2
+
+    def pack(fn, w, mode, K, N, taps):
+        ent = (L.PackEntry * 1)(L.PackEntry(0, 0, mode, K, K, N))
+        tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()
+        out = torch.zeros(G, taps * K * N, device='cuda')
+        L.check(fn(tab.data_ptr(), 1, G, w.data_ptr(), w[0].numel(), out.data_ptr(), out.stride(0), (9 if taps == 9 else 1) * K * N, st), 'pack')
+        return out
+
+    for case in range(20):
+        H = rnd.choice([32, 16, 8, 4])
+        Cin, Cout = rnd.choice([16, 32, 64, 96, 128]), rnd.choice([32, 64, 128])
+        B = rnd.randint(1, 11 if H >= 16 else 37)
+        mode = rnd.choice(['plain', 'act', 'cat'])
+        dgrad = mode == 'plain' and rnd.random() < 0.5
+        if mode == 'cat' and Cin < 32:
+            Cin = 64
+        gen = torch.Generator(device='cpu').manual_seed(case)
+        K, N = (Cout, Cin) if dgrad else (Cin, Cout)
+        if N % 32:
+            N = 32
+        w = (torch.randn(G, (K if dgrad else N), (N if dgrad else K), 3, 3, generator=gen) * 0.1).cuda()   # [Cout][Cin] of the forward conv
+        a = (torch.rand(G, K, generator=gen) + 0.5).cuda()
+        b = (torch.randn(G, K, generator=gen) * 0.2).cuda()
+        c0 = rnd.choice([16, 32]) if mode == 'cat' else K
+        c0 = min(c0, K - 16) // 16 * 16 if mode == 'cat' else K
+        x0 = torch.randn(G, B * H * H, c0, generator=gen).cuda()
+        x1 = torch.randn(G, B * H * H, max(K - c0, 1), generator=gen).cuda()
+        outs = []
+        for fn, pk, nt in ((lib.vv_conv_mfma, pack(lib.vv_pack_weights, w, 1 if dgrad else 0, K, N, 9), lib.vv_conv_ntiles(B, H, H)),
+                           (lib.vv_conv_wino, pack(lib.vv_pack_wino, w, 1 if dgrad else 0, K, N, 16), lib.vv_wino_ntiles(B, H))):
+            y = torch.full((G, B * H * H, N), 5.0, device='cuda')
+            s_ = torch.zeros(G, nt, 2, N, device='cuda')
+            im = {'plain': L.IN_PLAIN, 'act': L.IN_ACT, 'cat': L.IN_CAT}[mode]
+            cp = L.ConvParams(L.CONV3, im, G, B, H, H, K, K, N, L.view(x0, c0, 0, x0.stride(0)),
+                              None if mode == 'plain' else a.data_ptr(), None if mode == 'plain' else b.data_ptr(), K,
+                              L.view(x1, K - c0, 0, x1.stride(0)) if mode == 'cat' else L.NULL_VIEW, c0 if mode == 'cat' else 0, 0, None,
+                              pk.data_ptr(), pk.stride(0), None, 0, L.view(y, N, 0, y.stride(0)), s_.data_ptr())
+            L.check(fn(C.byref(cp), st), 'conv')
+            outs.append((y, s_.sum(1)))
+        scale = outs[0][0].abs().max().item()
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2e-5 * scale, (case, H, K, N, B, mode, dgrad)
+        torch.testing.assert_close(outs[0][1], outs[1][1], rtol=3e-4, atol=3e-3 * max(1.0, scale))
+
+    for case in range(12):
+        H = rnd.choice([32, 16, 8, 4])
+        Cin, Cout = rnd.choice([16, 32, 64]), rnd.choice([32, 64])
+        B = rnd.randint(1, 9 if H >= 16 else 21)
+        gen = torch.Generator(device='cpu').manual_seed(100 + case)
+        x = torch.randn(G, B * H * H, Cin, generator=gen).cuda()
+        dy = torch.randn(G, B * H * H, Cout, generator=gen).cuda()
+        a = (torch.rand(G, Cin, generator=gen) + 0.5).cuda()
+        b = (torch.randn(G, Cin, generator=gen) * 0.2).cuda()
+        nci, nco = (Cin + 31) // 32, Cout // 32
+        nt = lib.vv_wgrad_ntiles(L.CONV3, B, H, H)
+        ks = rnd.choice([1, 2, 3, 7, nt, nt + 3])
+        res = []
+        for flag in (0, 256):
+            part = torch.full((G, nci * nco * ks * 9 * 1024), 9.0, device='cuda')
+            grad = torch.zeros(G, Cout * Cin * 9, device='cuda')
+            wp = L.WgradParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, Cin, Cout, ks, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(), Cin,
+                               L.NULL_VIEW, 0, flag, None, L.View(dy.data_ptr(), dy.stride(0), Cout, 0), part.data_ptr(), part.stride(0))
+            L.check(lib.vv_wgrad_mfma(C.byref(wp), st), 'wgrad')
+            L.check(lib.vv_wgrad_reduce(L.CONV3, G, Cin, Cin, Cout, ks, part.data_ptr(), part.stride(0), grad.data_ptr(), grad.stride(0), st), 'reduce')
+            res.append(grad)
+        scale = res[0].abs().max().item()
+        assert (res[0] - res[1]).abs().max().item() <= 5e-5 * scale, (case, H, Cin, Cout, B, ks)
+
+
 def test_full_bank_b512_linearity_and_determinism():
     """BASELINE config 4 size (SelfCompleteNetFull = 10 UNets, B = 512, fp32): size-independent properties of the whole
     backward pass -- it is linear in d(loss)/d(out) (doubling dout doubles every gradient bit for bit: scaling by 2 is exact
