@@ -84,7 +84,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed.  This is a
     number read from profiles/, not something this run measured (PMC collection needs rocprofv3 around the process)."""
-    for n in (name, name.replace('r02_', 'r01_')):
+    for n in (name, name.replace('r03_', 'r02_'), name.replace('r03_', 'r01_')):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], n
@@ -214,13 +214,22 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
 
 
 def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap='none', breakdown=False, pool=4096,
-             measure_forward=True):
-    """W untimed + exactly K timed train steps; returns the record (rank 0) -- value is the whole-job rate."""
+             measure_forward=True, graph=True, ev_steps=2, small_batch_diag=False):
+    """W untimed + exactly K timed train steps; returns the record (rank 0) -- value is the whole-job rate.
+
+    graph=True (default): the train step is replayed from a hipGraph (FusedTrainer, captured during the warm-up).  The first
+    ``ev_steps`` of the K timed steps run the eager launch loop with HIP events around every launch of the dominant kernel family
+    (the roofline's live per-launch durations); the remaining steps replay the captured step.  graph=False / --breakdown / a
+    side-stream schedule: every timed step is eager with events (the round-2 behaviour)."""
     from vec_vad_amd.trainer import FusedTrainer
     net, tot_of = build_net(model, precision, dev)
     trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
                            overlap={'none': False, 'free': True, 'paired': 'paired'}[overlap])
     bank = trainer.bank
+    graph = bool(graph and trainer.use_graph and overlap == 'none' and not breakdown)
+    trainer.use_graph = graph
+    if graph:
+        warmup = max(warmup, 3)         # eager step (builds plans), capturing step, first replay
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     raw = torch.randint(0, 256, (pool, 5, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
     flow = (torch.randn((pool, tot_of, 32, 32, 2), generator=g) * 2.0).to(dev)
@@ -231,9 +240,12 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     ws = bank.workspace(B)
     fl = conv_flops(bank.lay, B, bank.Ga)
     ev = []
-    trainer.event_hook = lambda label, a, b: ev.append((label, a, b))
+    hook = lambda label, a, b: ev.append((label, a, b))
+    n_ev = steps if not graph else min(ev_steps, steps)
+    trainer.event_hook = hook if n_ev > 0 else None
     trainer.event_labels = set(fl.keys()) if not breakdown else None
-    if trainer.buckets is not None:
+    diag_comm = trainer.buckets is not None and not graph
+    if diag_comm:                      # per-bucket collective timings need the eager loop (events between the launches)
         trainer.buckets.timing = []
         trainer.comm_timing = []
     if dist is not None:
@@ -241,18 +253,32 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
+        if it == n_ev:
+            trainer.event_hook = None          # from here on: hipGraph replay
         trainer.step_cubes(raw, flow, perm[warmup + it])
+    t_host = time.perf_counter() - t0          # the host has enqueued everything (no sync yet)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tl = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(allt, tl)
+        per_rank = [B * steps / float(x.item()) for x in allt]
     trainer.event_hook = None
     comm = None
-    if trainer.buckets is not None:
+    if trainer.buckets is not None and not diag_comm:
+        comm = {'rccl_ranks': world, 'backend': dist.get_backend() if dist is not None else None,
+                'buckets': [{'bucket': k, 'columns': [trainer.buckets.bounds[k], trainer.buckets.bounds[k + 1]],
+                             'mbytes': 4e-6 * bank.G * (trainer.buckets.bounds[k + 1] - trainer.buckets.bounds[k])} for k in (2, 1, 0)],
+                'note': 'in-place all-reduce of three contiguous ranges of the bucket-major gradient buffer, launched between the '
+                        'hipGraph segments of the step; per-bucket timings need the eager loop: bench.py --no-graph'}
+    if trainer.buckets is not None and diag_comm:
         bt = {}
         for k, a, b in trainer.buckets.timing:
             bt.setdefault(k, []).append(a.elapsed_time(b) * 1e3)
@@ -264,7 +290,7 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
                              'allreduce_us_avg': sum(v) / len(v), 'launched_after': {2: 'decoder half of backward', 1: 'deep-encoder '
                              'weight gradients', 0: 'last backward launch'}[k]} for k, v in sorted(bt.items(), reverse=True)],
                 'exposed_comm_us_per_step': sum(exposed) / max(1, len(exposed)),
-                'note': 'allreduce_us = stage copy + collective on the communication stream (HIP events); exposed = main-stream '
+                'note': 'allreduce_us = in-place collective on the communication stream (HIP events); exposed = main-stream '
                         'time from the end of the backward pass to the arrival of the last sums'}
         trainer.buckets.timing = None
         trainer.comm_timing = None
@@ -298,8 +324,13 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     value = B * world * steps / dt
     peak = FP32_MFMA_PEAK if precision == 'fp32' else BF16_MFMA_PEAK
     tag = 'fp32' if precision == 'fp32' else 'bf16'
-    pmc_ok = model == 'net4' and B == 256          # the committed PMC passes were taken on the default workload
-    traffic = pmc_traffic('r02_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')) if pmc_ok else (None, None)
+    # the committed PMC passes: default workload (net4, B=256) and BASELINE config 4 (full, B=512, bf16)
+    if model == 'net4' and B == 256:
+        traffic = pmc_traffic('r03_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16'))
+    elif model == 'full' and B == 512 and precision == 'bf16':
+        traffic = pmc_traffic('r03_pmc_hbm_traffic_bf16_full_b512.json')
+    else:
+        traffic = (None, None)
     rec = {'value': value, 'unit': 'cubes/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
            'dtype': 'f32' if precision == 'fp32' else 'bf16 operands, f32 accumulate',
            'config': {'workload': {'net4': 'UCSDped2-shaped 5raw+1of UNet bank (SelfCompleteNet4, nf=32, padding=False) train step: '
@@ -326,7 +357,26 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
             exe = B * fwd_flop - conv_a + conv_x
             rec['config']['forward_frac_of_fp32_mfma_peak_executed'] = exe / (fwd_ms * 1e-3) / peak
     if comm is not None:
+        if dist is not None:
+            comm['per_rank_cubes_per_s'] = {'min': min(per_rank), 'max': max(per_rank)}
         rec['comm'] = comm
+    cap = next((c for k, c in trainer._graphs.items() if k[0] == 'train' and c != 'warm'), None)
+    rec['execution'] = {'mode': ('hipGraph replay of the captured step (%d launches in %d segment(s)); timed steps 0..%d ran the eager '
+                                 'launch loop with HIP events' % (cap.launches, len(cap.segments), n_ev - 1)) if (graph and cap is not None)
+                        else 'eager launch loop (ctypes), HIP events around the conv-family launches in every timed step',
+                        'launches_per_step': cap.launches if cap is not None else len(ws.fwd[True].calls) + len(ws.bwd.calls) + 3,
+                        'host_enqueue_ms_per_step': 1e3 * t_host / steps}
+    if small_batch_diag and graph:
+        # the same workload on the eager launch loop, for the launch-overhead comparison (outside the timed region)
+        trainer.use_graph = False
+        n = min(steps, 30)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for it in range(n):
+            trainer.step_cubes(raw, flow, perm[it])
+        th = time.perf_counter() - t1
+        torch.cuda.synchronize()
+        rec['execution'].update({'eager_ms_per_step': 1e3 * (time.perf_counter() - t1) / n, 'eager_host_loop_ms_per_step': 1e3 * th / n})
     del trainer, net, raw, flow
     torch.cuda.empty_cache()
     return rec
@@ -438,6 +488,7 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="bf16 = BASELINE config 4's mixed precision; the headline number is fp32, like the reference")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launch loop in every timed step (default: hipGraph replay)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-4 / config-5 / scoring records')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
     ap.add_argument('--overlap', nargs='?', const='free', default='none', choices=('none', 'free', 'paired'),
@@ -463,8 +514,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if dist is not None and dist.get_world_size() != args.gpus:
+        raise SystemExit('process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
     rec = run_unet(args.model, args.precision, args.batch, args.steps, args.warmup, dev, rank, world, dist, args.overlap,
-                   args.breakdown, args.pool)
+                   args.breakdown, args.pool, graph=not args.no_graph)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -472,12 +525,19 @@ def main():
     out = {'metric': 'spatio-temporal cubes/sec (train step)', 'value': rec['value'], 'unit': 'cubes/s', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'], 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': rec['dtype'], 'data': 'synthetic', 'config': rec['config'],
-           'roofline': rec['roofline']}
+           'roofline': rec['roofline'], 'execution': rec['execution']}
     if 'comm' in rec:
         out['comm'] = rec['comm']
     if world == 1 and not args.no_secondary:
         sec = {}
-        for name, fn in (('full_b512_bf16', lambda: run_unet('full', 'bf16', 512, 10, 3, dev, 0, 1, None, 'none', False, 2048)),
+        for name, fn in (('full_b512_bf16', lambda: run_unet('full', 'bf16', 512, 10, 3, dev, 0, 1, None, 'none', False, 2048,
+                                                             graph=not args.no_graph)),
+                         # the per-rank workloads of the reference's DataParallel split (train.py:375): BASELINE configs[2]
+                         # = 256 / 8 GPUs, config.cfg's batch_size = 128 / 8 GPUs -- 1-GPU proxies, hipGraph vs eager loop
+                         ('net4_b32', lambda: run_unet('net4', 'fp32', 32, 50, 5, dev, 0, 1, None, 'none', False, 1024,
+                                                       measure_forward=False, graph=not args.no_graph, small_batch_diag=True)),
+                         ('net4_b16', lambda: run_unet('net4', 'fp32', 16, 50, 5, dev, 0, 1, None, 'none', False, 1024,
+                                                       measure_forward=False, graph=not args.no_graph, small_batch_diag=True)),
                          ('flownet2_1024x448', lambda: run_flownet2(dev)),
                          ('net4_eval_scoring', lambda: run_scoring(dev))):
             try:
@@ -486,6 +546,8 @@ def main():
                 sec[name] = {'value': None, 'error': repr(e)}
         sec['full_b512_bf16']['baseline_config'] = 'configs[3]: ShanghaiTech 5raw+5of (context_of_num=4), batch 512, mixed bf16 -- ' \
                                                    'measured on 1 GPU (the 8-GPU run is the driver\'s)'
+        for nm, per in (('net4_b32', 'BASELINE configs[2] (batch 256 over 8 GPUs)'), ('net4_b16', "config.cfg's batch_size = 128 over 8 GPUs")):
+            sec[nm]['baseline_config'] = 'per-rank workload of %s, measured on 1 GPU without the gradient exchange' % per
         sec['flownet2_1024x448']['baseline_config'] = 'configs[4]: FlowNet2 correlation+conv forward on 1024x436 frame pairs, 1xMI355X'
         out['configs'] = sec
     if not args.no_cpu_baseline and world == 1:

@@ -30,7 +30,12 @@ def save_nested(path, nested, depth):
         for i in idx:
             leaf = leaf[i]
         arr[idx] = np.asarray(leaf)
-    np.save(path, arr, allow_pickle=True)
+    # atomic: a reader (another rank, a later run) sees the previous complete file or the new complete file, never a torn one
+    final = path if path.endswith('.npy') else path + '.npy'
+    tmp = '%s.tmp%d' % (final, os.getpid())
+    with open(tmp, 'wb') as f:
+        np.save(f, arr, allow_pickle=True)
+    os.replace(tmp, final)
 
 
 def load_bboxes(c, mode, dataset=None):

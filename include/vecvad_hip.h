@@ -283,6 +283,16 @@ int vv_bias_from_partials(int32_t G, int32_t C, int32_t ntiles, int32_t coff, in
 int vv_adam(int64_t n, float* param, const float* grad, float* m, float* v, float lr, float beta1, float beta2,
             float eps, float bias_corr1, float bias_corr2_sqrt, float grad_scale, vv_stream stream);
 
+/* Graph-replayable form of the same optimiser step (a captured train step must not carry host-computed bias corrections):
+ *  vv_adam_tick     : t_dev[0] += 1; sc_dev[0] = lr / (1 - beta1^t), sc_dev[1] = sqrt(1 - beta2^t)   (one thread; beta as doubles)
+ *  vv_adam_bucketed : Adam over param / m / v [G][U] reading sc_dev, with the gradient buffer in BUCKET-MAJOR layout -- bucket k =
+ *                     columns [bounds[k], bounds[k+1]) of every UNet, contiguous as [G][width_k] at float offset G*bounds[k], so
+ *                     that each data-parallel all-reduce (train.py:375) runs in place on one contiguous range.  bounds: HOST array
+ *                     of nb+1 multiples of 4, bounds[0] = 0, bounds[nb] = U, nb <= 8. */
+int vv_adam_tick(int64_t* t_dev, float lr, double beta1, double beta2, float* sc_dev, vv_stream stream);
+int vv_adam_bucketed(int32_t G, int64_t U, int32_t nb, const int64_t* bounds, float* param, const float* grad, float* m,
+                     float* v, const float* sc_dev, float beta1, float beta2, float eps, float grad_scale, vv_stream stream);
+
 /* ---- cube adapter (vad_datasets.py:130-168: [T,H,W,C] -> [H,W,T*C], uint8 -> float/255) ----
  * raw  uint8 [N][T][HW][3]  -> x   fp32 NHWC [B][HW][3T]   for the cubes idx[0..B)
  * flow fp32  [N][Tf][HW][2] -> xof fp32 NHWC [B][HW][2Tf]                                      */

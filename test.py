@@ -42,39 +42,70 @@ def load_model(net, state_dict, device):
     return net
 
 
-def score_cubes_device(trainer, cube_list, flow_list, score_batch):
+def score_cubes_device(trainer, cube_list, flow_list, score_batch, chunk_cubes=None):
     """cube_list / flow_list: per-frame arrays [n_i,5,32,32,3] uint8 / [n_i,(Tf,)32,32,2] fp32 (n_i may be 0).
-    All cubes are uploaded ONCE and scored in launches of exactly ``score_batch`` cubes (the tail launch re-scores the last cube
-    as padding: eval-mode scores do not depend on the batch), so one workspace and one launch plan serve the whole test set.
-    Returns the DEVICE tensors (raw [n], of [n] | None) of all cubes in frame order -- they feed vv_frame_scores without
-    visiting the host."""
+    The cubes go to the GPU in bounded super-chunks (``chunk_cubes``, default 32 launches' worth, >= 4096: ~55 KB per cube for the
+    5raw+5of bank, so host and device staging stay at a few hundred MB whatever the size of the test set) through ONE fixed device
+    staging buffer, and are scored in launches of exactly ``score_batch`` cubes (the tail launch re-scores the chunk's last cube
+    as padding: eval-mode scores do not depend on the batch) -- one workspace, one launch plan and one captured hipGraph serve
+    the whole test set.  Returns the DEVICE tensors (raw [n], of [n] | None) of all cubes in frame order -- they feed
+    vv_frame_scores without visiting the host."""
     dev = trainer.bank.device
     keep = [k for k in range(len(cube_list)) if len(cube_list[k])]
     if not keep:
         return torch.zeros(0, device=dev), None
-    raw = np.concatenate([np.asarray(cube_list[k]) for k in keep])
-    flow = np.concatenate([np.asarray(flow_list[k], dtype=np.float32) for k in keep])
-    if raw.dtype != np.uint8:
-        raise TypeError('foreground cubes must be uint8 (the -raw.npy files of train.py:218-222), got %s' % raw.dtype)
-    if raw.ndim == 4:
-        raw = raw[:, None]
-    if flow.ndim == 4:
-        flow = flow[:, None]
-    n = raw.shape[0]
-    rawd = torch.from_numpy(np.ascontiguousarray(raw)).to(dev)
-    flowd = torch.from_numpy(np.ascontiguousarray(flow)).to(dev)
+    counts = [len(cube_list[k]) for k in keep]
+    n = int(sum(counts))
     B = int(min(score_batch, n)) if n < score_batch else int(score_batch)
+    cap = int(chunk_cubes) if chunk_cubes else max(4096, 32 * B)
+    cap = max(B, min(cap, n))
+
+    def prep(k):
+        raw = np.asarray(cube_list[k])
+        flow = np.asarray(flow_list[k], dtype=np.float32)
+        if raw.dtype != np.uint8:
+            raise TypeError('foreground cubes must be uint8 (the -raw.npy files of train.py:218-222), got %s' % raw.dtype)
+        return (raw[:, None] if raw.ndim == 4 else raw), (flow[:, None] if flow.ndim == 4 else flow)
+
+    r0, f0 = prep(keep[0])
+    rawd = torch.empty((cap,) + r0.shape[1:], dtype=torch.uint8, device=dev)
+    flowd = torch.empty((cap,) + f0.shape[1:], dtype=torch.float32, device=dev)
     r_all = torch.empty(n, device=dev)
     o_all = None
-    for s0 in range(0, n, B):
-        idx = torch.arange(s0, s0 + B, device=dev).clamp_(max=n - 1)
-        r, o = trainer.score_cubes(rawd, flowd, idx)
-        m = min(B, n - s0)
-        r_all[s0:s0 + m] = r[:m]
-        if o is not None:
-            if o_all is None:
-                o_all = torch.empty(n, device=dev)
-            o_all[s0:s0 + m] = o[:m]
+    done = 0
+    pend_r, pend_f, pend_n = [], [], 0
+
+    def flush():
+        nonlocal done, pend_r, pend_f, pend_n, o_all
+        m_tot = pend_n
+        if not m_tot:
+            return
+        rawd[:m_tot].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate(pend_r))))
+        flowd[:m_tot].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate(pend_f))))
+        for s0 in range(0, m_tot, B):
+            idx = torch.arange(s0, s0 + B, device=dev).clamp_(max=m_tot - 1)
+            r, o = trainer.score_cubes(rawd, flowd, idx)
+            m = min(B, m_tot - s0)
+            r_all[done + s0:done + s0 + m] = r[:m]
+            if o is not None:
+                if o_all is None:
+                    o_all = torch.empty(n, device=dev)
+                o_all[done + s0:done + s0 + m] = o[:m]
+        done += m_tot
+        pend_r, pend_f, pend_n = [], [], 0
+
+    for k in keep:
+        raw, flow = prep(k)
+        p = 0
+        while p < len(raw):              # a single frame may hold more cubes than a chunk
+            take = min(len(raw) - p, cap - pend_n)
+            pend_r.append(raw[p:p + take])
+            pend_f.append(flow[p:p + take])
+            pend_n += take
+            p += take
+            if pend_n == cap:
+                flush()
+    flush()
     return r_all, o_all
 
 

@@ -172,7 +172,7 @@ def main():
             name = conv_key_to_state_name(stems, key)
             ref = sd[name].grad
             n = ref.numel()
-            mine = bank.grads[g, off:off + n].view(ref.shape)
+            mine = bank.grad_view(g, key, shape=ref.shape)
             d, r = err(mine, ref)
             is_bn_bias_conv = key.startswith('c') and key.endswith('.b')
             if is_bn_bias_conv:

@@ -192,19 +192,24 @@ def _worker_rccl_world1(port, q):
     raw, flow = O.seeded_cubes(12, 1, 33)
     rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
     outs = []
-    for group, overlap in ((None, False), (dist.group.WORLD, False), (dist.group.WORLD, True)):
+    # last configuration: the hipGraph path -- the step captured as three segments with the collectives launched between them
+    for group, overlap, graphed in ((None, False, False), (dist.group.WORLD, False, False), (dist.group.WORLD, True, False),
+                                    (dist.group.WORLD, False, True)):
         net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=True,
                                padding=False)
         net.load_state_dict(O.seeded_state_dict('net4', nf=32, padding=False, seed=0))
         net = net.cuda().train()
         tr = FusedTrainer(net, process_group=group, overlap=overlap, always_bucket=True)
         assert (tr.buckets is not None) == (group is not None)
-        if tr.buckets is not None:
+        if tr.buckets is not None and not graphed:
             tr.buckets.timing = []
-        for _ in range(2):
+        for _ in range(4):          # graphed: eager step, capturing step, two replays
             tr.step_cubes(rawd, flowd, torch.arange(12, device='cuda'))
         torch.cuda.synchronize()
-        n_coll = len(tr.buckets.timing) if tr.buckets is not None else 0
+        n_coll = len(tr.buckets.timing) if (tr.buckets is not None and not graphed) else 0
+        if graphed:
+            caps = [c for k, c in tr._graphs.items() if k[0] == 'train' and c != 'warm']
+            n_coll = -len(caps[0].segments) if caps else 0
         outs.append((tr.bank.params.cpu().numpy(), n_coll))
     t = torch.ones(4, device='cuda')
     dist.all_reduce(t)
@@ -222,8 +227,10 @@ def test_rccl_world1_bucketed_step_bitwise_equal_to_no_group():
     outs, s, backend = q.get(timeout=600)
     p.join(120)
     assert backend == 'nccl' and s == 4.0
-    assert outs[0][1] == 0 and outs[1][1] == 6 and outs[2][1] == 6        # 3 buckets x 2 steps went through RCCL
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], outs[2][0])
+    assert outs[0][1] == 0 and outs[1][1] == 12 and outs[2][1] == 12       # 3 buckets x 4 steps went through RCCL
+    assert outs[3][1] == -4                                                  # captured as 4 segments (3 exchanges between them)
+    for k in (1, 2, 3):
+        assert np.array_equal(outs[0][0], outs[k][0]), k
 
 
 def _worker_uneven(rank, world, port, q):
@@ -306,8 +313,7 @@ def test_uneven_global_batch_is_the_global_mean_gradient():
         if name.endswith('.0.bias') or name.endswith('.3.bias'):
             continue
         g, key = by_id[id(p)]
-        off, _ = bank.lay.p[key]
-        got = flat[g, off:off + p.numel()].view(p.shape).double()
+        got = bank.grad_view(g, key, grads=flat, shape=p.shape).double()
         num += float(((got - tot[name].double()) ** 2).sum())
         den += float((tot[name].double() ** 2).sum())
     assert num <= (2e-2 ** 2) * den, (num, den)          # 3- and 2-cube train-mode BatchNorm: tie flips dominate (cf. the small-batch tests)

@@ -23,8 +23,7 @@ def _grad_table(net):
     out = {}
     for name, p in net.named_parameters():
         g, key = by_id[id(p)]
-        off, _ = bank.lay.p[key]
-        out[name] = bank.grads[g, off:off + p.numel()].view(p.shape)
+        out[name] = bank.grad_view(g, key, shape=p.shape)
     return out
 
 

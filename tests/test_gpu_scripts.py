@@ -11,6 +11,26 @@ from _util import load_golden
 pytestmark = pytest.mark.gpu
 
 
+def _observe(name, **vals):
+    """Observed deviations of a parity check: printed (pytest -s / -rP) and appended to gpurun_out/observed.jsonl so that the
+    bars in this file can be set from measurements (bars at 2x the observed value)."""
+    import json
+    rec = dict(test=name, **{k: float(v) for k, v in vals.items()})
+    print('OBSERVED', json.dumps(rec))
+    try:
+        root = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'observed.jsonl'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
+
+
 @pytest.mark.parametrize('precision,golden', [('fp32', 'script_net4'), ('fp32', 'script_net4_f240'), ('bf16', 'script_net4'),
                                               ('bf16', 'script_net4_f240')])
 def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precision, golden):
@@ -42,12 +62,14 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
     sd, raw_train, of_train = T.train_block(net, [lambda: (raw, flow[:, 0])], epochs=2, batch_size=8, shuffle_seed=-1,
                                             device='cuda', log=lines.append)
     assert all(k.startswith('module.') for k in sd)
+    obs = dict(train_raw=_rel(raw_train, g['raw_train']), train_of=_rel(of_train, g['of_train']))
     np.testing.assert_allclose(raw_train, g['raw_train'], rtol=tol['train'])
     np.testing.assert_allclose(of_train, g['of_train'], rtol=tol['train'])
     # running-average loss lines (printed every 5 batches): first line is batch 0 of epoch 0
     first = lines[0]
     assert 'raw loss: ' in first
     l_raw0 = float(first.split('raw loss: ')[1].split(',')[0])
+    obs['loss0'] = abs(l_raw0 - g['losses'][0][0]) / g['losses'][0][0]
     assert abs(l_raw0 - g['losses'][0][0]) <= tol['loss'] * g['losses'][0][0]
 
     # ---- test stage on synthetic frames (same construction as the golden script)
@@ -83,14 +105,46 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
     out_dir = str(tmp_path / 'score_mask')
     fs = S.score_frames([[[net2]]], stats_r, stats_o, fset, fset2, bset, h, w, 1.0, 1.0, True, 'cuda', score_batch=5,
                         result_dir=out_dir)
+    obs['frame'] = float(np.max(np.abs(np.asarray(fs) - g['frame_scores']) / (1.0 + np.abs(g['frame_scores']))))
+    from utils import save_roc_pr_curve_data, frame_roc_auc
+    auc = save_roc_pr_curve_data(fs, np.array(labels), str(tmp_path / 'roc.npz'), verbose=False)
+    obs['auc'] = abs(auc - float(g['auc']))
+    _observe('scripts[%s-%s]' % (precision, golden), **obs)
     np.testing.assert_allclose(fs, g['frame_scores'], rtol=tol['frame'], atol=tol['frame'])
     # the saved maps have the reference's format (torch-pickled float64 [h,w]) and the same maxima
     m3 = torch.load(os.path.join(out_dir, '3'), weights_only=False)
     assert m3.shape == (h, w) and m3.dtype == np.float64 and abs(m3.max() - fs[3]) < 1e-12
-    from utils import save_roc_pr_curve_data, frame_roc_auc
-    auc = save_roc_pr_curve_data(fs, np.array(labels), str(tmp_path / 'roc.npz'), verbose=False)
     assert abs(auc - float(g['auc'])) <= tol['auc']
     assert abs(frame_roc_auc(fs, np.array(labels)) - auc) < 1e-12
+
+
+def test_score_cubes_device_bounded_chunks_equal_one_upload():
+    """test.py's scoring helper uploads the test set in bounded super-chunks through one staging buffer: chunks smaller
+    than a frame, frames smaller than a launch, empty frames -- same scores, bit for bit, as one chunk holding everything."""
+    from oracle import unet_oracle as O
+    import test as S
+    from model.unet import SelfCompleteNet4
+    from vec_vad_amd.trainer import FusedTrainer
+    net = SelfCompleteNet4(features_root=32, tot_raw_num=5, tot_of_num=1, border_mode='predict', rawRange=None, useFlow=True,
+                           padding=False)
+    net.load_state_dict(O.seeded_state_dict('net4', nf=32, padding=False, seed=0))
+    net = net.cuda().eval()
+    tr = FusedTrainer(net)
+    counts = [3, 0, 9, 1, 0, 4, 7]
+    cubes, flows = [], []
+    for k, c in enumerate(counts):
+        rw, fl = O.seeded_cubes(max(c, 1), 1, 50 + k)
+        cubes.append(rw[:c])
+        flows.append(fl[:c, 0])
+    ref_r, ref_o = S.score_cubes_device(tr, cubes, flows, 4, chunk_cubes=10 ** 6)
+    assert ref_r.shape[0] == sum(counts)
+    for chunk in (5, 4, 11):
+        r, o = S.score_cubes_device(tr, cubes, flows, 4, chunk_cubes=chunk)
+        assert torch.equal(r, ref_r) and torch.equal(o, ref_o), chunk
+    x, x_of = O.cubes_to_inputs(np.concatenate(cubes), np.concatenate(flows)[:, None])
+    rs, os_ = O.score_pass(O.seeded_state_dict('net4', nf=32, padding=False, seed=0), O.bank_spec('net4'), x, x_of, sum(counts))
+    np.testing.assert_allclose(ref_r.cpu().numpy(), rs, rtol=1e-3)
+    np.testing.assert_allclose(ref_o.cpu().numpy(), os_, rtol=1e-3)
 
 
 @pytest.mark.gpu

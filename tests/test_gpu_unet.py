@@ -252,6 +252,46 @@ def test_side_stream_weight_grad_is_bitwise_identical():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize('precision,kind,B', [('fp32', 'net4', 32), ('fp32', 'net4', 16), ('bf16', 'full', 24)])
+def test_hipgraph_step_and_scoring_bitwise_equal_to_eager(monkeypatch, precision, kind, B):
+    """The captured train step (cube gather + forward + backward + Adam with device-side step scalars) and the captured scoring
+    pass replay bit for bit what the eager launch loop computes -- with different cubes every step (static index buffer), over
+    enough steps that Adam's bias corrections matter, at the per-rank batch sizes of the reference's DataParallel split
+    (train.py:375: 256 / 8 and config.cfg's 128 / 8)."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    monkeypatch.setenv('VV_PRECISION', precision)
+    tot_of = 1 if kind == 'net4' else 5
+    raw, flow = O.seeded_cubes(3 * B, tot_of, 21)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    g = torch.Generator().manual_seed(5)
+    perms = [torch.randperm(3 * B, generator=g)[:B].cuda() for _ in range(7)]
+    outs = []
+    for graph in (False, True):
+        net, _, _ = _build(kind, False)
+        net.train()
+        tr = FusedTrainer(net)
+        tr.use_graph = graph
+        losses = []
+        for p in perms:
+            ws = tr.step_cubes(rawd, flowd, p)
+            losses.append(torch.stack([x for x in tr.losses(ws) if x is not None]).clone())
+        cap = [c for k, c in tr._graphs.items() if k[0] == 'train' and c != 'warm']
+        assert (len(cap) == 1 and len(cap[0].segments) == 1 and cap[0].launches > 100) if graph else not cap
+        assert tr.bank.adam_t == 7 and int(tr.bank._adam_t_dev.item()) == 7
+        net.eval()
+        sc = []
+        for k in range(4):          # eager, capturing, two replays -- on different cubes, then the default "first B cubes" form
+            r, o = tr.score_cubes(rawd, flowd, perms[k])
+            sc.append(torch.cat([r, o]).clone())
+        r, o = tr.score_cubes(rawd, flowd, None, B)
+        sc.append(torch.cat([r, o]).clone())
+        outs.append((tr.bank.params.clone(), tr.bank.bufs.clone(), tr.bank.nbt.clone(), torch.stack(losses), torch.stack(sc)))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][3]).all() and int(outs[0][2].min()) == 7
+
+
 def test_bn_backward_sums_fused_into_data_gradient(monkeypatch):
     """The first reduction pass of a layer's BatchNorm backward (sum dz, sum dz * xhat) runs in the epilogue of the Winograd
     data-gradient launch that produces dA (vv_conv_params.bn_partial, VV_BNBWD_PARTIALS_PER_TILE) where that launch is the only
@@ -270,7 +310,7 @@ def test_bn_backward_sums_fused_into_data_gradient(monkeypatch):
         assert tr.bank.fuse_bn_sums == (fuse == '1')
         tr.step_cubes(rawd, flowd, torch.arange(37, device='cuda'))
         torch.cuda.synchronize()
-        grads.append(tr.bank.grads.clone())
+        grads.append(tr.bank.grads_gu())
     lay = tr.bank.lay
     worst = 0.0
     for key, (off, shape) in lay.p.items():

@@ -119,8 +119,8 @@ def _bucket_worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from vec_vad_amd.trainer import GradBuckets, shard_batch
-    g = torch.arange(6 * 10, dtype=torch.float32).view(6, 10) * (rank + 1)
-    b = GradBuckets(g, [0, 4, 10], dist.group.WORLD)
+    g = torch.arange(6 * 10, dtype=torch.float32) * (rank + 1)          # bucket-major flat buffer: [6][4] then [6][6]
+    b = GradBuckets(g, 6, [0, 4, 10], dist.group.WORLD)
     b.launch(1)
     b.launch(0)
     b.finish()
@@ -141,9 +141,59 @@ def test_grad_buckets_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     for p in ps:
         p.join(60)
-    expect = torch.arange(60, dtype=torch.float32).view(6, 10) * 3
+    expect = torch.arange(60, dtype=torch.float32) * 3
     assert np.array_equal(res[0][1], expect.numpy()) and np.array_equal(res[1][1], expect.numpy())
     assert res[0][2].tolist() == [0, 1, 2, 3] and res[1][2].tolist() == [4, 5, 6, 7]
+
+
+def _extract_worker(rank, world, port, root, fail, q):
+    import time
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import foreground
+    import train
+    c = {'data_root_dir': root, 'modality': 'raw2flow', 'dataset_name': 'UCSDped2', 'mode_fg': 'detection'}
+    probe = os.path.join(root, 'raw2flow', 'UCSDped2_foreground_train_detection-raw.npy')
+
+    def fake_extract(c, device):
+        time.sleep(1.5)                          # the other rank is already waiting on the side group by now
+        if fail:
+            raise ValueError('no frames')
+        os.makedirs(os.path.dirname(probe), exist_ok=True)
+        foreground.save_nested(probe, [[np.zeros((2, 3))]], 2)
+    foreground.extract_train = fake_extract
+    t0 = time.time()
+    try:
+        train._extract_once(c, 'cpu', dist, timeout_h=0.05)
+        q.put((rank, 'ok', os.path.exists(probe), time.time() - t0))
+    except Exception as e:
+        q.put((rank, type(e).__name__, os.path.exists(probe), time.time() - t0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fail', [False, True])
+def test_extract_once_other_ranks_wait_on_a_side_group(tmp_path, fail):
+    """train._extract_once under torchrun: rank 0 cuts the cubes, rank 1 waits on a gloo side group (no marker file that a
+    crashed or restarted job could leave behind) and only continues when the atomically written file is there; a failure of
+    rank 0 reaches rank 1 at once instead of after the timeout."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 1000) + (7 if fail else 0)
+    ps = [ctx.Process(target=_extract_worker, args=(r, 2, port, str(tmp_path), fail, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps])
+    for p in ps:
+        p.join(60)
+    if fail:
+        assert res[0][1] == 'ValueError' and res[1][1] == 'RuntimeError' and not res[1][2]
+    else:
+        assert res[0][1] == 'ok' and res[1][1] == 'ok' and res[0][2] and res[1][2]
+        assert res[1][3] >= 1.0                  # rank 1 really waited for rank 0
+    assert not [f for f in os.listdir(tmp_path) if f.startswith('.')]          # nothing left behind
 
 
 def test_context_range_matches_reference_golden():

@@ -114,22 +114,42 @@ def _dist():
     return dist, dist.get_rank(), dist.get_world_size()
 
 
-def _extract_once(c, device, poll_s=2.0):
-    """Rank 0 cuts the training cubes and then drops a marker file; every other rank of the same torchrun job polls for it."""
-    import time
-    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
-    job = '%s_%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.environ.get('MASTER_PORT', '0'))
-    marker = os.path.join(c['data_root_dir'], c['modality'], '.%s_train_extracted_%s' % (c['dataset_name'], job))
-    if rank == 0:
+def _extract_once(c, device, dist=None, timeout_h=48.0):
+    """Rank 0 cuts the training cubes (train.py:102-226); every other rank of the job waits for it.
+
+    The wait is a barrier on a gloo SIDE group with its own, long, explicit timeout -- cutting a large dataset takes longer than
+    the default collective timeout, and the RCCL group must not carry a 48 h watchdog for its real collectives.  No marker
+    files: nothing survives a crash or a ``torchrun --max-restarts`` restart that a later attempt could mistake for "done", and
+    the .npy files are written atomically (foreground.save_nested: tmp + os.replace), so a rank that gets past the barrier reads
+    complete files.  All ranks must see ``data_root_dir`` (one node, or a shared filesystem); the ranks check that after the
+    barrier instead of assuming it."""
+    rank = dist.get_rank() if dist is not None else 0
+    if dist is None:
         from foreground import extract_train
         extract_train(c, device)
-        if world > 1:
-            os.makedirs(os.path.dirname(marker), exist_ok=True)
-            with open(marker, 'w') as f:
-                f.write('done')
-    else:
-        while not os.path.exists(marker):
-            time.sleep(poll_s)
+        return
+    import datetime
+    side = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=timeout_h))
+    err = None
+    if rank == 0:
+        try:
+            from foreground import extract_train
+            extract_train(c, device)
+        except Exception as e:          # the other ranks must not wait 48 h for a rank that died
+            err = e
+    flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
+    dist.broadcast(flag, src=0, group=side)          # = the barrier; carries rank 0's verdict
+    dist.destroy_process_group(side)
+    if err is not None:
+        raise err
+    if int(flag.item()):
+        raise RuntimeError('rank 0 failed while extracting the training cubes')
+    base = os.path.join(c['data_root_dir'], c['modality'], c['dataset_name'] + '_')
+    fg = c['mode_fg']
+    probe = base + ('foreground_train_{}_seg_0-raw.npy' if c['dataset_name'] == 'ShanghaiTech' else 'foreground_train_{}-raw.npy').format(fg)
+    if not os.path.exists(probe):
+        raise RuntimeError('rank %d cannot see %s: train.py under torchrun needs data_root_dir on a filesystem every rank mounts'
+                           % (rank, probe))
 
 
 def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0, shuffle_seed=0, device='cuda',
@@ -245,11 +265,9 @@ def main(config_path='config.cfg'):
     cp, ds, fg, root, mod, method = c['cp'], c['dataset_name'], c['mode_fg'], c['data_root_dir'], c['modality'], c['method']
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(device)
-    if not cp.getboolean(ds, 'train_foreground_saved'):      # train.py:102-226, cubes cut on the GPU (vv_crop_resize)
-        # BEFORE the process group exists: extraction of a large dataset takes longer than a collective's watchdog allows, so
-        # the other ranks wait on a marker file, not on a barrier
-        _extract_once(c, device)
     dist, rank, world = _dist()
+    if not cp.getboolean(ds, 'train_foreground_saved'):      # train.py:102-226, cubes cut on the GPU (vv_crop_resize)
+        _extract_once(c, device, dist)
     net = build_network(c)
     base = os.path.join(root, mod, ds + '_')
     shanghai = ds == 'ShanghaiTech'
@@ -302,11 +320,6 @@ def main(config_path='config.cfg'):
         print('Training of {} for dataset: {} has completed!'.format(method, ds))
     if dist is not None:
         dist.barrier()
-        if rank == 0:
-            job = '%s_%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.environ.get('MASTER_PORT', '0'))
-            marker = os.path.join(root, mod, '.%s_train_extracted_%s' % (ds, job))
-            if os.path.exists(marker):
-                os.remove(marker)
 
 
 if __name__ == '__main__':

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- MUST be imported before the .so: both link libamd
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VV_LIB_PATH') or os.path.join(HERE, 'csrc', 'libvecvad_hip.so')      # VV_LIB_PATH: A/B experiments (tools/)
 
-c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
 IN_PLAIN, IN_ACT, IN_POOL, IN_CAT, IN_CUBE = 0, 1, 2, 3, 4
 CONV3, CONVT_FWD, CONVT_DGRAD = 0, 1, 2
@@ -120,6 +120,8 @@ _SIGS = {
     'vv_bias_grad': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'vv_bias_from_partials': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'vv_adam': (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    'vv_adam_tick': (c_i32, [c_vp, c_f32, c_f64, c_f64, c_vp, c_vp]),
+    'vv_adam_bucketed': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
     'vv_cube_gather': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vv_pool_act': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_cube_erase': (c_i32, [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

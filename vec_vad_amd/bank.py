@@ -182,16 +182,35 @@ class UNetBank:
         self.device = torch.device(device)
         self._alloc_state()
         self.ws = {}
-        self.adam_t = 0
+
+    @property
+    def adam_t(self):
+        return self._adam_t
+
+    @adam_t.setter
+    def adam_t(self, t):
+        self._adam_t = int(t)
+        self._adam_t_dev.fill_(int(t))
 
     # ------------------------------------------------------------------------------------------ persistent state
     def _alloc_state(self):
         d, lay, G = self.device, self.lay, self.G
         self.params = torch.zeros(G, lay.U, device=d)
         self.bufs = torch.zeros(G, lay.UB, device=d)
-        self.grads = torch.zeros(G, lay.U, device=d)
+        # gradients: BUCKET-MAJOR flat buffer.  Bucket k = parameter columns [gb[k], gb[k+1]) of every UNet, stored contiguously as
+        # [G][gb[k+1]-gb[k]] at float offset G*gb[k]: the three data-parallel exchanges (decoder / deep encoder / shallow encoder,
+        # trainer.GradBuckets) are in-place all-reduces of contiguous ranges -- no staging copies.  Kernels address a gradient
+        # tensor through (pointer, per-UNet stride) pairs, so only the stride changes (self._g).
+        self.gb = [0, lay.p['c4.w'][0], lay.p['c8.w'][0], lay.U]
+        self._gb_c = (C.c_int64 * len(self.gb))(*self.gb)
+        self.grads = torch.zeros(G * lay.U, device=d)
         self.adam_m = None
         self.adam_v = None
+        # Adam's step counter and bias-correction scalars live on the device (vv_adam_tick), so a captured train step (hipGraph)
+        # replays with the right values; the host copy (adam_t) is bookkeeping and is pushed to the device when it is assigned
+        self._adam_t = 0
+        self._adam_t_dev = torch.zeros(1, dtype=torch.long, device=d)
+        self._adam_sc = torch.zeros(2, device=d)
         self.nbt = torch.zeros(G, len(lay.convs), dtype=torch.long, device=d)
         self.packed = torch.zeros(G, lay.UP, device=d)
         cin_p = lay.convs[0].cinp
@@ -274,7 +293,7 @@ class UNetBank:
         device = torch.device(device)
         if device == self.device:
             return self
-        for n in ('params', 'bufs', 'grads', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table', 'pack_table_w', 'fold_table', 'ab_ident'):
+        for n in ('params', 'bufs', 'grads', '_adam_t_dev', '_adam_sc', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table', 'pack_table_w', 'fold_table', 'ab_ident'):
             setattr(self, n, getattr(self, n).to(device))
         if self.adam_m is not None:
             self.adam_m, self.adam_v = self.adam_m.to(device), self.adam_v.to(device)
@@ -291,12 +310,43 @@ class UNetBank:
             n *= s
         return self.params[g, off:off + n].view(shape)
 
-    def grad_view(self, g, key, grads=None):
-        off, shape = self.lay.p[key]
+    def _bucket_of(self, off):
+        for k in range(len(self.gb) - 1):
+            if self.gb[k] <= off < self.gb[k + 1]:
+                return k
+        raise KeyError(off)
+
+    def grad_offset(self, g, key):
+        """float offset of the gradient of parameter ``key`` of UNet ``g`` inside the bucket-major buffer."""
+        off = self.lay.p[key][0]
+        k = self._bucket_of(off)
+        lo, w = self.gb[k], self.gb[k + 1] - self.gb[k]
+        return self.G * lo + g * w + (off - lo)
+
+    def _g(self, key):
+        """(device pointer, per-UNet stride in floats) of the gradient of ``key`` for the active window's first UNet."""
+        k = self._bucket_of(self.lay.p[key][0])
+        return self.grads.data_ptr() + 4 * self.grad_offset(self.g0, key), self.gb[k + 1] - self.gb[k]
+
+    def grad_view(self, g, key, grads=None, shape=None):
+        """gradient of parameter ``key`` of UNet ``g``; ``shape``: the module parameter's own shape where the bank pads (the 1x1 output
+        conv has 4 rows in the bank, 3 / 2 in the module)."""
+        off, lshape = self.lay.p[key]
+        shape = lshape if shape is None else tuple(shape)
         n = 1
         for s in shape:
             n *= s
-        return (self.grads if grads is None else grads)[g, off:off + n].view(shape)
+        o = self.grad_offset(g, key)
+        return (self.grads if grads is None else grads).view(-1)[o:o + n].view(shape)
+
+    def grads_gu(self, grads=None):
+        """the gradient buffer re-assembled as [G][U] (a copy; tests / diagnostics)."""
+        src = (self.grads if grads is None else grads).view(-1)
+        out = torch.empty(self.G, self.lay.U, device=src.device, dtype=src.dtype)
+        for k in range(len(self.gb) - 1):
+            lo, hi = self.gb[k], self.gb[k + 1]
+            out[:, lo:hi] = src[self.G * lo:self.G * hi].view(self.G, hi - lo)
+        return out
 
     def buf_view(self, g, key):
         off, shape = self.lay.b[key]
@@ -524,7 +574,6 @@ class UNetBank:
         f = lambda *s: torch.empty(*s, device=d, dtype=torch.float32)
         P = _Plan()
         pbase, kbase = self._p(self.params, g0 * U), self._p(self.packed, g0 * UP)
-        gbase = self._p(self.grads, g0 * U)
         abg = lay.cmax
         HWp = HW0 * HW0
         last = lay.convs[-1]
@@ -581,8 +630,9 @@ class UNetBank:
                                    # ... and the BatchNorm-backward partial sums of the last conv layer (no reduction pass for it)
                                    self._p(ws.ab[2, last.idx]), self._p(ws.ab[3, last.idx]), ws.bnpart.data_ptr(),
                                    (1 if self.da16 else 0) | (2 if self.y16 else 0)), 'outconv_bwd')
-        P.add(lib.vv_outconv_bwd_reduce, (Ga, nf, B, ws.ocpart.data_ptr(), self._p(self.oc, g0), gbase + 4 * lay.p['o.w'][0],
-                                          gbase + 4 * lay.p['o.b'][0], U), 'outconv_bwd_reduce')
+        assert self._g('o.w')[1] == self._g('o.b')[1]
+        P.add(lib.vv_outconv_bwd_reduce, (Ga, nf, B, ws.ocpart.data_ptr(), self._p(self.oc, g0), self._g('o.w')[0],
+                                          self._g('o.b')[0], self._g('o.w')[1]), 'outconv_bwd_reduce')
 
         def dA_for(l):
             """(dA view, dpool ptr, dpool gstride) feeding the BN backward of conv layer l."""
@@ -648,8 +698,8 @@ class UNetBank:
             P.keep.append(bp)
             if not (from_outconv or from_dgrad):
                 P.add(lib.vv_bn_bwd_reduce, (C.byref(bp),), 'bn_bwd_reduce%d' % i, wait=reuse_wait)
-            P.add(lib.vv_bn_bwd_apply, (C.byref(bp), pbase + 4 * lay.p['c%d.g' % i][0], U, gbase + 4 * lay.p['c%d.g' % i][0],
-                                        gbase + 4 * lay.p['c%d.beta' % i][0], U, ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
+            P.add(lib.vv_bn_bwd_apply, (C.byref(bp), pbase + 4 * lay.p['c%d.g' % i][0], U, self._g('c%d.g' % i)[0],
+                                        self._g('c%d.beta' % i)[0], self._g('c%d.g' % i)[1], ws.bnscr.data_ptr()), 'bn_bwd_apply%d' % i,
                   record='dy%d' % i, wait=reuse_wait if (from_outconv or from_dgrad) else ())
             # data gradient
             if i > 0:
@@ -687,8 +737,8 @@ class UNetBank:
             P.keep.append(wp)
             P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,),
                   record='wdone%d' % i, pwait=('*main',))
-            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * max(kw, 1), ws.wpart.data_ptr(), wpg,
-                                        gbase + 4 * lay.p['c%d.w' % i][0], U), 'wgrad_reduce%d' % i, stream=1)
+            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * max(kw, 1), ws.wpart.data_ptr(), wpg)
+                  + self._g('c%d.w' % i), 'wgrad_reduce%d' % i, stream=1)
 
         def convT_bwd(u, m):
             """m: the CAT conv layer that consumed convT u; its data gradient holds d(convT out) in channels [skipC, cin)."""
@@ -703,8 +753,8 @@ class UNetBank:
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
             ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles2(B, m.H, m.H, L.CONV3, self.cflag)
-            P.add(lib.vv_bias_from_partials, (Ga, m.cin, ntd, skipc, co, ws.dstats.data_ptr(), ntd * 2 * m.cin,
-                                              gbase + 4 * lay.p['t%d.b' % u][0], U), 'convT_bias%d' % u)
+            P.add(lib.vv_bias_from_partials, (Ga, m.cin, ntd, skipc, co, ws.dstats.data_ptr(), ntd * 2 * m.cin)
+                  + self._g('t%d.b' % u), 'convT_bias%d' % u)
             y = ws.y[sidx]
             wpl = wplan['t%d' % u]
             ks, kw = wpl[0], (wpl[2] if len(wpl) > 2 else 0)
@@ -716,8 +766,8 @@ class UNetBank:
             # side stream: its dy is the concat layer's data gradient (main stream) -- wait for it
             P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1,
                   wait=('D%d' % m.idx,), pwait=('*main',))
-            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr(), wpg,
-                                        gbase + 4 * lay.p['t%d.w' % u][0], U), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
+            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr(), wpg)
+                  + self._g('t%d.w' % u), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
 
         for l in reversed(lay.convs):
             conv_bwd(l)
@@ -790,14 +840,16 @@ class UNetBank:
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
-        self.adam_t += 1
+        self._adam_t += 1
         self.mark_dirty()
-        bc1 = 1.0 - beta1 ** self.adam_t
-        bc2 = 1.0 - beta2 ** self.adam_t
         g = self.grads if grads is None else grads
-        L.check(self.lib.vv_adam(self.params.numel(), self.params.data_ptr(), g.data_ptr(), self.adam_m.data_ptr(),
-                                 self.adam_v.data_ptr(), lr, beta1, beta2, eps, bc1, math.sqrt(bc2), grad_scale,
-                                 self._stream()), 'adam')
+        st = self._stream()
+        # step counter + bias corrections on the device (1 - beta^t in double like torch.optim.Adam, train.py:376), then one
+        # launch over the whole bank reading the bucket-major gradient buffer
+        L.check(self.lib.vv_adam_tick(self._adam_t_dev.data_ptr(), lr, beta1, beta2, self._adam_sc.data_ptr(), st), 'adam_tick')
+        L.check(self.lib.vv_adam_bucketed(self.G, self.lay.U, len(self.gb) - 1, self._gb_c, self.params.data_ptr(), g.data_ptr(),
+                                          self.adam_m.data_ptr(), self.adam_v.data_ptr(), self._adam_sc.data_ptr(), beta1, beta2,
+                                          eps, grad_scale, st), 'adam')
 
     def outputs_nchw(self, ws):
         """(of_out [B,2*n_of,32,32], raw_out [B,3*n_raw,32,32]) in the reference's channel order."""

@@ -270,7 +270,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             float v = acc[m][n][i] + bias[n];
-            if (p.pad0 & VV_CONV_RELU) v = fmaxf(v, 0.f);
+            if (p.pad0 & VV_CONV_RELU) v = v < 0.f ? 0.f : v;      // NaN-propagating (fmaxf would drop a NaN)
             const __bf16 hv = (__bf16)v;
             lo[pp * ORS + n * 32 + l31] = __builtin_bit_cast(unsigned short, hv);
             v = ok ? (float)hv : 0.f;
@@ -321,7 +321,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             float v = acc[m][n][i] + bias[n];
-            if (p.pad0 & VV_CONV_RELU) v = fmaxf(v, 0.f);      // eval mode: BatchNorm folded into the filter, ReLU in the epilogue
+            if (p.pad0 & VV_CONV_RELU) v = v < 0.f ? 0.f : v;      // NaN-propagating (fmaxf would drop a NaN)      // eval mode: BatchNorm folded into the filter, ReLU in the epilogue
             if (o16) {
               const __bf16 hv = (__bf16)v;
               outh[e + n * 32] = hv;

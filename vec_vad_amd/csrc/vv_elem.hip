@@ -697,6 +697,48 @@ adam_kernel(const int64_t n4, float4* __restrict__ p, const float4* __restrict__
   }
 }
 
+// Step scalars of Adam in device memory, so that a captured step (hipGraph) replays with the right bias corrections: one thread
+// advances the step counter and leaves sc[0] = lr / (1 - beta1^t) (float / float like vv_adam), sc[1] = sqrt(1 - beta2^t).
+// beta1 / beta2 arrive as the doubles torch.optim.Adam computes with.
+__global__ void adam_tick_kernel(int64_t* __restrict__ t_dev, const float lr, const double beta1, const double beta2,
+                                 float* __restrict__ sc) {
+  if (threadIdx.x | blockIdx.x) return;
+  const int64_t t = t_dev[0] + 1;
+  t_dev[0] = t;
+  const float bc1 = (float)(1.0 - pow(beta1, (double)t));
+  sc[0] = __fdiv_rn(lr, bc1);
+  sc[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
+
+// Adam over param / m / v [G][U] with the gradients in BUCKET-MAJOR layout: bucket k = columns [bound[k], bound[k+1]) of every
+// UNet, stored contiguously as [G][bound[k+1]-bound[k]] at float offset G*bound[k] (one in-place all-reduce per bucket).
+struct adam_buckets { int64_t bound4[9]; int nb; };       // bounds in float4 units
+__global__ void __launch_bounds__(VV_WG)
+adam_bucketed_kernel(const int G, const int64_t U4, const adam_buckets bk, float4* __restrict__ p, const float4* __restrict__ gr,
+                     float4* __restrict__ m, float4* __restrict__ v, const float* __restrict__ sc, const float beta1,
+                     const float beta2, const float eps, const float gscale) {
+  const float step_size = sc[0], bc2_sqrt = sc[1];
+  const int64_t n4 = (int64_t)G * U4;
+  for (int64_t i = (int64_t)blockIdx.x * VV_WG + threadIdx.x; i < n4; i += (int64_t)gridDim.x * VV_WG) {
+    const int64_t g = i / U4, col = i - g * U4;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) k += (q < bk.nb && col >= bk.bound4[q]) ? 1 : 0;
+    const int64_t lo = bk.bound4[k], w = bk.bound4[k + 1] - lo;
+    float4 pv = p[i], gv = gr[(int64_t)G * lo + g * w + (col - lo)], mv = m[i], vv = v[i];
+    float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float gk = gp[q] * gscale;
+      mp[q] = mp[q] + (gk - mp[q]) * (1.f - beta1);
+      vp[q] = fmaf(1.f - beta2, gk * gk, vp[q] * beta2);
+      const float denom = __fsqrt_rn(vp[q]) / bc2_sqrt + eps;
+      pp[q] = pp[q] - step_size * (mp[q] / denom);
+    }
+    p[i] = pv; m[i] = mv; v[i] = vv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ adapters
 __global__ void __launch_bounds__(VV_WG)
 cube_gather_kernel(const int B, const int T, const int Tf, const int HW, const int64_t* __restrict__ idx,
@@ -970,6 +1012,32 @@ extern "C" int vv_adam(int64_t n, float* param, const float* grad, float* m, flo
   VV_LAUNCH(adam_kernel, dim3(nblocks(n4, 4096)), dim3(VV_WG), 0, (hipStream_t)stream, n4, (float4*)param,
                      (const float4*)grad, (float4*)m, (float4*)v, lr / bias_corr1, beta1, beta2, eps, bias_corr2_sqrt,
                      grad_scale);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_adam_tick(int64_t* t_dev, float lr, double beta1, double beta2, float* sc_dev, vv_stream stream) {
+  if (!t_dev || !sc_dev) return VV_ERR_BAD_ARG;
+  VV_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_dev, lr, beta1, beta2, sc_dev);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_adam_bucketed(int32_t G, int64_t U, int32_t nb, const int64_t* bounds, float* param, const float* grad,
+                                float* m, float* v, const float* sc_dev, float beta1, float beta2, float eps, float grad_scale,
+                                vv_stream stream) {
+  if (!param || !grad || !m || !v || !sc_dev || !bounds || (U & 3) || nb < 1 || nb > 8) return VV_ERR_BAD_ARG;
+  adam_buckets bk;
+  bk.nb = nb;
+  for (int k = 0; k <= nb; ++k) {
+    if ((bounds[k] & 3) || (k && bounds[k] <= bounds[k - 1])) return VV_ERR_BAD_ARG;
+    bk.bound4[k] = bounds[k] >> 2;
+  }
+  if (bounds[0] != 0 || bounds[nb] != U) return VV_ERR_BAD_ARG;
+  for (int k = nb + 1; k < 9; ++k) bk.bound4[k] = bk.bound4[nb];
+  const int64_t n4 = (int64_t)G * (U >> 2);
+  VV_LAUNCH(adam_bucketed_kernel, dim3(nblocks(n4, 4096)), dim3(VV_WG), 0, (hipStream_t)stream, G, U >> 2, bk, (float4*)param,
+            (const float4*)grad, (float4*)m, (float4*)v, sc_dev, beta1, beta2, eps, grad_scale);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }

@@ -294,8 +294,10 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     if (jok[j]) {
       const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
       v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
-      ya = __builtin_elementwise_max(ya, (v2f){lo, lo});
-      yb = __builtin_elementwise_max(yb, (v2f){lo, lo});
+      // ReLU of the folded eval path (lo = 0; train mode: lo = -inf, a no-op).  Compare + select, not v_max: v_max_f32 returns the
+      // non-NaN operand, which would turn a diverged model's NaN into 0 / -inf where torch's ReLU propagates it
+      ya[0] = ya[0] < lo ? lo : ya[0]; ya[1] = ya[1] < lo ? lo : ya[1];
+      yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
       const int so = (((img0 + im) * H_ + oy) * H_ + ox) * ocs * 4;
       const float a0 = ya[0], a1v = ya[1], b0 = yb[0], b1 = yb[1];
 #if (VV_EXPM & 8)

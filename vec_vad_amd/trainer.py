@@ -7,7 +7,16 @@ statistics (what DataParallel does), gradients are summed
 backward pass is still running -- and scaled by 1/world inside the fused Adam kernel.  No parameter broadcast per step:
 parameters, BatchNorm buffers and step counters are broadcast from rank 0 ONCE when the trainer is built (DataParallel
 replicates rank 0's module, train.py:375) and the ranks then apply identical updates.
+
+Launch overhead: a train step is ~130 kernel launches through ctypes.  At the reference's per-replica batch sizes (train.py:375 splits
+``batch_size`` over the GPUs: 256 / 8 = 32 cubes, config.cfg's 128 / 8 = 16) the kernels are short and the host loop would set the
+pace, so a step -- cube gather, forward, backward, Adam -- is captured ONCE per (batch size, cube store) into a hipGraph and
+replayed (VV_GRAPH=0 keeps the eager loop).  Everything that varies between steps lives in device memory: the cube indices in
+a static buffer, Adam's step counter and bias corrections in ``bank._adam_sc`` (vv_adam_tick).  With a process group the step
+is captured as segments split where the gradient buckets become final; the collectives are launched eagerly between them.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -24,26 +33,27 @@ def shard_batch(indices, rank, world):
 
 
 class GradBuckets:
-    """Sum-all-reduce of a [G][U] gradient buffer in column buckets.
+    """Sum-all-reduce of the bank's BUCKET-MAJOR gradient buffer, one in-place collective per bucket.
 
-    Bucket k covers columns [bounds[k], bounds[k+1]) of every row.  ``launch(k)`` stages the strided slab into a
-    contiguous buffer and starts the collective on ``comm_stream`` (after everything already queued on the current
-    stream); ``finish()`` makes the current stream wait and scatters the sums back.  Works with any backend
-    (RCCL on the GPU, gloo on CPU tensors for the tests)."""
+    ``grads`` is the flat buffer of UNetBank (bucket k = columns [bounds[k], bounds[k+1]) of every UNet, contiguous as
+    [G][width_k] at float offset G*bounds[k]), so bucket k is the contiguous range ``grads[G*bounds[k] : G*bounds[k+1]]`` and
+    the collective runs on it directly -- no staging copies.  ``launch(k)`` starts the collective on ``comm_stream`` (after
+    everything already queued on the current stream); ``finish()`` makes the current stream wait for all of them.  Works with
+    any backend (RCCL on the GPU, gloo on CPU tensors for the tests)."""
 
-    def __init__(self, grads, bounds, group=None):
+    def __init__(self, grads, G, bounds, group=None):
         import torch.distributed as dist
         self.dist = dist
-        self.grads, self.bounds, self.group = grads, list(bounds), group
+        self.grads, self.G, self.bounds, self.group = grads, int(G), list(bounds), group
         self.cuda = grads.is_cuda
-        self.stage = [torch.empty(grads.shape[0], b - a, device=grads.device, dtype=grads.dtype)
-                      for a, b in zip(self.bounds[:-1], self.bounds[1:])]
+        flat = grads.view(-1)
+        assert flat.numel() == self.G * self.bounds[-1] and self.bounds[0] == 0
+        self.views = [flat[self.G * a:self.G * b] for a, b in zip(self.bounds[:-1], self.bounds[1:])]
         self.comm_stream = torch.cuda.Stream(device=grads.device) if self.cuda else None
         self.pending = []
         self.timing = None          # set to [] to collect (bucket, start event, end event) per collective (bench diagnostics)
 
     def launch(self, k):
-        a, b = self.bounds[k], self.bounds[k + 1]
         if self.cuda:
             ready = torch.cuda.Event()
             ready.record()
@@ -52,28 +62,23 @@ class GradBuckets:
                 if self.timing is not None:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(self.comm_stream)
-                self.stage[k].copy_(self.grads[:, a:b])
-                work = self.dist.all_reduce(self.stage[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = self.dist.all_reduce(self.views[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
                 if self.timing is not None:
                     work.wait()                 # stream-level wait (comm stream): the end event follows the collective
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record(self.comm_stream)
                     self.timing.append((k, e0, e1))
         else:
-            self.stage[k].copy_(self.grads[:, a:b])
-            work = self.dist.all_reduce(self.stage[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = self.dist.all_reduce(self.views[k], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.pending.append((k, work))
 
     def finish(self):
         for k, work in self.pending:
-            a, b = self.bounds[k], self.bounds[k + 1]
             if self.cuda:
                 with torch.cuda.stream(self.comm_stream):
                     work.wait()
-                    self.grads[:, a:b].copy_(self.stage[k])
             else:
                 work.wait()
-                self.grads[:, a:b].copy_(self.stage[k])
         if self.cuda and self.pending:
             torch.cuda.current_stream(self.grads.device).wait_stream(self.comm_stream)
         self.pending = []
@@ -107,7 +112,7 @@ class FusedTrainer:
             # (45 % of the parameters), [c4.w, c8.w) the deep encoder layers (51 %), [0, c4.w) the shallow encoder layers (3 %).
             # Each all-reduce is launched right after the last kernel that writes into its columns and overlaps everything that
             # follows; only the 3 % bucket is exposed at the end of the step.
-            self.buckets = GradBuckets(self.bank.grads, [0, lay.p['c4.w'][0], lay.p['c8.w'][0], lay.U], process_group)
+            self.buckets = GradBuckets(self.bank.grads, self.bank.G, self.bank.gb, process_group)
             self.split_label = 'wgradT_reduce0'   # last launch of the decoder half of the backward plan
             self.split_label_mid = 'wgrad_reduce4'  # last launch that writes gradients of layers 4..7
         self.event_hook = None
@@ -119,6 +124,10 @@ class FusedTrainer:
         # gradient is the next layer's HBM-bound BatchNorm backward; every conv_mfma launch still runs alone.
         self.overlap = overlap
         self.debug_delay = None          # (stream id, cycles): see _run_dual
+        self.use_graph = os.environ.get('VV_GRAPH', '1') != '0'
+        self._graphs = {}                # (kind, B, cube-store pointers) -> 'warm' | _Captured
+        self._graph_pool = None
+        self.comm_timing = None
         self.side = torch.cuda.Stream(device=self.bank.device) if overlap else None
 
     def sync_from_rank0(self, params=True, buffers=True):
@@ -242,8 +251,106 @@ class FusedTrainer:
             e1.record()
             ct.append((e0, e1))
 
+    # ---- hipGraph capture of a whole step
+    def _graph_ok(self):
+        return (self.use_graph and not self.overlap and self.event_hook is None and self.comm_timing is None
+                and (self.buckets is None or self.buckets.timing is None) and self.bank.device.type == 'cuda')
+
+    def _capture(self, segments):
+        """segments: list of (list of thunks taking the raw stream handle, eager callable or None).  Returns [(graph, after)]."""
+        out = []
+        for thunks, after in segments:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):      # RCCL's watchdog thread polls events
+                st = torch.cuda.current_stream(self.bank.device).cuda_stream
+                for t in thunks:
+                    t(st)
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()
+            out.append((g, after))
+        return out
+
+    @staticmethod
+    def _thunk(fn, args, label):
+        def run(st):
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, label)
+        return run
+
+    def _capture_train(self, raw_u8, flow, B):
+        bank, lib = self.bank, self.bank.lib
+        ws = bank.workspace(B)
+        if ws.bwd is None:
+            ws.bwd = bank._plan_backward(ws, B)
+        if bank.adam_m is None:
+            bank.adam_m, bank.adam_v = torch.zeros_like(bank.params), torch.zeros_like(bank.params)
+        idx = torch.zeros(B, dtype=torch.long, device=bank.device)
+        HWp = ws.cube.shape[1]
+        keep = (raw_u8, flow)
+        seg = [self._thunk(lib.vv_cube_gather, (B, bank.tot_raw, bank.tot_of, HWp, idx.data_ptr(), raw_u8.data_ptr(),
+                                                flow.data_ptr() if flow is not None else None, ws.cube.data_ptr(),
+                                                ws.flow.data_ptr()), 'cube_gather')]
+        seg += [self._thunk(*c) for c in ws.fwd[True].calls]
+
+        def nbt(st):           # torch op on the capturing stream: BatchNorm's num_batches_tracked (views of bank.nbt)
+            bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+        seg.append(nbt)
+        segments = []
+        for c in ws.bwd.calls:
+            seg.append(self._thunk(*c))
+            if self.buckets is not None and c[2] in (self.split_label, self.split_label_mid):
+                k = 2 if c[2] == self.split_label else 1
+                segments.append((seg, (lambda k=k: self.buckets.launch(k))))
+                seg = []
+        if self.buckets is not None:
+            segments.append((seg, self._finish_exchange))
+            seg = []
+        b1, b2 = self.betas
+
+        def adam(st):
+            L.check(lib.vv_adam_tick(bank._adam_t_dev.data_ptr(), self.lr, b1, b2, bank._adam_sc.data_ptr(), st), 'adam_tick')
+            L.check(lib.vv_adam_bucketed(bank.G, bank.lay.U, len(bank.gb) - 1, bank._gb_c, bank.params.data_ptr(),
+                                         bank.grads.data_ptr(), bank.adam_m.data_ptr(), bank.adam_v.data_ptr(),
+                                         bank._adam_sc.data_ptr(), b1, b2, self.eps, 1.0 / self.world, st), 'adam')
+        seg.append(adam)
+        segments.append((seg, None))
+        cap = type('Captured', (), {})()
+        cap.ws, cap.idx, cap.keep = ws, idx, keep
+        cap.launches = sum(len(t) for t, _ in segments)
+        cap.segments = self._capture(segments)
+        return cap
+
+    def _step_graphed(self, raw_u8, flow, idx):
+        bank = self.bank
+        B = int(idx.numel())
+        key = ('train', B, raw_u8.data_ptr(), flow.data_ptr() if flow is not None else 0, self.lr, self.eps, self.betas)
+        cap = self._graphs.get(key)
+        if cap is None or cap == 'warm':
+            # the first step of a (batch size, cube store) runs the eager loop: it builds the workspace, the backward plan and the
+            # Adam moments and loads every kernel; the second one captures
+            ws = self._step(bank.set_input_cubes(raw_u8, flow, idx))
+            if cap is None:
+                self._graphs[key] = 'warm'
+                return ws
+            torch.cuda.current_stream(bank.device).synchronize()
+            if len(self._graphs) > 8:
+                self._graphs = {}
+            self._graphs[key] = self._capture_train(raw_u8, flow, B)
+            return ws
+        cap.idx.copy_(idx)
+        for g, after in cap.segments:
+            g.replay()
+            if after is not None:
+                after()
+        bank._adam_t += 1            # host mirror of the device step counter (vv_adam_tick advanced it inside the graph)
+        bank.mark_dirty()
+        return cap.ws
+
     def step_cubes(self, raw_u8, flow, idx):
         """One optimisation step on cubes ``idx`` of a device-resident cube store (uint8 [N,5,32,32,3], fp32 [N,Tf,32,32,2])."""
+        if self._graph_ok() and idx is not None and idx.numel() > 0:
+            return self._step_graphed(raw_u8, flow, idx)
         return self._step(self.bank.set_input_cubes(raw_u8, flow, idx))
 
     def step_cubes_uneven(self, raw_u8, flow, idx, n_global):
@@ -284,9 +391,52 @@ class FusedTrainer:
     @torch.no_grad()
     def score_cubes(self, raw_u8, flow, idx=None, batch=None):
         bank = self.bank
+        if self._graph_ok():
+            return self._score_graphed(raw_u8, flow, idx, batch)
         ws = bank.set_input_cubes(raw_u8, flow, idx, batch)
         bank.forward(ws, False)
         return bank.cube_scores(ws)
+
+    def _score_graphed(self, raw_u8, flow, idx, batch):
+        """Eval-mode scoring of one batch replayed from a hipGraph: cube gather + folded-model forward + the per-cube score sums.
+        The folded model is rebuilt OUTSIDE the graph when the parameters changed (bank.prepare_eval)."""
+        bank, lib = self.bank, self.bank.lib
+        B = int(idx.numel()) if idx is not None else (batch if batch is not None else raw_u8.shape[0])
+        key = ('eval', B, raw_u8.data_ptr(), flow.data_ptr() if flow is not None else 0)
+        cap = self._graphs.get(key)
+        if cap is None or cap == 'warm':
+            ws = bank.set_input_cubes(raw_u8, flow, idx, batch)
+            bank.forward(ws, False)
+            out = bank.cube_scores(ws)
+            if cap is None:
+                self._graphs[key] = 'warm'
+                return out
+            torch.cuda.current_stream(bank.device).synchronize()
+            sidx = torch.arange(B, dtype=torch.long, device=bank.device)
+            HWp = ws.cube.shape[1]
+            seg = [self._thunk(lib.vv_cube_gather, (B, bank.tot_raw, bank.tot_of, HWp, sidx.data_ptr(), raw_u8.data_ptr(),
+                                                    flow.data_ptr() if flow is not None else None, ws.cube.data_ptr(),
+                                                    ws.flow.data_ptr()), 'cube_gather')]
+            seg += [self._thunk(*c) for c in ws.fwd[False].calls]
+            cap = type('Captured', (), {})()
+            cap.ws, cap.idx, cap.keep = ws, sidx, (raw_u8, flow)
+            cap.launches = len(seg)
+            cap.segments = self._capture([(seg, None)])
+            if len(self._graphs) > 8:
+                self._graphs = {}
+            self._graphs[key] = cap
+            return out
+        if bank.eval_fold:
+            bank.prepare_eval()
+        if idx is None:
+            if not getattr(cap, 'identity', False):
+                cap.idx.copy_(torch.arange(B, dtype=torch.long, device=bank.device))
+                cap.identity = True
+        else:
+            cap.idx.copy_(idx)
+            cap.identity = False
+        cap.segments[0][0].replay()
+        return bank.cube_scores(cap.ws)
 
     @torch.no_grad()
     def score_nchw(self, x, x_of):

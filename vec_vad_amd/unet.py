@@ -116,8 +116,7 @@ class _BankFn(torch.autograd.Function):
         out = []
         for (gi, key, p) in model._param_index:
             if bank.g0 <= gi < bank.g0 + bank.Ga:
-                off, shape = bank.lay.p[key]
-                out.append(g[gi, off:off + p.numel()].view(p.shape))
+                out.append(bank.grad_view(gi, key, grads=g, shape=p.shape))      # (the 1x1 output conv is padded to 4 rows in the bank)
             else:
                 out.append(None)
         return (None, None, None, None) + tuple(out)
