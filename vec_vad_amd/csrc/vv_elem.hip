@@ -129,15 +129,17 @@ bn_finalize_kernel(const int C, const int ntiles, const double count, const int 
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
-// dz = (dA [+ maxpool-routed dPool]) * [z > 0]; pass 0 = partial sums of dz and dz*xhat per block of 256 pixels,
-// pass 1 = dy.
+// dz = (dA [+ maxpool-routed dPool]) * [z > 0]; pass 0 = partial sums of dz and dz*xhat per block of bp pixels,
+// pass 1 = dy.  bp = bn_bp(C) = 8192 / C (256 for the 32-channel layers ... 32 for 256 channels): a workgroup's 256 lanes cover
+// 1024 / C pixels per iteration, so every thread runs 8 dependent load rounds whatever the width -- with 256-pixel blocks the
+// 256-channel layers ran 64 rounds on a sixth of the CUs (34 us for 25 MB at B = 256, and the same 33 us at B = 32).
 // PASS 0: only the per-block partial sums of dz and dz*xhat (dz is NOT written);
 // PASS 1: recompute dz the same way and write dy = gamma*invstd*(dz - c1 - xhat*c2) -- one HBM pass less than
 //         materialising dz first and rewriting it.
 template <bool POOL, int PASS>
 __global__ void __launch_bounds__(VV_WG)
-bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __restrict__ gamma, const int64_t param_gstride,
-                     const float* __restrict__ scratch) {
+bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const int bp, const float* __restrict__ gamma,
+                     const int64_t param_gstride, const float* __restrict__ scratch) {
   __shared__ float sh[2][VV_WG * 4];
   const int g = blockIdx.y, blk = blockIdx.x;
   const int C = p.C, Q4 = C >> 2, PL = VV_WG / Q4;
@@ -190,8 +192,8 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
 
   if constexpr (!POOL) {
     // (four pixels' loads in flight per thread: measured -15 % on the apply pass -- not kept)
-    for (int i = pl; i < 256; i += PL) {
-      const int64_t pix = (int64_t)blk * 256 + i;
+    for (int i = pl; i < bp; i += PL) {
+      const int64_t pix = (int64_t)blk * bp + i;
       if (pix < M) one(pix, ldA(pix), ldY(pix));
     }
   } else {
@@ -199,8 +201,8 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const float* __res
     const int H2 = p.H >> 1, W2 = p.W >> 1;
     const int64_t MW = M >> 2;
     const float* __restrict__ dP = p.dpool + (int64_t)g * p.dpool_gstride;
-    for (int i = pl; i < 64; i += PL) {
-      const int64_t wi = (int64_t)blk * 64 + i;
+    for (int i = pl; i < (bp >> 2); i += PL) {
+      const int64_t wi = (int64_t)blk * (bp >> 2) + i;
       if (wi >= MW) continue;
       const int wx = (int)(wi % W2);
       const int64_t t = wi / W2;
@@ -269,8 +271,8 @@ __device__ __forceinline__ uint4 vv_pack_bf16x8(const vv_f8& f) {
 
 template <bool POOL, int PASS>
 __global__ void __launch_bounds__(VV_WG)
-bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const float* __restrict__ gamma, const int64_t param_gstride,
-                const float* __restrict__ scratch) {
+bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const int bp, const float* __restrict__ gamma,
+                const int64_t param_gstride, const float* __restrict__ scratch) {
   __shared__ float sh[2][VV_WG * 8];
   const int g = blockIdx.y, blk = blockIdx.x;
   const int C = p.C, Q8 = C >> 3, PL = VV_WG / Q8;
@@ -310,16 +312,16 @@ bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const float* __restrict
     if constexpr (PASS == 1) *reinterpret_cast<uint4*>(dzh + pix * C + c) = vv_pack_bf16x8(o);
   };
   if constexpr (!POOL) {
-    for (int i = pl; i < 256; i += PL) {
-      const int64_t pix = (int64_t)blk * 256 + i;
+    for (int i = pl; i < bp; i += PL) {
+      const int64_t pix = (int64_t)blk * bp + i;
       if (pix < M) one(pix, ld8(dAh + pix * dcs + c), ld8(yh + pix * C + c));
     }
   } else {
     const int H2 = p.H >> 1, W2 = p.W >> 1;
     const int64_t MW = M >> 2;
     const unsigned short* __restrict__ dPh = reinterpret_cast<const unsigned short*>(p.dpool + (int64_t)g * p.dpool_gstride);
-    for (int i = pl; i < 64; i += PL) {
-      const int64_t wi = (int64_t)blk * 64 + i;
+    for (int i = pl; i < (bp >> 2); i += PL) {
+      const int64_t wi = (int64_t)blk * (bp >> 2) + i;
       if (wi >= MW) continue;
       const int wx = (int)(wi % W2);
       const int64_t t = wi / W2;
@@ -893,10 +895,16 @@ static inline bool bn_all16(const vv_bnbwd_params* p) {
   return (p->flags & all) == all && p->C % 8 == 0 && VV_WG % (p->C / 8) == 0 && p->dA.cstride % 8 == 0 && p->dA.coff % 8 == 0;
 }
 
+static inline int bn_bp(int C) {
+  int bp = 8192 / (C > 0 ? C : 1);
+  bp = bp > 256 ? 256 : (bp < 16 ? 16 : bp);
+  return bp & ~3;                       // whole 2x2 pooling windows
+}
+
 extern "C" int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C) {
-  (void)C;
   const int64_t M = (int64_t)B * H * W;
-  return (int)((M + 255) / 256);
+  const int bp = bn_bp(C);
+  return (int)((M + bp - 1) / bp);
 }
 
 extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
@@ -905,13 +913,13 @@ extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
   const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
   if (bn_all16(p)) {
     if (p->dpool)
-      VV_LAUNCH((bn_bwd16_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
+      VV_LAUNCH((bn_bwd16_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
     else
-      VV_LAUNCH((bn_bwd16_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
+      VV_LAUNCH((bn_bwd16_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
   } else if (p->dpool)
-    VV_LAUNCH((bn_bwd_reduce_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
   else
-    VV_LAUNCH((bn_bwd_reduce_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, nullptr, 0, nullptr);
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -931,13 +939,13 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
   VV_CHECK_LAUNCH();
   if (bn_all16(p)) {
     if (p->dpool)
-      VV_LAUNCH((bn_bwd16_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
+      VV_LAUNCH((bn_bwd16_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
     else
-      VV_LAUNCH((bn_bwd16_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
+      VV_LAUNCH((bn_bwd16_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
   } else if (p->dpool)
-    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
   else
-    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, gamma, param_gstride, scratch);
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }

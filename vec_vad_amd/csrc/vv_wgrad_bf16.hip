@@ -1,13 +1,13 @@
 // Weight gradient of the 3x3 / stride 1 / pad 1 convolution with bf16 operands (mixed precision, BASELINE config 4):
 //     dW[tap][ci][co] = sum_pixels bf16(act[pixel + tap][ci]) * bf16(dy[pixel][co]),   fp32 accumulation
 // on v_mfma_f32_32x32x16_bf16: M = ci, N = co, K = 16 pixels per instruction.  The instruction wants, per lane, 8 consecutive
-// K values (= 8 pixels) of ONE channel, while the tensors are NHWC (channels contiguous).  Instead of transposing through
-// LDS, the staged tiles stay pixel-major ([pixel][32 channels] bf16, 72 B pixel stride -- the forward kernel's layout, written
-// by the same register-staged loader with the producer's BatchNorm+ReLU applied on the way in) and every lane gathers its 8
-// pixels as aligned dwords (lane&31 = channel: two neighbouring lanes share a dword = broadcast, a wave reads 64 contiguous bytes
-// per pixel, lanes 32-63 eight pixels further = the other banks) and picks its half while packing pixel pairs (v_perm_b32 with a
-// per-lane selector).  The three column-shifted operands of one input row share 10 reads; the three row shifts are a sliding
-// window over the rows a wave walks down: 10 + 8 LDS reads and 16 packs per 9 MFMAs.
+// K values (= 8 pixels) of ONE channel, while the tensors are NHWC (channels contiguous).  The staged tiles stay pixel-major
+// ([pixel][32 channels] bf16, 64 B per pixel, written by the register-staged loader with the producer's BatchNorm+ReLU applied on
+// the way in) and the operands come out of LDS already transposed: gfx950's ds_read_b64_tr_b16 lets the 16 lanes of a group
+// address a 4-pixel x 16-channel block (lane 4j+q: pixel j, channels 4q..4q+3) and hands lane l the 4 pixels of channel l, so an
+// operand is two such reads with no VALU work (round 2 gathered dwords and packed pixel pairs with 16 v_perm_b32 per 9 MFMAs:
+// the matrix pipe was busy 0.18-0.27 of the time).  Per-lane addresses are free, so tap shifts are immediate offsets on one base
+// register; the three row shifts are still a sliding window over the rows a wave walks down: 6 + 2 LDS reads per 9 MFMAs.
 //
 // The matrix work is 1/16 of the fp32 instruction's, so this kernel is bound by memory and its first concern is not to re-read:
 // one workgroup stages up to 64 input channels x 64 output channels per pixel tile (each tensor crosses HBM once when the
@@ -24,6 +24,21 @@
 namespace {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char* vv_lds_t;          // byte pointer into LDS
+
+__device__ __forceinline__ vv_lds_t vv_lds_ptr(float* p) { return (vv_lds_t)p; }
+
+// One MFMA operand (8 consecutive K = pixels of this lane's channel) from a pixel-major bf16 tile: two ds_read_b64_tr_b16.
+// Within a 16-lane group, lane 4j+q supplies the address of [pixel j][4 channels 4q..4q+3] (8 B) and lane l receives the 4 pixels
+// of channel l; p already carries the lane's (pixel j, channel quad, 16-channel half) part, o0 / o1 are the byte offsets of the
+// operand's first / second group of 4 pixels (immediates).  Addresses must be 8-byte aligned.
+__device__ __forceinline__ v8bf vv_tr8(const vv_lds_t p, const int o0, const int o1) {
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + o0));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + o1));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(v8bf, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 template <int TH, int TW, int NI, int CB, int OB, bool DY16, bool A16>      // DY16 / A16: dy / the layer input hold bf16 elements
 __global__ void __launch_bounds__(VV_WG, 1)
@@ -32,7 +47,7 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   constexpr int RL = KW == 4 ? 4 : 8;        // rows a wave walks down per strip
   constexpr int NSEG = KW == 1 ? 2 : 1;      // strips per wave
   constexpr int AHH = TH + 2, AHW = TW + 2;
-  constexpr int S = 18, SH = 2 * S;          // pixel stride: 18 floats = 36 bf16 (32 channels + 8 B pad)
+  constexpr int S = 16;                      // pixel stride: 16 floats = 32 bf16 channels, no pad (transpose reads: see vv_tr8)
   constexpr int APX = NI * AHH * AHW, BPX = NI * TH * TW;
   constexpr int ASZ = APX * S, BSZ = BPX * S;
   static_assert(TH * TW * NI == 256, "16 K steps per tile");
@@ -116,13 +131,11 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     }
   };
 
-  // operands are gathered as aligned dwords (two neighbouring lanes = two channels share one: a broadcast, no bank conflict)
-  // and the lane's half is selected while packing pixel pairs: v_perm_b32 with a per-lane selector
-  const unsigned* ldsw = reinterpret_cast<const unsigned*>(lds);
-  const unsigned* xt = ldsw + cb * ASZ + (l31 >> 1);
-  const unsigned* yt = ldsw + CB * ASZ + ob * BSZ + (l31 >> 1);
-  const unsigned sel = (l31 & 1) ? 0x07060302u : 0x05040100u;       // {hi half of b, hi half of a} : {lo half of b, lo half of a}
-  auto pk = [&](const unsigned a, const unsigned b) -> unsigned { return __builtin_amdgcn_perm(b, a, sel); };
+  // transpose-read addressing (vv_tr8): lane 4j+q of a 16-lane group points at pixel j, channels 16*(group&1) + 4q .. +3
+  const int trj = (lane >> 2) & 3;
+  const int trc = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;            // byte offset inside the pixel's 64 B
+  const vv_lds_t xt = vv_lds_ptr(lds + cb * ASZ) + trc;
+  const vv_lds_t yt = vv_lds_ptr(lds + CB * ASZ + ob * BSZ) + trc;
 
   // this workgroup's pixel tiles: ks, ks + KS, ... -- at any moment the workgroups of a launch walk neighbouring tiles
   // (shared halo rows hit in L2, DRAM pages stay open); contiguous ranges per workgroup measured 25 % slower
@@ -137,33 +150,21 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
       // 4x4 level: a lane's 8 pixels are a 2x4 block (rows 2*half, 2*half+1 of image im), a K step is one image.  The nine
       // tap-shifted operands are cut from a 4 x 6 window of the halo tile: 24 reads, 24 packs, no window carried over.
       constexpr int NKS = 16 / KW;
+      // lane's 8 pixels of image im: rows 2*half, 2*half+1 (first / second read), columns j (= its position in the read)
+      const vv_lds_t xp = xt + ((kq * NKS * AHH + 2 * half) * AHW + trj) * 64;       // halo row 2*half (image row 2*half-1), halo column j
+      const vv_lds_t yp = yt + ((kq * NKS * TH + 2 * half) * TW + trj) * 64;
       vv_static_for<0, NKS>([&](auto KK) {
-        const int im = kq * NKS + KK.value;
-        const int r = 2 * half;
-        const unsigned* xp = xt + ((im * AHH + r) * AHW) * S;      // halo row r (image row r-1), halo column 0 (column -1)
-        const unsigned* yp = yt + ((im * TH + r) * TW) * S;
-        unsigned P[4][3][2];
+        constexpr int io = KK.value * AHH * AHW * 64, yo = KK.value * TH * TW * 64;
+        const v8bf bq = vv_tr8(yp, yo, yo + TW * 64);
 #pragma unroll
-        for (int rho = 0; rho < 4; ++rho) {
-          unsigned v[6];
-#pragma unroll
-          for (int j = 0; j < 6; ++j) v[j] = xp[(rho * AHW + j) * S];
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) { P[rho][kx][0] = pk(v[kx], v[kx + 1]); P[rho][kx][1] = pk(v[kx + 2], v[kx + 3]); }
+        for (int ky = 0; ky < 3; ++ky) {
+          const v8bf a0 = vv_tr8(xp, io + (ky * AHW + 0) * 64, io + ((ky + 1) * AHW + 0) * 64);
+          const v8bf a1 = vv_tr8(xp, io + (ky * AHW + 1) * 64, io + ((ky + 1) * AHW + 1) * 64);
+          const v8bf a2 = vv_tr8(xp, io + (ky * AHW + 2) * 64, io + ((ky + 1) * AHW + 2) * 64);
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq, acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq, acc[ky * 3 + 2], 0, 0, 0);
         }
-        unsigned d[8];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[i * 4 + j] = yp[(i * TW + j) * S];
-        const v8bf bq = __builtin_bit_cast(v8bf, (v4u){pk(d[0], d[1]), pk(d[2], d[3]), pk(d[4], d[5]), pk(d[6], d[7])});
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const v4u aq = (v4u){P[ky][kx][0], P[ky][kx][1], P[ky + 1][kx][0], P[ky + 1][kx][1]};
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, aq), bq, acc[ky * 3 + kx], 0, 0, 0);
-          }
       });
     } else {
 #pragma unroll
@@ -176,32 +177,29 @@ wgrad_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
       else if constexpr (TW == 16) { im = 0; rbase = 8 * strip; c0 = 8 * half; }
       else { im = 2 * strip + half; rbase = 0; c0 = 0; }
       const int R = rbase + r0;
-      const unsigned* xp = xt + ((im * AHH + R) * AHW + c0) * S;     // halo row R (image row R-1), halo column c0 (column c0-1)
-      const unsigned* yp = yt + ((im * TH + R) * TW + c0) * S;
-      v4u win[3][3];                                                        // [halo row slot][column shift]
-      auto load_row = [&](const int slot, const int hr) __attribute__((always_inline)) {
-        unsigned v[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = xp[(hr * AHW + j) * S];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          win[slot][dx] = (v4u){pk(v[dx], v[dx + 1]), pk(v[dx + 2], v[dx + 3]), pk(v[dx + 4], v[dx + 5]), pk(v[dx + 6], v[dx + 7])};
-      };
-      load_row(0, 0);
-      load_row(1, 1);
+      // this lane's pixel of a read: halo row R (image row R-1), halo column c0 + j (image column c0 + j - 1); the second read of an
+      // operand is 4 pixels further, tap (ky, kx) and the row walked are immediate offsets
+      const vv_lds_t xp = xt + ((im * AHH + R) * AHW + c0 + trj) * 64;
+      const vv_lds_t yp = yt + ((im * TH + R) * TW + c0 + trj) * 64;
+      v8bf win[3][3];                                                       // [halo row slot][column shift]
+      win[0][0] = vv_tr8(xp, (0 * AHW + 0) * 64, (0 * AHW + 4) * 64);
+      win[0][1] = vv_tr8(xp, (0 * AHW + 1) * 64, (0 * AHW + 5) * 64);
+      win[0][2] = vv_tr8(xp, (0 * AHW + 2) * 64, (0 * AHW + 6) * 64);
+      win[1][0] = vv_tr8(xp, (1 * AHW + 0) * 64, (1 * AHW + 4) * 64);
+      win[1][1] = vv_tr8(xp, (1 * AHW + 1) * 64, (1 * AHW + 5) * 64);
+      win[1][2] = vv_tr8(xp, (1 * AHW + 2) * 64, (1 * AHW + 6) * 64);
       vv_static_for<0, RL>([&](auto KK) {
         constexpr int k = KK.value;
-        load_row((k + 2) % 3, k + 2);
-        unsigned d[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = yp[(k * TW + j) * S];
-        const v8bf bq = __builtin_bit_cast(v8bf, (v4u){pk(d[0], d[1]), pk(d[2], d[3]), pk(d[4], d[5]), pk(d[6], d[7])});
+        constexpr int ro = (k + 2) * AHW * 64;
+        win[(k + 2) % 3][0] = vv_tr8(xp, ro + 0 * 64, ro + 4 * 64);
+        win[(k + 2) % 3][1] = vv_tr8(xp, ro + 1 * 64, ro + 5 * 64);
+        win[(k + 2) % 3][2] = vv_tr8(xp, ro + 2 * 64, ro + 6 * 64);
+        const v8bf bq = vv_tr8(yp, k * TW * 64, (k * TW + 4) * 64);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, win[(k + ky) % 3][kx]), bq,
-                                                                       acc[ky * 3 + kx], 0, 0, 0);
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(win[(k + ky) % 3][kx], bq, acc[ky * 3 + kx], 0, 0, 0);
       });
     }
     }
@@ -251,7 +249,7 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
   constexpr int KW = 4 / (CB * OB);
   constexpr int NKS = 8 / KW;                // K steps per wave and tile
   constexpr int BHH = 2 * TH + 1, BHW = 2 * TW + 1;
-  constexpr int S = 18;
+  constexpr int S = 16;
   constexpr int APX = NI * TH * TW, BPX = NI * BHH * BHW;
   constexpr int ASZ = APX * S, BSZ = BPX * S;
   static_assert(APX == 128, "8 K steps per tile");
@@ -331,11 +329,10 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
     }
   };
 
-  const unsigned* ldsw = reinterpret_cast<const unsigned*>(lds);
-  const unsigned* xt = ldsw + cb * ASZ + (l31 >> 1);
-  const unsigned* yt = ldsw + CB * ASZ + ob * BSZ + (l31 >> 1);
-  const unsigned sel = (l31 & 1) ? 0x07060302u : 0x05040100u;
-  auto pk = [&](const unsigned a, const unsigned b) -> unsigned { return __builtin_amdgcn_perm(b, a, sel); };
+  const int trj = (lane >> 2) & 3;
+  const int trc = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const vv_lds_t xt = vv_lds_ptr(lds + cb * ASZ) + trc;
+  const vv_lds_t yt = vv_lds_ptr(lds + CB * ASZ + ob * BSZ) + trc;
 
   issue(ks);
   for (int pt = ks; pt < NT; pt += KS) {
@@ -346,39 +343,26 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
 
     vv_static_for<0, NKS>([&](auto KK) {
       const int k = kq * NKS + KK.value;          // K step of the tile: 16 pixels, 8 per half-wave
-      // this lane's 8 pixels: image im, rows r .. r+GR-1, columns c0 .. c0+GC-1 (GR x GC = 1x8, or 2x4 on the 4x4 level)
-      constexpr int GR = TW == 4 ? 2 : 1, GC = 8 / GR;
+      // this lane's 8 pixels: image im, rows r .. r+GR-1, columns c0 .. c0+GC-1 (GR x GC = 1x8, or 2x4 on the 4x4 level); its pixel
+      // in a read is column c0 + j (first read) / c0 + 4 + j or the next row (second read)
+      constexpr int GR = TW == 4 ? 2 : 1;
       int im, r, c0;
       if constexpr (TW == 16) { im = 0; r = k; c0 = 8 * half; }
       else if constexpr (TW == 8) { im = half; r = k; c0 = 0; }
       else { im = k; r = 2 * half; c0 = 0; }
-      const unsigned* xp = xt + ((im * TH + r) * TW + c0) * S;
-      const unsigned* yp = yt + ((im * BHH + 2 * r) * BHW + 2 * c0) * S;   // halo row 2r (image row 2r-1), halo column 2c0
-      unsigned xv[8];
-#pragma unroll
-      for (int i = 0; i < GR; ++i)
-#pragma unroll
-        for (int j = 0; j < GC; ++j) xv[i * GC + j] = xp[(i * TW + j) * S];
-      const v8bf aq = __builtin_bit_cast(v8bf, (v4u){pk(xv[0], xv[1]), pk(xv[2], xv[3]), pk(xv[4], xv[5]), pk(xv[6], xv[7])});
+      const vv_lds_t xp = xt + ((im * TH + r) * TW + c0 + trj) * 64;
+      const vv_lds_t yp = yt + ((im * BHH + 2 * r) * BHW + 2 * (c0 + trj)) * 64;   // halo row 2r (image row 2r-1), halo column 2(c0+j)
+      constexpr int X1 = GR == 1 ? 4 * 64 : TW * 64;                 // second read of the un-shifted operand
+      constexpr int Y1 = GR == 1 ? 8 * 64 : 2 * BHW * 64;            // ... of the stride-2 gathered one
+      const v8bf aq = vv_tr8(xp, 0, X1);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        unsigned dv[GR][2 * GC + 1];
-#pragma unroll
-        for (int i = 0; i < GR; ++i)
-#pragma unroll
-          for (int j = 0; j < 2 * GC + 1; ++j) dv[i][j] = yp[((2 * i + ky) * BHW + j) * S];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          v4u bq;
-          if constexpr (GR == 1) {
-            bq = (v4u){pk(dv[0][kx], dv[0][kx + 2]), pk(dv[0][kx + 4], dv[0][kx + 6]), pk(dv[0][kx + 8], dv[0][kx + 10]),
-                       pk(dv[0][kx + 12], dv[0][kx + 14])};
-          } else {
-            bq = (v4u){pk(dv[0][kx], dv[0][kx + 2]), pk(dv[0][kx + 4], dv[0][kx + 6]), pk(dv[GR - 1][kx], dv[GR - 1][kx + 2]),
-                       pk(dv[GR - 1][kx + 4], dv[GR - 1][kx + 6])};
-          }
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, __builtin_bit_cast(v8bf, bq), acc[ky * 3 + kx], 0, 0, 0);
-        }
+        const v8bf b0 = vv_tr8(yp, (ky * BHW + 0) * 64, (ky * BHW + 0) * 64 + Y1);
+        const v8bf b1 = vv_tr8(yp, (ky * BHW + 1) * 64, (ky * BHW + 1) * 64 + Y1);
+        const v8bf b2 = vv_tr8(yp, (ky * BHW + 2) * 64, (ky * BHW + 2) * 64 + Y1);
+        acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, b0, acc[ky * 3 + 0], 0, 0, 0);
+        acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, b1, acc[ky * 3 + 1], 0, 0, 0);
+        acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, b2, acc[ky * 3 + 2], 0, 0, 0);
       }
     });
   }
