@@ -248,7 +248,7 @@ typedef struct vv_outconv_params {
   const float* tgt1; int32_t tgt1_cstride; int32_t pad1;   /* flow NHWC [B,HW,2*T_of] */
   const int32_t* tgt_src;        /* [G] 0: tgt0, 1: tgt1 */
   const int32_t* tgt_coff;       /* [G] first target channel */
-  float* out4;                   /* [G][B*HW][4] reconstruction (channels >= oc are 0) */
+  float* out4;                   /* NULL (fused train / scoring steps: nobody reads it) or [G][B*HW][4] reconstruction (channels >= oc are 0) */
   float* score;                  /* [G][B] */
   const float* gscale;           /* NULL or [G] */
   float* dout4;                  /* NULL or [G][B*HW][4] */

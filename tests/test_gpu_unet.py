@@ -74,6 +74,7 @@ def test_three_train_steps_fused(name, kind, padding, n, rawRange):
     x, x_of = O.cubes_to_inputs(raw, flow)
     net.train()
     tr = FusedTrainer(net)
+    tr.keep_outputs = True          # the reconstructions of step 0 are compared below
     xs, xo = x.cuda(), x_of.cuda()
     losses = []
     for step in range(3):

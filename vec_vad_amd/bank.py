@@ -399,6 +399,10 @@ class UNetBank:
         ws.n_raw, ws.n_of = n_raw, n_of
         ws.fwd = {True: self._plan_forward(ws, B, True),
                   False: self._plan_eval(ws, B) if self.eval_fold else self._plan_forward(ws, B, False)}
+        # the same plans without the reconstruction store (FusedTrainer's train step and scoring pass only read the per-cube scores
+        # and d(loss)/d(out); the module API -- forward() -> outputs_nchw() -- uses ws.fwd)
+        ws.fwdq = {True: self._plan_forward(ws, B, True, out4=False),
+                   False: self._plan_eval(ws, B, out4=False) if self.eval_fold else self._plan_forward(ws, B, False, out4=False)}
         ws.bwd = None
         return ws
 
@@ -420,7 +424,7 @@ class UNetBank:
         return (L.IN_CAT, L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]),
                 L.view(t, t.shape[2], 0, t.stride(0)), s.cout, None)
 
-    def _plan_forward(self, ws, B, train):
+    def _plan_forward(self, ws, B, train, out4=True):
         lib, lay, Ga, g0 = self.lib, self.lay, self.Ga, self.g0
         U, UB, UP = lay.U, lay.UB, lay.UP
         P = _Plan()
@@ -475,7 +479,7 @@ class UNetBank:
         op = L.OutconvParams(Ga, B, HW0 * HW0, self.nf, y.data_ptr(), y.stride(0), self._p(ws.ab[0, last.idx]),
                              self._p(ws.ab[1, last.idx]), abg, pbase + 4 * lay.p['o.w'][0], pbase + 4 * lay.p['o.b'][0], U,
                              self._p(self.oc, g0), ws.cube.data_ptr(), ws.cube.shape[2], 1 if self.y16 else 0, ws.flow.data_ptr(),
-                             ws.flow.shape[2], 0, self._p(self.tsrc, g0), self._p(self.tcoff, g0), ws.out4.data_ptr(),
+                             ws.flow.shape[2], 0, self._p(self.tsrc, g0), self._p(self.tcoff, g0), ws.out4.data_ptr() if out4 else None,
                              ws.score.data_ptr(), ws.gscale.data_ptr() if train else None,
                              ws.dout4.data_ptr() if train else None)
         P.keep.append(op)
@@ -508,7 +512,7 @@ class UNetBank:
                                      self.packed_eval.data_ptr(), lay.UP, self.pack_w_max, st), 'pack_wino (eval)')
         self._eval_key = key
 
-    def _plan_eval(self, ws, B):
+    def _plan_eval(self, ws, B, out4=True):
         """Eval-mode forward on the folded model (see _alloc_state): cube_erase, 14 convs (+3 pools, +3 transposed convs), fused
         1x1 conv + score.  33 launches fewer arithmetic on every load path than the train-mode plan; same tensors otherwise."""
         lib, lay, Ga, g0 = self.lib, self.lay, self.Ga, self.g0
@@ -562,7 +566,7 @@ class UNetBank:
         op = L.OutconvParams(Ga, B, HW0 * HW0, self.nf, y.data_ptr(), y.stride(0), one, zero, abg,
                              pbase + 4 * lay.p['o.w'][0], pbase + 4 * lay.p['o.b'][0], U, self._p(self.oc, g0), ws.cube.data_ptr(),
                              ws.cube.shape[2], 0, ws.flow.data_ptr(), ws.flow.shape[2], 0, self._p(self.tsrc, g0),
-                             self._p(self.tcoff, g0), ws.out4.data_ptr(), ws.score.data_ptr(), None, None)
+                             self._p(self.tcoff, g0), ws.out4.data_ptr() if out4 else None, ws.score.data_ptr(), None, None)
         P.keep.append(op)
         P.add(lib.vv_outconv_fwd, (C.byref(op),), 'outconv')
         return P
@@ -800,11 +804,12 @@ class UNetBank:
                                         ws.flow.data_ptr(), self._stream()), 'cube_gather')
         return ws
 
-    def forward(self, ws, train):
-        """Runs the grouped forward.  train=True: batch statistics, running-stat update, dout4 = d(loss)/d(out)."""
+    def forward(self, ws, train, outputs=True):
+        """Runs the grouped forward.  train=True: batch statistics, running-stat update, dout4 = d(loss)/d(out).
+        outputs=False: only the per-cube scores (and dout4) are needed -- the reconstruction ws.out4 is not written."""
         if not train and self.eval_fold:
             self.prepare_eval()
-        ws.fwd[bool(train)].run(self._stream())
+        (ws.fwd if outputs else ws.fwdq)[bool(train)].run(self._stream())
         if train:
             self.nbt[self.g0:self.g0 + self.Ga] += 1
             self.mark_dirty()
@@ -890,7 +895,7 @@ class UNetBank:
 
     def train_step(self, ws, lr=1e-3, eps=1e-7, grad_scale=1.0, allreduce=None):
         """Fused fast path: forward (train) -> backward -> [gradient all-reduce] -> Adam.  No host sync."""
-        self.forward(ws, True)
+        self.forward(ws, True, outputs=False)
         self.backward(ws)
         if allreduce is not None:
             allreduce(self.grads)

@@ -7,48 +7,55 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ pack
+// One workgroup = one tile of 8 K values x 32 N values x 9 taps, staged through LDS: the source is read as contiguous runs (72
+// floats per n when the filter tensor is n-major -- modes 0 / 3 --, 288 floats per k when it is k-major -- modes 1 / 2) and every
+// tap leaves as contiguous 512-byte runs of the panel.  (Round 2 gathered single floats at a 36-byte stride straight from global
+// memory: 547 MB of HBM reads for 86 MB of weights in the 10-UNet bank, 119 us per step.)
 __global__ void __launch_bounds__(VV_WG)
 pack_weights_kernel(const vv_pack_entry* __restrict__ table, const float* __restrict__ params,
                     const int64_t params_gstride, float* __restrict__ packed, const int64_t packed_gstride) {
+  __shared__ float tile[8 * 32 * 9 + 8];
   const vv_pack_entry e = table[blockIdx.y];
   const int g = blockIdx.z;
-  const int total = 9 * e.KP * e.N;
   const float* src = params + (int64_t)g * params_gstride + e.src_off;
   float* dst = packed + (int64_t)g * packed_gstride + e.dst_off;
-  const int KQ = e.KP >> 3;
   const bool b16 = (e.mode & 4) != 0;        // bf16 panel [tap][KP/16][2][N][8] for the bf16-operand kernels (K step = 16 channels)
-  for (int d = blockIdx.x * VV_WG + threadIdx.x; d < total; d += gridDim.x * VV_WG) {
-    int n, tap, k;
-    if (b16) {
-      const int e8 = d & 7;
-      int t = d >> 3;
-      n = t % e.N; t /= e.N;
-      const int half = t & 1; t >>= 1;
-      const int ks = t % (e.KP >> 4);
-      tap = t / (e.KP >> 4);
-      k = ks * 16 + half * 8 + e8;
-    } else {
-      const int j = d & 3;
-      int t = d >> 2;
-      n = t % e.N; t /= e.N;
-      const int half = t & 1; t >>= 1;
-      const int kq = t % KQ;
-      tap = t / KQ;
-      k = kq * 8 + half * 4 + j;
-    }
-    float v = 0.f;
-    if (k < e.K) {
+  const int m = e.mode & 3;
+  const bool kmajor = m == 1 || m == 2;      // source index (k * N + n) * 9 + tap'  (else (n * K + k) * 9 + tap)
+  const bool flip = m == 1;                  // data gradient: spatially flipped filter
+  const int NB = e.N >> 5, KB = e.KP >> 3;
+  const int tid = threadIdx.x;
+  for (int blk = blockIdx.x; blk < KB * NB; blk += gridDim.x) {
+    const int kb = blk / NB, nb = blk % NB;
+    const int k0 = kb * 8, n0 = nb * 32;
+    __syncthreads();                         // the previous tile has been written out
+    // the tile is kept in source order (linear, conflict-free stores); the write phase gathers (tap, k, n) from it
+    for (int i = tid; i < 8 * 32 * 9; i += VV_WG) {
       int64_t si;
-      switch (e.mode & 3) {
-        case 0: si = ((int64_t)n * e.K + k) * 9 + tap; break;          // W[co=n][ci=k][tap]
-        case 1: si = ((int64_t)k * e.N + n) * 9 + (8 - tap); break;    // W[co=k][ci=n][flipped tap]
-        case 2: si = ((int64_t)k * e.N + n) * 9 + tap; break;          // Wt[ci=k][co=n][tap]
-        default: si = ((int64_t)n * e.K + k) * 9 + tap; break;         // Wt[ci=n][co=k][tap]
-      }
-      v = src[si];
+      bool ok;
+      if (kmajor) { const int kk = i / 288; si = ((int64_t)(k0 + kk) * e.N + n0) * 9 + (i % 288); ok = k0 + kk < e.K; }
+      else { const int nn = i / 72, r = i % 72; si = ((int64_t)(n0 + nn) * e.K + k0) * 9 + r; ok = k0 + r / 9 < e.K; }
+      tile[i] = ok ? src[si] : 0.f;
     }
-    if (b16) reinterpret_cast<__bf16*>(dst)[d] = (__bf16)v;
-    else dst[d] = v;
+    __syncthreads();
+    auto at = [&](const int tap, const int kk, const int nn) -> float {
+      return kmajor ? tile[kk * 288 + nn * 9 + (flip ? 8 - tap : tap)] : tile[nn * 72 + kk * 9 + tap];
+    };
+    if (b16) {
+      // k = ks*16 + half*8 + e8: this tile is one (ks, half); per tap 32 n x 8 e8 bf16 = 512 contiguous bytes
+      const int ks = kb >> 1, half = kb & 1;
+      __bf16* d16 = reinterpret_cast<__bf16*>(dst);
+      for (int i = tid; i < 9 * 256; i += VV_WG) {
+        const int tap = i >> 8, r = i & 255, nn = r >> 3, e8 = r & 7;
+        d16[((((int64_t)tap * (e.KP >> 4) + ks) * 2 + half) * e.N + n0 + nn) * 8 + e8] = (__bf16)at(tap, e8, nn);
+      }
+    } else {
+      // k = kq*8 + half*4 + j: this tile is one kq, both halves; per (tap, half) 32 n x 4 j floats = 512 contiguous bytes
+      for (int i = tid; i < 9 * 256; i += VV_WG) {
+        const int tap = i >> 8, r = i & 255, half = r >> 7, nn = (r >> 2) & 31, j = r & 3;
+        dst[((((int64_t)tap * KB + kb) * 2 + half) * e.N + n0 + nn) * 4 + j] = at(tap, half * 4 + j, nn);
+      }
+    }
   }
 }
 
@@ -190,10 +197,14 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const int bp, cons
     }
   };
 
+  const int64_t nchunks = (M + bp - 1) / bp;
+  // persistent workgroups: nblk (<= VV_BN_MAXBLK per UNet) of them walk the chunks blk, blk + nblk, ... -- the per-channel
+  // constants are loaded once per workgroup instead of once per 256 pixels, and neighbouring workgroups stream neighbouring memory
+  for (int64_t chunk = blk; chunk < nchunks; chunk += nblk) {
   if constexpr (!POOL) {
-    // (four pixels' loads in flight per thread: measured -15 % on the apply pass -- not kept)
+    // (four pixels' loads in flight per thread: measured -15 % on the apply pass in round 2 and again in round 3 -- not kept)
     for (int i = pl; i < bp; i += PL) {
-      const int64_t pix = (int64_t)blk * bp + i;
+      const int64_t pix = chunk * bp + i;
       if (pix < M) one(pix, ldA(pix), ldY(pix));
     }
   } else {
@@ -202,7 +213,7 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const int bp, cons
     const int64_t MW = M >> 2;
     const float* __restrict__ dP = p.dpool + (int64_t)g * p.dpool_gstride;
     for (int i = pl; i < (bp >> 2); i += PL) {
-      const int64_t wi = (int64_t)blk * (bp >> 2) + i;
+      const int64_t wi = chunk * (bp >> 2) + i;
       if (wi >= MW) continue;
       const int wx = (int)(wi % W2);
       const int64_t t = wi / W2;
@@ -236,6 +247,7 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const int bp, cons
       }
     }
   }
+  }      // chunk loop
   if constexpr (PASS == 1) return;
   // block reduction over the PL pixel lanes in fixed order
   float* r1 = sh[0];
@@ -285,18 +297,19 @@ bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const int bp, const flo
   const int dcs = p.dA.cstride;
   const int64_t abo = (int64_t)g * p.ab_gstride + c;
   float a[8], b[8], m[8], iv[8], s1[8], s2[8], gk[8], c1[8], c2[8];
+  auto ld8f = [](const float* q, float* o) {          // 8 consecutive floats, 16-byte aligned: two 16-byte loads
+    const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+  };
+  ld8f(p.a + abo, a); ld8f(p.b + abo, b); ld8f(p.mean + abo, m); ld8f(p.invstd + abo, iv);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    a[j] = p.a[abo + j]; b[j] = p.b[abo + j]; m[j] = p.mean[abo + j]; iv[j] = p.invstd[abo + j];
-    s1[j] = 0.f; s2[j] = 0.f; gk[j] = 0.f; c1[j] = 0.f; c2[j] = 0.f;
-  }
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; gk[j] = 0.f; c1[j] = 0.f; c2[j] = 0.f; }
   if constexpr (PASS == 1) {
+    ld8f(gamma + (int64_t)g * param_gstride + c, gk);
+    ld8f(scratch + (int64_t)g * 2 * C + c, c1);
+    ld8f(scratch + (int64_t)g * 2 * C + C + c, c2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      gk[j] = gamma[(int64_t)g * param_gstride + c + j] * iv[j];
-      c1[j] = scratch[(int64_t)g * 2 * C + c + j];
-      c2[j] = scratch[(int64_t)g * 2 * C + C + c + j];
-    }
+    for (int j = 0; j < 8; ++j) gk[j] *= iv[j];
   }
   auto ld8 = [&](const unsigned short* q8) -> vv_f8 { return vv_unpack_bf16x8(*reinterpret_cast<const uint4*>(q8)); };
   auto one = [&](const int64_t pix, vv_f8 d, const vv_f8& yv) {
@@ -311,17 +324,32 @@ bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const int bp, const flo
     }
     if constexpr (PASS == 1) *reinterpret_cast<uint4*>(dzh + pix * C + c) = vv_pack_bf16x8(o);
   };
+  const int64_t nchunks = (M + bp - 1) / bp;
+  for (int64_t chunk = blk; chunk < nchunks; chunk += nblk) {       // persistent workgroups, see bn_bwd_reduce_kernel
   if constexpr (!POOL) {
-    for (int i = pl; i < bp; i += PL) {
-      const int64_t pix = (int64_t)blk * bp + i;
-      if (pix < M) one(pix, ld8(dAh + pix * dcs + c), ld8(yh + pix * C + c));
+    // bp = 4 * PL for every channel count the bank has (bn_bp): each thread owns four pixels; all eight 16-byte loads are issued
+    // before the first use (one pixel at a time made every workgroup a chain of four HBM round trips)
+    for (int i0 = pl; i0 < bp; i0 += 4 * PL) {
+      uint4 qa[4], qy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pix = chunk * bp + i0 + u * PL;
+        const bool ok = i0 + u * PL < bp && pix < M;
+        qa[u] = ok ? *reinterpret_cast<const uint4*>(dAh + pix * dcs + c) : make_uint4(0, 0, 0, 0);
+        qy[u] = ok ? *reinterpret_cast<const uint4*>(yh + pix * C + c) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pix = chunk * bp + i0 + u * PL;
+        if (i0 + u * PL < bp && pix < M) one(pix, vv_unpack_bf16x8(qa[u]), vv_unpack_bf16x8(qy[u]));
+      }
     }
   } else {
     const int H2 = p.H >> 1, W2 = p.W >> 1;
     const int64_t MW = M >> 2;
     const unsigned short* __restrict__ dPh = reinterpret_cast<const unsigned short*>(p.dpool + (int64_t)g * p.dpool_gstride);
     for (int i = pl; i < (bp >> 2); i += PL) {
-      const int64_t wi = (int64_t)blk * (bp >> 2) + i;
+      const int64_t wi = chunk * (bp >> 2) + i;
       if (wi >= MW) continue;
       const int wx = (int)(wi % W2);
       const int64_t t = wi / W2;
@@ -351,6 +379,7 @@ bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const int bp, const flo
       }
     }
   }
+  }      // chunk loop
   if constexpr (PASS == 1) return;
   float* r1 = sh[0];
   float* r2 = sh[1];
@@ -398,10 +427,14 @@ bn_bwd_sum_kernel(const int C, const int nblk, const double M, const float* __re
 // 32 in every shipped config.cfg, 64 = the default of SelfCompleteNet1raw1of, model/unet.py:563).
 template <int CC>
 __global__ void __launch_bounds__(VV_WG)
-outconv_fwd_kernel(const vv_outconv_params p) {
+outconv_fwd_kernel(const vv_outconv_params p, const int total, const int nper) {
   constexpr int LPP = CC / 4, NPG = VV_WG / LPP;
   __shared__ float red[4];
-  const int g = blockIdx.y, cube = blockIdx.x;
+  // work item = (cube, UNet), the G UNets of a cube adjacent in one XCD's chunk of the list: they read the same target pixels
+  // (3 of the cube's 15 channels / 2 of the flow's each), which then cross HBM once instead of once per UNet
+  const int wi = vv_xcd_remap(blockIdx.x, nper);
+  if (wi >= total) return;
+  const int g = wi % p.G, cube = wi / p.G;
   const int tid = threadIdx.x, sub = tid % LPP, pg = tid / LPP;
   const int c = sub * 4;
   const int C = CC, oc = p.oc[g];
@@ -433,7 +466,20 @@ outconv_fwd_kernel(const vv_outconv_params p) {
     return (p.pad0 & 1) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c))
                         : *reinterpret_cast<const float4*>(y + pix * C + c);      // pad0 bit 0: y holds bf16 elements
   };
-  auto body = [&](const int i, const float4 yq) {
+  // the target pixel (3 / 2 floats) of lane sub == 0, loaded with the batch: read inside the body it sat behind the previous
+  // pixel group's stores, one exposed HBM round trip per body (32 per wave and cube)
+  auto ldt = [&](const int i) -> float4 {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sub == 0) {
+      const float* q = tgt + ((int64_t)cube * p.HW + i) * tcs + tco;
+      t.x = q[0];
+      if (oc > 1) t.y = q[1];
+      if (oc > 2) t.z = q[2];
+      if (oc > 3) t.w = q[3];
+    }
+    return t;
+  };
+  auto body = [&](const int i, const float4 yq, const float4 tq) {
     const int64_t pix = (int64_t)cube * p.HW + i;
     const float4 v = vv_act4(yq, a4, b4);
     float o[4];
@@ -448,16 +494,17 @@ outconv_fwd_kernel(const vv_outconv_params p) {
     if (sub == 0) {
       float4 ov = make_float4(0, 0, 0, 0), dv = make_float4(0, 0, 0, 0);
       float e[4] = {0, 0, 0, 0};
+      const float tv[4] = {tq.x, tq.y, tq.z, tq.w};
 #pragma unroll
       for (int co = 0; co < 4; ++co)
         if (co < oc) {
-          e[co] = o[co] - tgt[pix * tcs + tco + co];
+          e[co] = o[co] - tv[co];
           sse = fmaf(e[co], e[co], sse);
         } else {
           o[co] = 0.f;
         }
       ov = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(p.out4 + ((int64_t)g * MB + pix) * 4) = ov;
+      if (p.out4) *reinterpret_cast<float4*>(p.out4 + ((int64_t)g * MB + pix) * 4) = ov;      // NULL: nobody reads the reconstruction (fused train / scoring steps)
       if (p.dout4) {
         dv = make_float4(gs * e[0], gs * e[1], gs * e[2], gs * e[3]);
         *reinterpret_cast<float4*>(p.dout4 + ((int64_t)g * MB + pix) * 4) = dv;
@@ -465,13 +512,13 @@ outconv_fwd_kernel(const vv_outconv_params p) {
     }
   };
   for (int i0 = pg; i0 < p.HW; i0 += 4 * NPG) {
-    float4 yq4[4];
+    float4 yq4[4], tq4[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (i0 + u * NPG < p.HW) yq4[u] = ldy(i0 + u * NPG);
+      if (i0 + u * NPG < p.HW) { yq4[u] = ldy(i0 + u * NPG); tq4[u] = ldt(i0 + u * NPG); }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (i0 + u * NPG < p.HW) body(i0 + u * NPG, yq4[u]);
+      if (i0 + u * NPG < p.HW) body(i0 + u * NPG, yq4[u], tq4[u]);
   }
   // block reduce sse (only sub==0 lanes hold data): wave reduce then 4 waves
 #pragma unroll
@@ -838,23 +885,30 @@ pool_act_kernel(const int64_t n4, const int C, const int H2, const int W2, const
 
 // frame erasure: out[g][pixel][k] = chmap[g][k] >= 0 ? cube[pixel][chmap[g][k]] : 0   (model/unet.py:178-183)
 __global__ void __launch_bounds__(VV_WG)
-cube_erase_kernel(const int64_t npix, const int Cc, const int CP, const float* __restrict__ cube, const int* __restrict__ chmap,
-                  float* __restrict__ out, const int64_t out_gstride, const int out16) {
-  // one thread per float4 of the output (CP / 4 threads per pixel): a wave writes 1 KB contiguous; the 3-4 source channels of a
-  // group come through L1 (the pixel's 60 bytes are read by its CP / 4 neighbours)
-  const int g = blockIdx.y;
+cube_erase_kernel(const int G, const int64_t npix, const int Cc, const int CP, const float* __restrict__ cube,
+                  const int* __restrict__ chmap, float* __restrict__ out, const int64_t out_gstride, const int out16) {
+  // one thread per float4 of an output pixel (CP / 4 threads per pixel) for ALL G UNets: the pixel's 60 bytes are read once
+  // (through L1 by its CP / 4 neighbours) and feed G stores, each wave writing 0.5 / 1 KB contiguous per UNet
   const int Q = CP >> 2;
   const int64_t t = (int64_t)blockIdx.x * VV_WG + threadIdx.x;
   const int64_t e = t / Q;
   const int k = (int)(t % Q) * 4;
   if (e >= npix) return;
   const float* q = cube + e * Cc;
-  const int* m = chmap + (int64_t)g * CP;
-  const int m0 = m[k], m1 = m[k + 1], m2 = m[k + 2], m3 = m[k + 3];
-  float4 v;
-  v.x = m0 >= 0 ? q[m0] : 0.f; v.y = m1 >= 0 ? q[m1] : 0.f; v.z = m2 >= 0 ? q[m2] : 0.f; v.w = m3 >= 0 ? q[m3] : 0.f;
-  if (out16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out + (int64_t)g * out_gstride) + e * CP + k) = vv_pack_bf16x4(v);
-  else *reinterpret_cast<float4*>(out + (int64_t)g * out_gstride + e * CP + k) = v;
+  float src[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) src[i] = i < Cc ? q[i] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    const int* m = chmap + (int64_t)g * CP;
+    const int m0 = m[k], m1 = m[k + 1], m2 = m[k + 2], m3 = m[k + 3];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {          // register-resident select (a dynamic index would spill the pixel to scratch)
+      v.x = m0 == i ? src[i] : v.x; v.y = m1 == i ? src[i] : v.y; v.z = m2 == i ? src[i] : v.z; v.w = m3 == i ? src[i] : v.w;
+    }
+    if (out16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out + (int64_t)g * out_gstride) + e * CP + k) = vv_pack_bf16x4(v);
+    else *reinterpret_cast<float4*>(out + (int64_t)g * out_gstride + e * CP + k) = v;
+  }
 }
 
 inline int nblocks(int64_t n, int cap = 1 << 20) {
@@ -901,10 +955,15 @@ static inline int bn_bp(int C) {
   return bp & ~3;                       // whole 2x2 pooling windows
 }
 
+// workgroups (= partial-sum blocks) per UNet: one per chunk of bn_bp(C) pixels, at most VV_BN_MAXBLK persistent ones.  Measured
+// with 256 persistent workgroups per UNet: the passes over the 32x32 tensors already run at 5.5-6 TB/s with one chunk per
+// workgroup and lost 10-15 % in fp32 -- the cap is therefore far above any chunk count the bank produces.
+constexpr int VV_BN_MAXBLK = 1 << 20;
 extern "C" int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C) {
   const int64_t M = (int64_t)B * H * W;
   const int bp = bn_bp(C);
-  return (int)((M + bp - 1) / bp);
+  const int64_t n = (M + bp - 1) / bp;
+  return (int)(n < VV_BN_MAXBLK ? n : VV_BN_MAXBLK);
 }
 
 extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
@@ -951,11 +1010,11 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
 }
 
 extern "C" int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream) {
-  if (!p || !p->y || !p->a || !p->b || !p->w || !p->bias || !p->oc || !p->tgt_src || !p->tgt_coff || !p->out4 ||
-      !p->score || !p->tgt0)
+  if (!p || !p->y || !p->a || !p->b || !p->w || !p->bias || !p->oc || !p->tgt_src || !p->tgt_coff || !p->score || !p->tgt0)
     return VV_ERR_BAD_ARG;
-  if (p->C == 32) VV_LAUNCH(outconv_fwd_kernel<32>, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
-  else if (p->C == 64) VV_LAUNCH(outconv_fwd_kernel<64>, dim3(p->B, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p);
+  const int total = p->B * p->G, nper = (total + 7) / 8;
+  if (p->C == 32) VV_LAUNCH(outconv_fwd_kernel<32>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, total, nper);
+  else if (p->C == 64) VV_LAUNCH(outconv_fwd_kernel<64>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, total, nper);
   else return VV_ERR_UNSUPPORTED;      /* features_root 32 (every shipped config) or 64 (SelfCompleteNet1raw1of's default) */
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -1096,8 +1155,8 @@ extern "C" int vv_pool_act(int32_t G, int32_t B, int32_t H2, int32_t W2, int32_t
 
 extern "C" int vv_cube_erase(int32_t G, int64_t npix, int32_t Cc, int32_t CP, const float* cube, const int32_t* chmap,
                              float* out, int64_t out_gstride, int32_t out_bf16, vv_stream stream) {
-  if (!cube || !chmap || !out || CP % 4) return VV_ERR_BAD_ARG;
-  VV_LAUNCH(cube_erase_kernel, dim3(nblocks(npix * (CP / 4)), G), dim3(VV_WG), 0, (hipStream_t)stream, npix, Cc, CP, cube, chmap, out,
+  if (!cube || !chmap || !out || CP % 4 || Cc > 16) return VV_ERR_BAD_ARG;      // (15 channels: 5 frames x RGB, vad_datasets.py:159)
+  VV_LAUNCH(cube_erase_kernel, dim3(nblocks(npix * (CP / 4))), dim3(VV_WG), 0, (hipStream_t)stream, G, npix, Cc, CP, cube, chmap, out,
             out_gstride, out_bf16);
   VV_CHECK_LAUNCH();
   return VV_OK;

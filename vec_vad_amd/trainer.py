@@ -128,6 +128,9 @@ class FusedTrainer:
         self._graphs = {}                # (kind, B, cube-store pointers) -> 'warm' | _Captured
         self._graph_pool = None
         self.comm_timing = None
+        # True: the train step also stores the reconstructions (bank.outputs_nchw(ws) after a step); the reference's loop only uses the
+        # losses (train.py:385-399), so by default the fused step skips that store
+        self.keep_outputs = False
         self.side = torch.cuda.Stream(device=self.bank.device) if overlap else None
 
     def sync_from_rank0(self, params=True, buffers=True):
@@ -204,7 +207,7 @@ class FusedTrainer:
     def _step(self, ws):
         bank = self.bank
         stream = bank._stream()
-        self._run(ws.fwd[True], stream)
+        self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], stream)
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
         bank.mark_dirty()
         if ws.bwd is None:
@@ -291,7 +294,7 @@ class FusedTrainer:
         seg = [self._thunk(lib.vv_cube_gather, (B, bank.tot_raw, bank.tot_of, HWp, idx.data_ptr(), raw_u8.data_ptr(),
                                                 flow.data_ptr() if flow is not None else None, ws.cube.data_ptr(),
                                                 ws.flow.data_ptr()), 'cube_gather')]
-        seg += [self._thunk(*c) for c in ws.fwd[True].calls]
+        seg += [self._thunk(*c) for c in (ws.fwd if self.keep_outputs else ws.fwdq)[True].calls]
 
         def nbt(st):           # torch op on the capturing stream: BatchNorm's num_batches_tracked (views of bank.nbt)
             bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
@@ -324,7 +327,7 @@ class FusedTrainer:
     def _step_graphed(self, raw_u8, flow, idx):
         bank = self.bank
         B = int(idx.numel())
-        key = ('train', B, raw_u8.data_ptr(), flow.data_ptr() if flow is not None else 0, self.lr, self.eps, self.betas)
+        key = ('train', B, raw_u8.data_ptr(), flow.data_ptr() if flow is not None else 0, self.lr, self.eps, self.betas, self.keep_outputs)
         cap = self._graphs.get(key)
         if cap is None or cap == 'warm':
             # the first step of a (batch size, cube store) runs the eager loop: it builds the workspace, the backward plan and the
@@ -366,7 +369,7 @@ class FusedTrainer:
         ws = None
         if b:
             ws = bank.set_input_cubes(raw_u8, flow, idx)
-            self._run(ws.fwd[True], bank._stream())
+            self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], bank._stream())
             bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
             bank.mark_dirty()
             if ws.bwd is None:
@@ -394,7 +397,7 @@ class FusedTrainer:
         if self._graph_ok():
             return self._score_graphed(raw_u8, flow, idx, batch)
         ws = bank.set_input_cubes(raw_u8, flow, idx, batch)
-        bank.forward(ws, False)
+        bank.forward(ws, False, outputs=False)
         return bank.cube_scores(ws)
 
     def _score_graphed(self, raw_u8, flow, idx, batch):
@@ -406,7 +409,7 @@ class FusedTrainer:
         cap = self._graphs.get(key)
         if cap is None or cap == 'warm':
             ws = bank.set_input_cubes(raw_u8, flow, idx, batch)
-            bank.forward(ws, False)
+            bank.forward(ws, False, outputs=False)
             out = bank.cube_scores(ws)
             if cap is None:
                 self._graphs[key] = 'warm'
@@ -417,7 +420,7 @@ class FusedTrainer:
             seg = [self._thunk(lib.vv_cube_gather, (B, bank.tot_raw, bank.tot_of, HWp, sidx.data_ptr(), raw_u8.data_ptr(),
                                                     flow.data_ptr() if flow is not None else None, ws.cube.data_ptr(),
                                                     ws.flow.data_ptr()), 'cube_gather')]
-            seg += [self._thunk(*c) for c in ws.fwd[False].calls]
+            seg += [self._thunk(*c) for c in ws.fwdq[False].calls]
             cap = type('Captured', (), {})()
             cap.ws, cap.idx, cap.keep = ws, sidx, (raw_u8, flow)
             cap.launches = len(seg)
@@ -442,5 +445,5 @@ class FusedTrainer:
     def score_nchw(self, x, x_of):
         bank = self.bank
         ws = bank.set_input_nchw(x, x_of)
-        bank.forward(ws, False)
+        bank.forward(ws, False, outputs=False)
         return bank.cube_scores(ws)
