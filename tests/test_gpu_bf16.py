@@ -137,11 +137,14 @@ def test_bf16_transposed_conv_data_gradient(H, Cin, Cout, B):
 @pytest.mark.parametrize('H,Cin,CinP,Cout,B,ks', [(32, 12, 16, 32, 2, 3), (32, 32, 32, 32, 3, 1), (32, 64, 64, 32, 2, 5), (32, 32, 32, 64, 1, 2),
                                                  (16, 64, 64, 64, 5, 4), (16, 128, 128, 64, 2, 1), (8, 128, 128, 128, 9, 2),
                                                  (8, 256, 256, 128, 3, 1), (4, 128, 128, 256, 33, 2), (4, 256, 256, 256, 16, 1), (4, 32, 32, 32, 5, 1)])
-def test_bf16_weight_gradient_matches_rounded_operand_reference(H, Cin, CinP, Cout, B, ks):
+@pytest.mark.parametrize('stored16', [False, True])
+def test_bf16_weight_gradient_matches_rounded_operand_reference(H, Cin, CinP, Cout, B, ks, stored16):
     """vv_wgrad_bf16 (+ vv_wgrad_reduce into the nn.Conv2d weight layout) against the float64 weight gradient of the
     bf16-rounded operands -- every (ci-blocks, co-blocks) workgroup shape (1x1, 2x1, 1x2, 2x2 blocks of 32 channels), ragged
     batch (images per tile do not divide B), zero-padded input channels, k-split > 1: <= 2e-4 of the tensor maximum; the
-    unrounded operands are measurably somewhere else; two runs are bitwise identical."""
+    unrounded operands are measurably somewhere else; two runs are bitwise identical.
+    stored16: the layer input and dy are bf16 TENSORS (what the mixed-precision bank stores, BASELINE config 4) -- the LDS-ring kernel
+    (global -> LDS DMA three tiles deep, BatchNorm+ReLU applied in place in LDS); the same bars."""
     from vec_vad_amd import _lib as L
     lib = L.lib()
     G = 2
@@ -150,21 +153,28 @@ def test_bf16_weight_gradient_matches_rounded_operand_reference(H, Cin, CinP, Co
     x[:, :, Cin:] = 0
     x = x.cuda()
     dy = torch.randn(G, B * H * H, Cout, generator=g).cuda()
+    flags = 0
+    xs, dys, esz = x, dy, 1
+    if stored16:
+        flags = L.WGRAD_DY_BF16 | L.WGRAD_X_BF16
+        xs, dys = x.to(torch.bfloat16), dy.to(torch.bfloat16)
+        x, dy = xs.float(), dys.float()          # the values the kernel sees
+        esz = 2                                  # strides are given in fp32 units of the same buffer layout
     a = (torch.rand(G, CinP, generator=g) + 0.5).cuda()
     b = (torch.randn(G, CinP, generator=g) * 0.2).cuda()
     if CinP != Cin:
         b[:, Cin:] = 0
     st = torch.cuda.current_stream().cuda_stream
     nt, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
-    assert lib.vv_wgrad_bf16_plan(L.CONV3, B, H, H, CinP, Cout, C.byref(nt), C.byref(nblk), C.byref(kw)) == 1
+    assert lib.vv_wgrad_bf16_plan(L.CONV3 | (flags << 8), B, H, H, CinP, Cout, C.byref(nt), C.byref(nblk), C.byref(kw)) == 1
     ks = min(ks, nt.value)
     nci, nco = (CinP + 31) // 32, Cout // 32
     outs = []
     for rep in range(2):
         part = torch.full((G, nci * nco * ks * kw.value * 9 * 1024), 7.0, device='cuda')
         grad = torch.zeros(G, Cout * Cin * 9, device='cuda')
-        wp = L.WgradParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, CinP, Cout, ks, L.view(x, CinP, 0, x.stride(0)), a.data_ptr(), b.data_ptr(),
-                           CinP, L.NULL_VIEW, 0, 0, None, L.View(dy.data_ptr(), dy.stride(0), Cout, 0), part.data_ptr(), part.stride(0))
+        wp = L.WgradParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, CinP, Cout, ks, L.view(xs, CinP, 0, xs.stride(0) // esz), a.data_ptr(), b.data_ptr(),
+                           CinP, L.NULL_VIEW, 0, flags, None, L.View(dys.data_ptr(), dys.stride(0) // esz, Cout, 0), part.data_ptr(), part.stride(0))
         L.check(lib.vv_wgrad_bf16(C.byref(wp), st), 'wgrad_bf16')
         L.check(lib.vv_wgrad_reduce(L.CONV3, G, Cin, CinP, Cout, ks * kw.value, part.data_ptr(), part.stride(0), grad.data_ptr(),
                                     grad.stride(0), st), 'reduce')

@@ -608,7 +608,9 @@ class UNetBank:
             if self.cflag and self.bf16_wgrad:
                 # bf16 weight gradient: HBM bound, one workgroup (up to 512 registers per lane) per CU
                 ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
-                if lib.vv_wgrad_bf16_plan(L.CONV3, B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
+                # (the flags of the launch go with the query: the all-bf16 weight gradient runs the LDS-ring kernel, whose tiling differs)
+                wfl = (L.WGRAD_DY_BF16 | L.WGRAD_X_BF16) if (self.dz16 and self.y16) else 0
+                if lib.vv_wgrad_bf16_plan(L.CONV3 | (wfl << 8), B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
                     ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))      # one workgroup per CU, one round
                     wplan['c%d' % l.idx] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['c%d' % l.idx][1])

@@ -83,6 +83,22 @@ __device__ __forceinline__ float4 vv_unpack_bf16x4(uint2 u) {
                      __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xFFFF0000u));
 }
 
+// 8 bf16 (16 bytes) <-> 8 floats
+struct vv_f8 { float v[8]; };
+__device__ __forceinline__ vv_f8 vv_unpack_bf16x8(const uint4 u) {
+  vv_f8 r;
+  r.v[0] = __builtin_bit_cast(float, u.x << 16); r.v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+  r.v[2] = __builtin_bit_cast(float, u.y << 16); r.v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+  r.v[4] = __builtin_bit_cast(float, u.z << 16); r.v[5] = __builtin_bit_cast(float, u.z & 0xFFFF0000u);
+  r.v[6] = __builtin_bit_cast(float, u.w << 16); r.v[7] = __builtin_bit_cast(float, u.w & 0xFFFF0000u);
+  return r;
+}
+__device__ __forceinline__ uint4 vv_pack_bf16x8(const vv_f8& f) {
+  const uint2 lo = vv_pack_bf16x4(make_float4(f.v[0], f.v[1], f.v[2], f.v[3]));
+  const uint2 hi = vv_pack_bf16x4(make_float4(f.v[4], f.v[5], f.v[6], f.v[7]));
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // Resolved (per group) description of how a convolution reads its input.
 struct VVSrc {
   const float* p0; int cs0, co0;

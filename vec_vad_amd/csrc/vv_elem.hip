@@ -266,21 +266,6 @@ bn_bwd_reduce_kernel(const vv_bnbwd_params p, const int nblk, const int bp, cons
 
 // The same two passes when y, dA, dpool and dy are ALL stored as bf16 (mixed precision): 8 channels = 16 bytes per lane and tensor
 // instead of 4 channels = 8 bytes, the same 256-pixel blocks and partial-sum layout.  fp32 arithmetic as above.
-struct vv_f8 { float v[8]; };
-__device__ __forceinline__ vv_f8 vv_unpack_bf16x8(const uint4 u) {
-  vv_f8 r;
-  r.v[0] = __builtin_bit_cast(float, u.x << 16); r.v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
-  r.v[2] = __builtin_bit_cast(float, u.y << 16); r.v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
-  r.v[4] = __builtin_bit_cast(float, u.z << 16); r.v[5] = __builtin_bit_cast(float, u.z & 0xFFFF0000u);
-  r.v[6] = __builtin_bit_cast(float, u.w << 16); r.v[7] = __builtin_bit_cast(float, u.w & 0xFFFF0000u);
-  return r;
-}
-__device__ __forceinline__ uint4 vv_pack_bf16x8(const vv_f8& f) {
-  const uint2 lo = vv_pack_bf16x4(make_float4(f.v[0], f.v[1], f.v[2], f.v[3]));
-  const uint2 hi = vv_pack_bf16x4(make_float4(f.v[4], f.v[5], f.v[6], f.v[7]));
-  return make_uint4(lo.x, lo.y, hi.x, hi.y);
-}
-
 template <bool POOL, int PASS>
 __global__ void __launch_bounds__(VV_WG)
 bn_bwd16_kernel(const vv_bnbwd_params p, const int nblk, const int bp, const float* __restrict__ gamma,

@@ -397,6 +397,352 @@ wgradT_bf16_kernel(const vv_wgrad_params p, const int NT, const int NCI, const i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same weight gradient for the all-bf16 bank (layer input AND dy stored as bf16: BASELINE config 4), built around the memory
+// system instead of around registers.  The register-staged kernel above keeps ONE pixel tile in flight per CU (its loads are
+// issued after a tile's commit and must have landed at the next commit), so a 32 -> 32 channel layer -- 36 MFMAs per wave and
+// tile -- spends ~2 us of HBM latency per 0.5 us of matrix work: 2.9 TB/s, matrix pipe busy 0.2.  Here tiles go global -> LDS
+// directly (buffer_load_dwordx4 ... lds: 16 B per lane, a wave fills 16 pixels x 64 B, no staging registers) into a ring of
+// NBUF tile buffers, NBUF-1 tiles ahead of the one being multiplied; counted s_waitcnt vmcnt + raw s_barrier keep the later
+// tiles in flight across the barriers (a __syncthreads() would drain them).  The producer's BatchNorm+ReLU is applied in place in
+// LDS (ds_read_b128 -> VALU -> ds_write_b128) once a tile has landed; out-of-image halo pixels are zero-filled by the buffer
+// bounds check (plain sources) or by that pass (activated sources: relu(b) != 0).  Operands: ds_read_b64_tr_b16 as above.
+// Tiles of 256 pixels for 32 x 32 channel blocks, 128 pixels when a workgroup stages 64 input and / or output channels
+// (3 x 41-49 KB of the CU's 160 KB).
+// global -> LDS, 16 bytes per lane: the wave's 64 items land at lds_addr + lane * 16 (lds_addr wave-uniform, in M0), the source
+// offsets are per lane and bounds-checked (out of range: zeros).  Inline asm on purpose: hipcc tracks an LDS-DMA it knows about as a
+// pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read -- which would drain the tiles in flight before
+// every MFMA phase.  The counter arithmetic is done by hand in the kernel (s_waitcnt vmcnt(N) + raw s_barrier).
+__device__ __forceinline__ void vv_glds16(const __amdgpu_buffer_rsrc_t rs, const unsigned lds_addr, const unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
+}
+
+// Eight waves: waves 0-3 multiply (the consumers, one per SIMD), waves 4-7 feed them (the producers, one per SIMD): a producer
+// wave queues the DMAs of its share of a tile (16-pixel x 64-byte pieces) NBUF-1 tiles ahead, waits for the piece it loaded
+// itself (counted vmcnt -- no barrier needed: every lane activates exactly the 16 bytes it transferred), applies the producing
+// layer's BatchNorm+ReLU in place, and meets the consumers at ONE barrier per tile.  An elimination run of the four-wave form
+// (every wave loading, activating, multiplying in turn) showed the three phases adding up -- 32 -> 32 channels at 32 x 32:
+// MFMA phase alone 101 us, + activation 77, + HBM wait 50 = 228 us -- here they overlap on the SIMDs' two instruction streams.
+template <int TH, int TW, int NI, int CB, int OB, int NBUF>
+__global__ void __launch_bounds__(2 * VV_WG, 1)
+wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const int NCO, const int total, const int nper) {
+  constexpr int KW = 4 / (CB * OB);                        // consumer waves sharing one (ci-block, co-block) pair: they split the K steps
+  constexpr int AHH = TH + 2, AHW = TW + 2;
+  constexpr int APX = NI * AHH * AHW, BPX = NI * TH * TW;
+  static_assert(BPX == 256 || BPX == 128, "16 or 8 K steps per tile");
+  constexpr int NA = (APX + 15) / 16, NB = BPX / 16;       // pieces (16 pixels x 64 B = 1 KB, one DMA instruction) per 32-channel block
+  constexpr int ASZB = NA * 1024, BSZB = NB * 1024;        // bytes
+  constexpr int TB = CB * ASZB + OB * BSZB;                // one tile buffer
+  // a producer wave takes pieces wave, wave + 4, ... of every block: NPA / NPB DMAs per block (the last one may not exist for this
+  // wave: it is then an out-of-range DMA into the dump piece behind the ring, so that every wave queues the same number)
+  constexpr int NPA = (NA + 3) / 4, NPB = (NB + 3) / 4;
+  constexpr int NLA = CB * NPA, NLB = OB * NPB, NLW = NLA + NLB;      // DMAs per producer wave and tile
+  constexpr int RSZ = KW > 1 ? CB * OB * 9 * 4096 : 0;
+  constexpr int DUMP = NBUF * TB;                          // 1 KB
+  constexpr int LDSB = NBUF * TB + 1024 > RSZ ? NBUF * TB + 1024 : RSZ;
+  static_assert(LDSB <= 160 * 1024 && NBUF >= 3 && (NBUF - 2) * NLW <= 63, "ring geometry");
+  __shared__ __attribute__((aligned(16))) char ldsc[LDSB];          // the ONLY __shared__ object
+
+  int w = vv_xcd_remap(blockIdx.x, nper);
+  if (w >= total) return;
+  const int KS = p.ksplit;
+  const int NCI2 = NCI / CB, NCO2 = NCO / OB;
+  const int ks = w % KS; w /= KS;
+  const int cot2 = w % NCO2; w /= NCO2;
+  const int cit2 = w % NCI2;
+  const int g = w / NCI2;
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int H = p.H, W = p.W;
+  const int tpi = H / TH;                                  // tiles per image (TW == W on every level)
+  const vv_lds_t lbase = (vv_lds_t)ldsc;
+  const int ntl = (NT - ks + KS - 1) / KS;                 // tiles of this workgroup: pt = ks, ks + KS, ...
+
+  if (producer) {
+    // ---- sources.  A block j covers input channels (cit2*CB + j)*32 ..: skip-concat layers take it from src0 (activated) or src1
+    const VVSrc sa = vv_make_src(p, g, H, W);
+    __amdgpu_buffer_rsrc_t rsA[CB];
+    int csA[CB], coA[CB];
+    bool actA[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int c0 = (cit2 * CB + j) * 32;
+      const bool second = (sa.mode == VV_IN_CAT) && c0 >= sa.csplit;
+      rsA[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? sa.p1 : sa.p0), 0, 0x7FFFFFFF, 0x00020000);
+      csA[j] = second ? sa.cs1 : sa.cs0;
+      coA[j] = (second ? sa.co1 - sa.csplit : sa.co0) + c0;
+      actA[j] = (sa.mode == VV_IN_ACT) || (sa.mode == VV_IN_CAT && !second);
+    }
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy.ptr + (int64_t)g * p.dy.gstride), 0, 0x7FFFFFFF, 0x00020000);
+    const int csB = p.dy.cstride, coB = p.dy.coff + cot2 * OB * 32;
+    constexpr unsigned OOB = 0x80000000u;
+    // this lane's part of piece i of a tile (i is compile time): pixel (piece*16 + lane/4), 8 channels (lane%4)*8
+    const int lq = lane & 3, lp = lane >> 2;
+    int pixA[NLA];             // (im*H + hy)*W + hx relative to the tile origin, or < 0: never valid (x outside / pad pixel)
+    short hyA[NLA], imA[NLA];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      const int piece = (i % NPA) * 4 + wave;
+      const int px = piece * 16 + lp;
+      const int hx = px % AHW, t = px / AHW;
+      hyA[i] = (short)(t % AHH);
+      imA[i] = (short)(t / AHH);
+      const bool ok = piece < NA && px < APX && (unsigned)(hx - 1) < (unsigned)W;
+      pixA[i] = ok ? (imA[i] * H + hyA[i]) * W + hx : -(1 << 30);
+    }
+    int pixB[NLB];
+    short imB[NLB];
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int piece = (i % NPB) * 4 + wave;
+      const int px = piece * 16 + lp;
+      const int t = px / TW;
+      imB[i] = (short)(t / TH);
+      pixB[i] = piece < NB ? (imB[i] * H + t % TH) * W + px % TW : -(1 << 30);
+    }
+    // BatchNorm scale / shift of this lane's 8 channels, packed for v_pk_fma_f32
+    v2f sa2[CB][4], sb2[CB][4];
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (cit2 * CB + j) * 32 + lq * 8 + e;
+        const bool on = actA[j] && c < p.CinP;
+        float av = sa.a ? sa.a[on ? c : 0] : 0.f, bv = sa.b ? sa.b[on ? c : 0] : 0.f;
+        if (!on) { av = 0.f; bv = 0.f; }
+        sa2[j][e >> 1][e & 1] = av;
+        sb2[j][e >> 1][e & 1] = bv;
+      }
+    // the kernel's only ordinary loads: have them back before the first DMA is queued behind them
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(sa2[j][e]), "+v"(sb2[j][e]));
+
+    // queue this wave's NLW DMAs of pixel tile pt into ring slot `slot` (live = false: the same number of DMAs, all out of range:
+    // no memory traffic, zeros into a slot nobody reads -- the vmcnt arithmetic holds in the pipeline's tail)
+    auto issue = [&](const int pt, const int slot, const bool live) __attribute__((always_inline)) {
+      const int img0 = (pt / tpi) * NI;
+      const int ty0 = (pt % tpi) * TH;
+      const int tileA = (img0 * H + ty0 - 1) * W - 1;            // may be negative (top halo row of image 0)
+      const int tileB = (img0 * H + ty0) * W;
+      const unsigned sl = (unsigned)(size_t)(lbase + slot * TB + wave * 1024);
+      const unsigned dump = (unsigned)(size_t)(lbase + DUMP);
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        const int j = i / NPA;                                    // A block of this piece (compile time)
+        const bool exists = (i % NPA) * 4 + wave < NA;            // (wave-uniform)
+        const int y = ty0 - 1 + hyA[i];
+        const bool ok = live && pixA[i] >= 0 && (unsigned)y < (unsigned)H && img0 + imA[i] < p.B && (cit2 * CB + j) * 32 + lq * 8 < p.CinP;
+        const unsigned off = ok ? (unsigned)((tileA + pixA[i]) * csA[j] + coA[j] + lq * 8) * 2u : OOB;
+        vv_glds16(rsA[j], __builtin_amdgcn_readfirstlane(exists ? sl + j * ASZB + (i % NPA) * 4096 : dump), off);
+      }
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) {
+        const int j = i / NPB;
+        const bool exists = (i % NPB) * 4 + wave < NB;
+        const bool ok = live && pixB[i] >= 0 && img0 + imB[i] < p.B;
+        const unsigned off = ok ? (unsigned)((tileB + pixB[i]) * csB + coB + j * 32 + lq * 8) * 2u : OOB;
+        vv_glds16(rsB, __builtin_amdgcn_readfirstlane(exists ? sl + CB * ASZB + j * BSZB + (i % NPB) * 4096 : dump), off);
+      }
+    };
+    // BatchNorm+ReLU of the producing layer, in place, on the 16 bytes this lane transferred of every activated A piece; zero
+    // outside the image (plain sources: the bounds check already wrote the zero padding).  2.5 VALU instructions per value:
+    // packed fp32 multiply-add, round to bf16 pairs, ReLU as a packed signed 16-bit max with 0 (negative bf16 = negative int16)
+    auto activate = [&](const int pt, const int slot) __attribute__((always_inline)) {
+      const int img0 = (pt / tpi) * NI;
+      const int ty0 = (pt % tpi) * TH;
+      const vv_lds_t sl = lbase + slot * TB + wave * 1024 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        const int j = i / NPA;
+        if (!actA[j] || (i % NPA) * 4 + wave >= NA) continue;
+        uint4* q = (uint4*)(sl + j * ASZB + (i % NPA) * 4096);
+        const int y = ty0 - 1 + hyA[i];
+        const bool ok = pixA[i] >= 0 && (unsigned)y < (unsigned)H && img0 + imA[i] < p.B;
+        const uint4 u = *q;
+        const unsigned in[4] = {u.x, u.y, u.z, u.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v2f v = {__builtin_bit_cast(float, in[e] << 16), __builtin_bit_cast(float, in[e] & 0xFFFF0000u)};
+          v = __builtin_elementwise_fma(sa2[j][e], v, sb2[j][e]);
+          const v2bf r = __builtin_convertvector(v, v2bf);
+          typedef short v2s __attribute__((ext_vector_type(2)));
+          const v2s m = __builtin_elementwise_max(__builtin_bit_cast(v2s, r), (v2s){0, 0});
+          o[e] = ok ? __builtin_bit_cast(unsigned, m) : 0u;
+        }
+        *q = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    };
+
+    // prologue: tiles 0 .. NBUF-2 in flight, tile 0 landed + activated
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d) issue(ks + d * KS, d, d < ntl);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NLW) : "memory");
+    activate(ks, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // tile 0 is ready
+    for (int it = 0; it < ntl; ++it) {
+      // the consumers are multiplying tile `it`; the slot of tile it-1 is free: refill it NBUF-1 tiles ahead, then finish tile it+1
+#if defined(VV_EXPR) && (VV_EXPR == 3 || VV_EXPR == 4)
+      issue(ks + (it + NBUF - 1) * KS, (it + NBUF - 1) % NBUF, false);                // elimination run: no HBM traffic
+#else
+      issue(ks + (it + NBUF - 1) * KS, (it + NBUF - 1) % NBUF, it + NBUF - 1 < ntl);
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NLW) : "memory");       // this wave's pieces of tile it+1 have landed
+#if !defined(VV_EXPR) || (VV_EXPR != 2 && VV_EXPR != 4)
+      if (it + 1 < ntl) activate(ks + (it + 1) * KS, (it + 1) % NBUF);
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // the tail's dummy DMAs write zeros into ring slots: they must have landed before the consumers reuse the ring as reduction space
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (KW > 1)
+      for (int wv = 0; wv < KW; ++wv) __builtin_amdgcn_s_barrier();        // the consumers' reduction barriers (below)
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ consumers
+  const int blk = KW == 1 ? wave : (KW == 2 ? (wave & 1) : 0);
+  const int kq = KW == 1 ? 0 : (KW == 2 ? (wave >> 1) : wave);
+  const int cb = CB == 2 ? (OB == 2 ? (blk >> 1) : blk) : 0;
+  const int ob = OB == 2 ? (blk & 1) : 0;
+  v16f acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int trj = (lane >> 2) & 3;
+  const int trc = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int xoff = cb * ASZB + trc, yoff = CB * ASZB + ob * BSZB + trc;
+
+#ifdef VV_RING_PRIO
+  __builtin_amdgcn_s_setprio(VV_RING_PRIO);                      // experiment: the consumers' instructions ahead of their SIMD partner's
+#endif
+  __builtin_amdgcn_s_barrier();                                  // tile 0 is ready
+  for (int it = 0; it < ntl; ++it) {
+    const int slot = it % NBUF;
+    const vv_lds_t xt = lbase + slot * TB + xoff;
+    const vv_lds_t yt = lbase + slot * TB + yoff;
+#if defined(VV_EXPR) && VV_EXPR == 1
+    if (true) {} else                                           // elimination run: no operand reads, no MFMAs
+#endif
+    if constexpr (TW == 4) {
+      // 4x4 level: a K step is one image; the lane's 8 pixels are rows 2*half, 2*half+1 (first / second read), column j
+      constexpr int NKS = NI / KW;
+      const vv_lds_t xp = xt + ((kq * NKS * AHH + 2 * half) * AHW + trj) * 64;
+      const vv_lds_t yp = yt + ((kq * NKS * TH + 2 * half) * TW + trj) * 64;
+      vv_static_for<0, NKS>([&](auto KK) {
+        constexpr int io = KK.value * AHH * AHW * 64, yo = KK.value * TH * TW * 64;
+        const v8bf bq = vv_tr8(yp, yo, yo + TW * 64);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const v8bf a0 = vv_tr8(xp, io + (ky * AHW + 0) * 64, io + ((ky + 1) * AHW + 0) * 64);
+          const v8bf a1 = vv_tr8(xp, io + (ky * AHW + 1) * 64, io + ((ky + 1) * AHW + 1) * 64);
+          const v8bf a2 = vv_tr8(xp, io + (ky * AHW + 2) * 64, io + ((ky + 1) * AHW + 2) * 64);
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq, acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq, acc[ky * 3 + 2], 0, 0, 0);
+        }
+      });
+    } else {
+      // strips of K steps: a strip walks RLF rows of (TW == 32: one 16-column half | TW == 16: the image | TW == 8: an image pair)
+      constexpr int RLF = TW == 32 ? TH : 8;
+      constexpr int NSTR = (BPX / 16) / RLF;
+      constexpr int SEGS = NSTR >= KW ? NSTR / KW : 1;            // strips per wave
+      constexpr int WPS = NSTR >= KW ? 1 : KW / NSTR;             // waves per strip
+      constexpr int RL = RLF / WPS;
+      static_assert(RL >= 1, "strip geometry");
+#pragma unroll
+      for (int sg = 0; sg < SEGS; ++sg) {
+        const int strip = NSTR >= KW ? kq * SEGS + sg : kq / WPS;
+        const int r0 = NSTR >= KW ? 0 : (kq % WPS) * RL;
+        int im, rbase, c0;
+        if constexpr (TW == 32) { im = 0; rbase = 0; c0 = 16 * strip + 8 * half; }
+        else if constexpr (TW == 16) { im = 0; rbase = 8 * strip; c0 = 8 * half; }
+        else { im = 2 * strip + half; rbase = 0; c0 = 0; }
+        const int R = rbase + r0;
+        const vv_lds_t xp = xt + ((im * AHH + R) * AHW + c0 + trj) * 64;
+        const vv_lds_t yp = yt + ((im * TH + R) * TW + c0 + trj) * 64;
+        // operands one K step ahead of the MFMAs that consume them: a ring of four halo rows x three column shifts, two dy operands
+        v8bf win[4][3], bq[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) win[r][kx] = vv_tr8(xp, (r * AHW + kx) * 64, (r * AHW + kx + 4) * 64);
+        bq[0] = vv_tr8(yp, 0, 4 * 64);
+        vv_static_for<0, RL>([&](auto KK) {
+          constexpr int k = KK.value;
+          if constexpr (k + 1 < RL) {
+            constexpr int ro = (k + 3) * AHW * 64;
+            win[(k + 3) % 4][0] = vv_tr8(xp, ro + 0 * 64, ro + 4 * 64);
+            win[(k + 3) % 4][1] = vv_tr8(xp, ro + 1 * 64, ro + 5 * 64);
+            win[(k + 3) % 4][2] = vv_tr8(xp, ro + 2 * 64, ro + 6 * 64);
+            bq[(k + 1) & 1] = vv_tr8(yp, (k + 1) * TW * 64, ((k + 1) * TW + 4) * 64);
+          }
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(win[(k + ky) % 4][kx], bq[k & 1], acc[ky * 3 + kx], 0, 0, 0);
+        });
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (every operand read has returned: the slot may be refilled)
+    __builtin_amdgcn_s_barrier();                                // tile it+1 is ready; the producers may refill this slot
+  }
+
+  __builtin_amdgcn_s_barrier();                                  // the producers' last (dummy) DMAs have landed: the ring is idle
+  const int cit = cit2 * CB + cb, cot = cot2 * OB + ob;
+  float* out = p.partial + (int64_t)g * p.partial_gstride + ((int64_t)((cit * NCO + cot) * KS + ks)) * (9 * 1024);
+  if constexpr (KW == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+        out[t * 1024 + row * 32 + l31] = acc[t][i];
+      }
+  } else {
+    // the KW waves of a block pair are summed through LDS (the idle ring) in wave order: fixed, bitwise reproducible
+    float* red = reinterpret_cast<float*>(ldsc) + blk * (9 * 1024);
+    for (int wv = 0; wv < KW; ++wv) {
+      if (kq == wv) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+            float* q = red + t * 1024 + row * 32 + l31;
+            const float v = wv ? *q + acc[t][i] : acc[t][i];
+            if (wv == KW - 1) out[t * 1024 + row * 32 + l31] = v; else *q = v;
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
+// tile geometry of the ring kernel: 256-pixel tiles (16 K steps, four buffers) for one 32 x 32 channel block pair -- its four consumer
+// waves split the K steps --, 128-pixel tiles (three buffers) when a workgroup stages 64 input and / or output channels.  The 4x4
+// level stays on the register-staged kernel: a tile of 4x4 images is 2.25x halo, and the ring's producers do not keep up.
+struct RGeo { int TH, TW, NI; };
+inline bool rgeo(int H, int W, bool one, RGeo* t) {
+  if (H != W) return false;
+  if (H == 32) { *t = {one ? 8 : 4, 32, 1}; return true; }
+  if (H == 16) { *t = {one ? 16 : 8, 16, 1}; return true; }
+  if (H == 8) { *t = {8, 8, one ? 4 : 2}; return true; }
+  return false;
+}
+
 struct BGeo { int TH, TW, NI; };
 inline bool bgeo(int kind, int H, int W, BGeo* t) {
   if (H != W) return false;
@@ -477,10 +823,75 @@ int dispatch_b(const vv_wgrad_params* p, hipStream_t st) {
   return launch_b<TH, TW, NI, 1, 1>(p, st);
 }
 
+template <int TH, int TW, int NI, int CB, int OB, int NBUF>
+int launch_r(const vv_wgrad_params* p, hipStream_t st) {
+  const int NT = ((p->B + NI - 1) / NI) * (p->H / TH);
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  if (p->ksplit > NT) return VV_ERR_BAD_ARG;
+  const int total = p->G * (NCI / CB) * (NCO / OB) * p->ksplit;
+  const int nper = (total + 7) / 8;
+  VV_LAUNCH((wgrad_ring_kernel<TH, TW, NI, CB, OB, NBUF>), dim3(nper * 8), dim3(2 * VV_WG), 0, st, *p, NT, NCI, NCO, total, nper);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+// (ci blocks, co blocks) per workgroup of the ring kernel: 2 x 2 wherever the layer has them, 2 x 1 on the 4x4 level (three buffers
+// of a 2 x 2 tile of 8 images with their halos do not fit 160 KB)
+inline void ring_block_shape(int H, int NCI, int NCO, int* cbk, int* obk) {
+  (void)H;
+  *cbk = NCI % 2 == 0 ? 2 : 1;
+  *obk = NCO % 2 == 0 ? 2 : 1;
+}
+
+inline bool ring_ok(const vv_wgrad_params* p) {
+  const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
+  if (p->kind != VV_CONV3 || (p->pad0 & both) != both || p->H != p->W || p->H < 8) return false;
+  if (p->in_mode != VV_IN_PLAIN && p->in_mode != VV_IN_ACT && p->in_mode != VV_IN_CAT) return false;
+  if (p->src0.cstride % 8 || p->src0.coff % 8 || p->dy.cstride % 8 || p->dy.coff % 8 || p->CinP % 8) return false;
+  if (p->in_mode == VV_IN_CAT && (p->csplit % 32 || p->src1.cstride % 8 || p->src1.coff % 8)) return false;
+  return true;
+}
+
+int dispatch_r(const vv_wgrad_params* p, hipStream_t st) {
+  const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+  int c, o;
+  const int H = p->H == p->W ? p->H : 0;
+  ring_block_shape(H, NCI, NCO, &c, &o);
+#define VV_RING(H_, TH1, NI1, TH2, NI2, TW_)                                                   \
+  if (H == H_) {                                                                                \
+    if (c == 1 && o == 1) return launch_r<TH1, TW_, NI1, 1, 1, (H_ == 8 ? 3 : 4)>(p, st);        \
+    if (c == 2 && o == 1) return launch_r<TH2, TW_, NI2, 2, 1, 3>(p, st);                       \
+    if (c == 1 && o == 2) return launch_r<TH2, TW_, NI2, 1, 2, 3>(p, st);                       \
+    return launch_r<TH2, TW_, NI2, 2, 2, 3>(p, st);                                             \
+  }
+  VV_RING(32, 8, 1, 4, 1, 32)
+  VV_RING(16, 16, 1, 8, 1, 16)
+  VV_RING(8, 8, 4, 8, 2, 8)
+#undef VV_RING
+  return VV_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W, int32_t CinP, int32_t Cout, int32_t* ntiles,
                                   int32_t* nblocks, int32_t* kw) {
+  // kind: bits 0-7 = VV_CONV3 / VV_CONVT_FWD, bits 8.. = the vv_wgrad_params.pad0 flags the launch will carry (the all-bf16
+  // 3x3 weight gradient runs the LDS-ring kernel, whose tiles and block shapes differ)
+  const int flags = kind >> 8;
+  kind &= 0xff;
+  const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
+  if (kind == VV_CONV3 && (flags & both) == both && Cout % 32 == 0 && CinP > 0 && CinP % 8 == 0) {
+    const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
+    int cbk, obk;
+    ring_block_shape(H, NCI, NCO, &cbk, &obk);
+    RGeo r;
+    if (rgeo(H, W, cbk == 1 && obk == 1, &r)) {
+      if (ntiles) *ntiles = ((B + r.NI - 1) / r.NI) * (H / r.TH);
+      if (nblocks) *nblocks = (NCI / cbk) * (NCO / obk);
+      if (kw) *kw = 1;
+      return 1;
+    }
+  }
   BGeo t;
   if (!bgeo(kind, H, W, &t) || Cout % 32 || CinP <= 0) return 0;
   const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
@@ -499,6 +910,7 @@ extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   if ((p->pad0 & VV_WGRAD_DY_BF16) && p->dy.coff % 2) return VV_ERR_BAD_ARG;
   if ((p->pad0 & VV_WGRAD_X_BF16) && !(p->pad0 & VV_WGRAD_DY_BF16)) return VV_ERR_UNSUPPORTED;
+  if (ring_ok(p)) return dispatch_r(p, st);
   if (p->kind != VV_CONV3) {                   // weight gradient of the transposed conv (H x W = its input resolution)
     switch (p->H == p->W ? p->H : 0) {
       case 16: return dispatch_t<8, 16, 1>(p, st);
