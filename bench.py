@@ -93,76 +93,100 @@ def pmc_traffic(name):
     return None, None
 
 
-def cpu_baseline(batch=32, warm=3, steps=10, sweep=(8, 16, 32), budget_s=45.0):
-    """Reference op sequence (torch CPU ops, NCHW fp32, per-op BN/ReLU/pool/cat, Adam eps=1e-7) on the host cores:
-    BASELINE.json configs[0] (Net4, B=32), SURVEY 8(d): 3 warm-up + 10 timed train steps.  The host of an MI355X box has 256
-    hardware threads and the B=32 workload scales badly past ~16 of them (oneDNN/OpenMP oversubscription), so both figures
-    are reported: the best of a small thread sweep (``value`` / ``cores``) and all cores (``all_cores``; its step count is cut
-    when a step takes seconds, and says so).  ``eval_value`` is the eval-mode forward (scoring) at the best thread count.
-    This is the oracle restatement ("port"): test/bench infrastructure, never part of the product path."""
+def _cpu_topology():
+    """(model name, physical cores, hardware threads usable by this process) from /proc/cpuinfo."""
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return model, (len(cores) or usable), usable
+
+
+def cpu_child(nt, batch, warm, steps, limit_s):
+    """One leg of the CPU baseline in its own process (threads bound by the parent's OMP_* environment): prints one JSON line.
+    Timed steps stop early when ``limit_s`` is used up (at least 2 are timed) and the line says how many ran."""
+    torch.set_num_threads(nt)
     from oracle import unet_oracle as O
-    ncpu = os.cpu_count() or 1
     spec = O.bank_spec('net4')
     raw, flow = O.seeded_cubes(batch, 1, 3)
     x, x_of = O.cubes_to_inputs(raw, flow)
-    t_start = time.perf_counter()
-
-    def run(nt, w, k):
-        torch.set_num_threads(nt)
-        sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
-        opt = O.AdamState(O.param_names(sd))
-        for _ in range(w):
-            O.train_step(sd, spec, x, x_of, opt)
-        t0 = time.perf_counter()
-        for _ in range(k):
-            O.train_step(sd, spec, x, x_of, opt)
-        return batch * k / (time.perf_counter() - t0)
-
-    tried, best = [], None
-    for nt in [t for t in sweep if t <= ncpu] or [ncpu]:
-        v = run(nt, warm, steps)
-        tried.append('%d thr: %.0f' % (nt, v))
-        if best is None or v > best[0]:
-            best = (v, nt)
-        if time.perf_counter() - t_start > budget_s * 0.5:
-            break
-    # all cores: in a child process with a hard time limit -- on a 256-thread host the 32-cube step thrashes (oneDNN / OpenMP
-    # oversubscription: one step was measured at minutes), and a hung baseline must not take the bench line with it
-    ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else ncpu
-    allc = {'value': None, 'cores': ncore, 'warmup': warm, 'steps': steps, 'note': None}
-    code = ('import sys, time, torch; sys.path.insert(0, %r); from oracle import unet_oracle as O\n'
-            'torch.set_num_threads(%d); spec = O.bank_spec("net4"); raw, flow = O.seeded_cubes(%d, 1, 3); x, xo = O.cubes_to_inputs(raw, flow)\n'
-            'sd = O.seeded_state_dict("net4", nf=32, padding=False, seed=0); opt = O.AdamState(O.param_names(sd))\n'
-            '[O.train_step(sd, spec, x, xo, opt) for _ in range(%d)]\n'
-            't0 = time.perf_counter(); [O.train_step(sd, spec, x, xo, opt) for _ in range(%d)]\n'
-            'print("RATE", %d * %d / (time.perf_counter() - t0))' % (ROOT, ncore, batch, warm, steps, batch, steps))
-    import subprocess
-    limit = max(10.0, min(40.0, budget_s - (time.perf_counter() - t_start)))
-    try:
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=limit)
-        for line in r.stdout.splitlines():
-            if line.startswith('RATE'):
-                allc['value'] = float(line.split()[1])
-        if allc['value'] is None:
-            allc['note'] = 'child failed: ' + r.stderr[-200:]
-    except subprocess.TimeoutExpired:
-        allc['note'] = 'did not finish %d+%d steps of %d cubes within %.0f s on %d threads (oversubscription)' % (warm, steps, batch, limit, ncore)
-    # eval-mode forward (test.py:319-335) at the best thread count
-    torch.set_num_threads(best[1])
     sd = O.seeded_state_dict('net4', nf=32, padding=False, seed=0)
+    opt = O.AdamState(O.param_names(sd))
+    t_start = time.perf_counter()
     for _ in range(warm):
-        O.score_pass(sd, spec, x, x_of, batch)
+        O.train_step(sd, spec, x, x_of, opt)
+        if time.perf_counter() - t_start > 0.4 * limit_s:
+            break
     t0 = time.perf_counter()
-    for _ in range(steps):
+    n = 0
+    while n < steps and (n < 2 or time.perf_counter() - t_start < limit_s):
+        O.train_step(sd, spec, x, x_of, opt)
+        n += 1
+    dt = time.perf_counter() - t0
+    # eval-mode forward (test.py:319-335)
+    e0 = time.perf_counter()
+    m = 0
+    while m < steps and (m < 2 or time.perf_counter() - e0 < 0.25 * limit_s):
         O.score_pass(sd, spec, x, x_of, batch)
-    ev = batch * steps / (time.perf_counter() - t0)
-    return {'value': best[0], 'unit': 'cubes/s', 'cores': best[1], 'kind': 'port',
-            'all_cores': allc,
-            'eval_value': ev, 'eval_unit': 'cubes/s (eval-mode forward + per-cube scores)',
-            'sample': 'SelfCompleteNet4 train step (fwd+bwd+Adam) on stock torch %s CPU ops, batch %d (BASELINE configs[0]), %d warm-up + '
-                      '%d timed steps per thread count; host has %d hardware threads (%d usable); sweep (cubes/s): %s; all usable threads: %s'
-                      % (torch.__version__, batch, warm, steps, ncpu, ncore, '; '.join(tried),
-                         ('%.0f cubes/s' % allc['value']) if allc['value'] else allc['note'])}
+        m += 1
+    de = time.perf_counter() - e0
+    print(json.dumps({'threads': nt, 'train_cubes_per_s': batch * n / dt, 'timed_steps': n, 'eval_cubes_per_s': batch * m / de}))
+
+
+def cpu_baseline(batch=32, warm=3, steps=10, budget_s=55.0):
+    """Reference op sequence (torch CPU ops, NCHW fp32, per-op BN/ReLU/pool/cat, Adam eps=1e-7) on the host cores:
+    BASELINE.json configs[0] (Net4, B=32), SURVEY 8(d): 3 warm-up + 10 timed train steps per leg.  Every leg runs in its own
+    process with its OpenMP threads BOUND (OMP_PROC_BIND=close, OMP_PLACES=cores): unbound, the 256-thread host of an MI355X box
+    thrashed at its full thread count (round 2: the all-cores leg never finished).  Legs: 8, 16, 32, 64 ... up to the physical core
+    count; ``value`` / ``cores`` = the best leg, ``all_cores`` = the leg on every physical core.  This is the oracle restatement
+    ("port"): test / bench infrastructure, never part of the product path."""
+    import subprocess
+    model, ncore, usable = _cpu_topology()
+    top = max(1, min(ncore, usable))
+    legs = sorted({t for t in (8, 16, 32, 64, 128, 256) if t < top} | {top})
+    t_start = time.perf_counter()
+    res = {}
+    for i, nt in enumerate(legs):
+        left = budget_s - (time.perf_counter() - t_start)
+        per = max(6.0, left / (len(legs) - i))
+        env = dict(os.environ, OMP_NUM_THREADS=str(nt), OMP_PROC_BIND='close', OMP_PLACES='cores', MKL_NUM_THREADS=str(nt))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', str(nt), '--cpu-child-limit', '%.1f' % per,
+                                '--batch', str(batch)], capture_output=True, text=True, timeout=per * 2.5 + 20, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            res[nt] = json.loads(line[-1]) if line else {'error': r.stderr[-200:]}
+        except subprocess.TimeoutExpired:
+            res[nt] = {'error': 'timeout after %.0f s' % (per * 2.5 + 20)}
+    ok = {nt: v for nt, v in res.items() if 'train_cubes_per_s' in v}
+    if not ok:
+        raise RuntimeError('no CPU leg finished: %r' % (res,))
+    best = max(ok, key=lambda nt: ok[nt]['train_cubes_per_s'])
+    allc = res.get(top, {})
+    sweep = '; '.join('%d thr: %s' % (nt, ('%.0f (%d steps)' % (v['train_cubes_per_s'], v['timed_steps'])) if 'train_cubes_per_s' in v else v['error'])
+                      for nt, v in sorted(res.items()))
+    return {'value': ok[best]['train_cubes_per_s'], 'unit': 'cubes/s', 'cores': best, 'kind': 'port',
+            'cpu_model': model, 'physical_cores': ncore, 'hardware_threads': os.cpu_count(), 'usable_threads': usable,
+            'all_cores': {'value': allc.get('train_cubes_per_s'), 'cores': top, 'timed_steps': allc.get('timed_steps'),
+                          'note': allc.get('error')},
+            'eval_value': ok[best]['eval_cubes_per_s'], 'eval_unit': 'cubes/s (eval-mode forward + per-cube scores)',
+            'sample': 'SelfCompleteNet4 train step (fwd+bwd+Adam) on stock torch %s CPU ops, batch %d (BASELINE configs[0]), %d warm-up + up to '
+                      '%d timed steps per leg, one process per leg with OMP_PROC_BIND=close OMP_PLACES=cores; %s, %d physical cores / %d '
+                      'hardware threads; legs (cubes/s): %s' % (torch.__version__, batch, warm, steps, model, ncore, os.cpu_count() or 0, sweep)}
 
 
 def build_net(model, precision, dev):
@@ -488,6 +512,8 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="bf16 = BASELINE config 4's mixed precision; the headline number is fp32, like the reference")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-child', type=int, default=0, help=argparse.SUPPRESS)          # one leg of the CPU baseline (internal)
+    ap.add_argument('--cpu-child-limit', type=float, default=10.0, help=argparse.SUPPRESS)
     ap.add_argument('--no-graph', action='store_true', help='eager launch loop in every timed step (default: hipGraph replay)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-4 / config-5 / scoring records')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
@@ -495,6 +521,9 @@ def main():
                     help="side stream for the weight-gradient kernels: 'free' = under everything that follows (conv launches "
                          "are then contended), 'paired' = only under the next layer's BatchNorm backward (conv launches run alone)")
     args = ap.parse_args()
+    if args.cpu_child:
+        cpu_child(args.cpu_child, args.batch if args.batch != 256 else 32, 3, 10, args.cpu_child_limit)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
