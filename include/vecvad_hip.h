@@ -170,6 +170,15 @@ int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W, int32_t Ci
 int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t CinP, int32_t Cout, int32_t nslab_per_tile,
                     const float* partial, int64_t partial_gstride, float* grad, int64_t grad_gstride,
                     vv_stream stream);
+/* The same for several layers in ONE launch (e.g. every weight gradient of a data-parallel gradient bucket).  Device table, sorted by
+ * block_start; entry e owns blocks [block_start, block_start + ceil(CinP/32)*(Cout/32)*36) of the launch; total_blocks = their sum.
+ * Slabs of entry e start at partial + g*partial_gstride + part_off; its gradient at grads + grad_off + g*grad_gstride (floats). */
+typedef struct vv_reduce_entry {
+  int32_t kind, Cin, Cout, NCO, nslab, block_start;
+  int64_t part_off, grad_off, grad_gstride;
+} vv_reduce_entry;
+int vv_wgrad_reduce_grouped(const vv_reduce_entry* table_dev, int32_t nentries, int32_t total_blocks, int32_t G, const float* partial,
+                            int64_t partial_gstride, float* grads, vv_stream stream);
 
 /* ---- weight packing: PyTorch OIHW -> MFMA B-operand panels ----
  * mode 0: conv forward      Wp[t=ky*3+kx][k=ci][n=co] = W[co][ci][ky][kx]

@@ -59,6 +59,11 @@ class PackEntry(C.Structure):
     _fields_ = [('src_off', c_i64), ('dst_off', c_i64), ('mode', c_i32), ('K', c_i32), ('KP', c_i32), ('N', c_i32)]
 
 
+class ReduceEntry(C.Structure):
+    _fields_ = [('kind', c_i32), ('Cin', c_i32), ('Cout', c_i32), ('NCO', c_i32), ('nslab', c_i32), ('block_start', c_i32),
+                ('part_off', c_i64), ('grad_off', c_i64), ('grad_gstride', c_i64)]
+
+
 class FoldEntry(C.Structure):
     _fields_ = [('w_off', c_i64), ('b_off', c_i64), ('g_off', c_i64), ('beta_off', c_i64), ('rm_off', c_i64), ('rv_off', c_i64),
                 ('cout', c_i32), ('row', c_i32)]
@@ -106,6 +111,7 @@ _SIGS = {
     'vv_wgrad_bf16': (c_i32, [C.POINTER(WgradParams), c_vp]),
     'vv_wgrad_bf16_plan': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),
     'vv_wgrad_reduce': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'vv_wgrad_reduce_grouped': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'vv_pack_weights': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_bn_finalize': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp, c_i64,
                                c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

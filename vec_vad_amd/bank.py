@@ -625,8 +625,30 @@ class UNetBank:
                     ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))
                     wplan['t%d' % u] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['t%d' % u][1])
-        ws.wpart = f(Ga, wmax * 9 * 1024)
+        # weight-gradient slabs: one region per layer (the reductions of a whole gradient bucket run as ONE grouped launch after the
+        # bucket's last weight-gradient kernel, so every layer's slabs must still be there)
+        woff, wtot = {}, 0
+        for key, wpl in wplan.items():
+            woff[key] = wtot
+            wtot += wpl[1] * 9 * 1024
+        ws.wpart = f(Ga, wtot)
         wpg = ws.wpart.stride(0)
+        group_reduce = os.environ.get('VV_GROUP_REDUCE', '1') != '0'
+        pending = []                     # (key, kind, cin, cinp, cout, nslab) of weight gradients whose reduction is still to be launched
+
+        def flush_reduce(label, **kw_):
+            """one vv_wgrad_reduce_grouped launch for everything in `pending` (all of it lies in one gradient bucket)"""
+            ents = (L.ReduceEntry * len(pending))()
+            start = 0
+            for i, (key, kind, cin, cinp, cout, nslab) in enumerate(pending):
+                gptr, gstride = self._g(key + '.w')
+                ents[i] = L.ReduceEntry(kind, cin, cout, cout // 32, nslab, start, woff[key], (gptr - self.grads.data_ptr()) // 4, gstride)
+                start += ((cinp + 31) // 32) * (cout // 32) * 36
+            tab = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(d)
+            P.keep.append(tab)
+            P.add(lib.vv_wgrad_reduce_grouped, (tab.data_ptr(), len(pending), start, Ga, ws.wpart.data_ptr(), wpg, self.grads.data_ptr()),
+                  label, **kw_)
+            del pending[:]
 
         # 1x1 output conv
         y = ws.y[last.idx]
@@ -739,12 +761,17 @@ class UNetBank:
                 (self.wgrad_flag if self.wino_wgrad else 0)
             wp = L.WgradParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, ks, s0, a, b, abg, s1, csplit,
                                wflag, chmap,
-                               L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr(), wpg)
+                               L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), ws.wpart.data_ptr() + 4 * woff['c%d' % i], wpg)
             P.keep.append(wp)
             P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgrad%d' % i, stream=1, wait=('dy%d' % i,),
                   record='wdone%d' % i, pwait=('*main',))
-            P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * max(kw, 1), ws.wpart.data_ptr(), wpg)
-                  + self._g('c%d.w' % i), 'wgrad_reduce%d' % i, stream=1)
+            if group_reduce:
+                pending.append(('c%d' % i, L.CONV3, l.cin, l.cinp, l.cout, ks * max(kw, 1)))
+                if i in (4, 0):            # last weight gradient of the deep-encoder / shallow-encoder bucket (self.gb)
+                    flush_reduce('wgrad_reduce%d' % i, stream=1)
+            else:
+                P.add(lib.vv_wgrad_reduce, (L.CONV3, Ga, l.cin, l.cinp, l.cout, ks * max(kw, 1), ws.wpart.data_ptr() + 4 * woff['c%d' % i], wpg)
+                      + self._g('c%d.w' % i), 'wgrad_reduce%d' % i, stream=1)
 
         def convT_bwd(u, m):
             """m: the CAT conv layer that consumed convT u; its data gradient holds d(convT out) in channels [skipC, cin)."""
@@ -767,18 +794,24 @@ class UNetBank:
             wp = L.WgradParams(L.CONVT_FWD, L.IN_ACT, Ga, B, H, H, ci, ci, co, ks, L.view(y, ci, 0, y.stride(0)),
                                self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx]), abg, L.NULL_VIEW, 0,
                                ((L.WGRAD_DY_BF16 | (L.WGRAD_X_BF16 if self.y16 else 0)) if (kw and self.da16) else 0), None, dy,
-                               ws.wpart.data_ptr(), wpg)
+                               ws.wpart.data_ptr() + 4 * woff['t%d' % u], wpg)
             P.keep.append(wp)
             # side stream: its dy is the concat layer's data gradient (main stream) -- wait for it
             P.add(lib.vv_wgrad_bf16 if kw else lib.vv_wgrad_mfma, (C.byref(wp),), 'wgradT%d' % u, stream=1,
                   wait=('D%d' % m.idx,), pwait=('*main',))
-            P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr(), wpg)
-                  + self._g('t%d.w' % u), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
+            if group_reduce:
+                pending.append(('t%d' % u, L.CONVT_FWD, ci, ci, co, ks * max(kw, 1)))
+                if u == 0:                 # last weight gradient of the decoder bucket
+                    flush_reduce('wgradT_reduce0', stream=1, record='sideT0')
+            else:
+                P.add(lib.vv_wgrad_reduce, (L.CONVT_FWD, Ga, ci, ci, co, ks * max(kw, 1), ws.wpart.data_ptr() + 4 * woff['t%d' % u], wpg)
+                      + self._g('t%d.w' % u), 'wgradT_reduce%d' % u, stream=1, record='sideT%d' % u)
 
         for l in reversed(lay.convs):
             conv_bwd(l)
             if l.mode == L.IN_CAT:
                 convT_bwd(l.up, l)
+        assert not pending
         return P
 
     # ------------------------------------------------------------------------------------------ public operations

@@ -513,6 +513,40 @@ wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO
   }
 }
 
+// The same reduction for SEVERAL layers in one launch (all weight gradients of a gradient bucket: up to 13 launches of 8-20 us
+// become one): blockIdx.x runs over the concatenated block lists of the table's entries.
+__global__ void __launch_bounds__(VV_WG)
+wgrad_reduce_grouped_kernel(const vv_reduce_entry* __restrict__ table, const int n, const float* __restrict__ partial,
+                            const int64_t partial_gstride, float* __restrict__ grads) {
+  int e = 0;
+  for (int i = 1; i < n; ++i) e = (int)blockIdx.x >= table[i].block_start ? i : e;      // entries are sorted by block_start
+  const vv_reduce_entry t = table[e];
+  const int bx = blockIdx.x - t.block_start;
+  const int quarter = bx & 3;
+  const int tap = (bx >> 2) % 9;
+  const int tile = (bx >> 2) / 9;
+  const int g = blockIdx.y;
+  const int cit = tile / t.NCO, cot = tile % t.NCO;
+  const int el = quarter * VV_WG + threadIdx.x;
+  const float* src = partial + (int64_t)g * partial_gstride + t.part_off + (int64_t)tile * t.nslab * (9 * 1024) + tap * 1024 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= t.nslab; k += 4) {
+    s0 += src[(int64_t)(k + 0) * (9 * 1024)];
+    s1 += src[(int64_t)(k + 1) * (9 * 1024)];
+    s2 += src[(int64_t)(k + 2) * (9 * 1024)];
+    s3 += src[(int64_t)(k + 3) * (9 * 1024)];
+  }
+  for (; k < t.nslab; ++k) s0 += src[(int64_t)k * (9 * 1024)];
+  const float s = (s0 + s1) + (s2 + s3);
+  float* dst = grads + t.grad_off + (int64_t)g * t.grad_gstride;
+  const int ci = cit * 32 + (el >> 5), co = cot * 32 + (el & 31);
+  if (ci < t.Cin && co < t.Cout) {
+    if (t.kind == VV_CONV3) dst[((int64_t)co * t.Cin + ci) * 9 + tap] = s;
+    else dst[((int64_t)ci * t.Cout + co) * 9 + tap] = s;
+  }
+}
+
 struct WGeo { int TH, TW, NI; };
 inline bool wgeo(int kind, int H, int W, WGeo* t) {
   if (H != W) return false;
@@ -600,6 +634,15 @@ extern "C" int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t Cin
   const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
   VV_LAUNCH(wgrad_reduce_kernel, dim3(NCI * NCO * 9 * 4, G), dim3(VV_WG), 0, (hipStream_t)stream, kind, Cin, Cout,
                      NCO, nslab_per_tile, partial, partial_gstride, grad, grad_gstride);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_wgrad_reduce_grouped(const vv_reduce_entry* table_dev, int32_t nentries, int32_t total_blocks, int32_t G,
+                                       const float* partial, int64_t partial_gstride, float* grads, vv_stream stream) {
+  if (!table_dev || !partial || !grads || nentries <= 0 || total_blocks <= 0) return VV_ERR_BAD_ARG;
+  VV_LAUNCH(wgrad_reduce_grouped_kernel, dim3(total_blocks, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, nentries, partial,
+            partial_gstride, grads);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
