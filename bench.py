@@ -87,10 +87,24 @@ def pmc_traffic(name):
     for n in (name, name.replace('r03_', 'r02_'), name.replace('r03_', 'r01_')):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
-            return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], n
+            return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], _profile_tag(n, d)
         except Exception:
             continue
     return None, None
+
+
+def _profile_tag(name, d):
+    """'<file> (counters taken on library build X; this run: X = same kernels | Y = STALE)' -- a constant read from profiles/ must
+    say which kernels it was measured on."""
+    try:
+        from vec_vad_amd import build as B
+        cur = B.wanted()[1][:16]
+    except Exception:
+        cur = None
+    was = d.get('library_build')
+    if was is None:
+        return '%s (library build of the counters not recorded)' % name
+    return '%s (counters taken on library build %s; this run %s: %s)' % (name, was, cur, 'same kernels' if was == cur else 'STALE')
 
 
 def _cpu_topology():
@@ -438,6 +452,14 @@ def run_scoring(dev, B=512, n=8192, reps=3):
     return rec
 
 
+def _fn2_traffic():
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic_flownet2.json')))
+        return d['total_hbm_bytes_per_run_corrected'], _profile_tag('r03_pmc_hbm_traffic_flownet2.json', d)
+    except Exception:
+        return None, None
+
+
 def run_flownet2(dev, reps=10):
     """BASELINE config 5: FlowNet2 forward on one 1024x436 pair zero-padded to 1024x448 (the reference itself fails at 436),
     xavier weights (no checkpoint offline), hipGraph replay; per-kernel-family timings from one eager pass with HIP events."""
@@ -491,7 +513,8 @@ def run_flownet2(dev, reps=10):
            'algorithmic_gflop': FLOWNET2_GFLOP, 'finite': bool(torch.isfinite(out).all()),
            'roofline': {'bound': 'mfma', 'kernel': 'conv2d_mfma_kernel family (whole forward: 464.2 GFLOP of conv / deconv work)',
                         'achieved': FLOWNET2_GFLOP / ms, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
-                        'frac': FLOWNET2_GFLOP / ms / (FP32_MFMA_PEAK / 1e12), 'traffic': None,
+                        'frac': FLOWNET2_GFLOP / ms / (FP32_MFMA_PEAK / 1e12), 'traffic': _fn2_traffic()[0],
+                        'traffic_source': _fn2_traffic()[1], 'traffic_unit': 'HBM bytes per forward pass (all kernels)',
                         'dominant_family': dom, 'dominant_family_frac': fams[dom]['tflops'] / (FP32_MFMA_PEAK / 1e12)},
            'four_pairs_per_launch': {'ms_per_pair': ms4, 'pairs_per_s': 1e3 / ms4, 'tflops': FLOWNET2_GFLOP / ms4,
                                      'frac': FLOWNET2_GFLOP / ms4 / (FP32_MFMA_PEAK / 1e12)},

@@ -33,3 +33,19 @@ def digest_close(d, g, rtol, atol_scale=1.0):
     samp_tol = rtol * (np.abs(g[4:]) + np.abs(g[4:]).max() + 1e-30)
     ok &= bool(np.all(np.abs(d[4:] - g[4:]) <= samp_tol * 4))
     return bool(ok)
+
+
+def observe(name, **vals):
+    """Observed deviations of a parity check: printed (pytest -s / -rP) and appended to gpurun_out/observed.jsonl so that the bars
+    in the tests can be set from measurements (bars at ~2x the observed value)."""
+    import json
+    import os
+    rec = dict(test=name, **{k: float(v) for k, v in vals.items()})
+    print('OBSERVED', json.dumps(rec))
+    try:
+        root = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'observed.jsonl'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass

@@ -116,6 +116,9 @@ def test_full_bank_bf16_b512_vs_mixed_oracle(monkeypatch):
     r, o = tr.score_cubes(rawd, flowd, torch.tensor([0, 100, 301, 511], device='cuda'))
     sel = [0, 100, 301, 511]
     rs, os_ = O.score_pass({k: v.clone() for k, v in sd.items()}, spec, x[sel], x_of[sel], 4)
+    from _util import observe
+    observe('full_bf16_b512 eval scores vs mixed oracle', raw=float(np.max(np.abs(r.cpu().numpy() - rs) / np.abs(rs))),
+            of=float(np.max(np.abs(o.cpu().numpy() - os_) / np.abs(os_))))
     np.testing.assert_allclose(r.cpu().numpy(), rs, rtol=1e-2)
     np.testing.assert_allclose(o.cpu().numpy(), os_, rtol=1e-2)
     # train-mode forward of the full batch
@@ -127,6 +130,7 @@ def test_full_bank_bf16_b512_vs_mixed_oracle(monkeypatch):
         oo, ro, ot, rt = O.bank_forward({k: v.clone() for k, v in sd.items()}, spec, x, x_of, True, False)
         _, lr_, lo_ = O.train_loss(oo, ro, ot, rt)
     lr_, lo_ = float(lr_), float(lo_)
+    observe('full_bf16_b512 train losses vs mixed oracle', raw=abs(l_raw - lr_) / lr_, of=abs(l_of - lo_) / lo_)
     assert abs(l_raw - lr_) <= 2e-3 * lr_ and abs(l_of - lo_) <= 2e-3 * lo_, (l_raw, lr_, l_of, lo_)
     r, o = tr.bank.cube_scores(ws)
     for got, ref in ((r.cpu().numpy(), O.cube_scores(ro, rt).numpy()), (o.cpu().numpy(), O.cube_scores(oo, ot).numpy())):

@@ -11,19 +11,7 @@ from _util import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _observe(name, **vals):
-    """Observed deviations of a parity check: printed (pytest -s / -rP) and appended to gpurun_out/observed.jsonl so that the
-    bars in this file can be set from measurements (bars at 2x the observed value)."""
-    import json
-    rec = dict(test=name, **{k: float(v) for k, v in vals.items()})
-    print('OBSERVED', json.dumps(rec))
-    try:
-        root = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
-        with open(os.path.join(root, 'gpurun_out', 'observed.jsonl'), 'a') as f:
-            f.write(json.dumps(rec) + '\n')
-    except OSError:
-        pass
+from _util import observe as _observe  # noqa: E402
 
 
 def _rel(a, b):
@@ -43,10 +31,12 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
     1.3e-3 at worst (1 of 240 frames above 1e-3), i.e. per-cube ~1e-5.  The 240-frame golden has graded anomalies
     (normal and anomalous scores overlap, AUROC 0.768): one swapped pair moves its AUROC by 1.2e-4, so the AUROC bar is a real
     statement there; on the 10-frame golden it only says the ranking is identical.
-    bf16 (`[mi355x] precision = bf16`, BASELINE config 4): judged on AUROC -- within 2e-2 of the reference's --
-    with the per-cube / per-frame quantities within 5 % / 0.1."""
+    bf16 (`[mi355x] precision = bf16`, BASELINE config 4): bars at ~2x what round 3 observed against the REFERENCE's fp32 golden
+    (gpurun_out/observed.jsonl: per-cube training scores 6.4e-4 / 2.2e-4, first loss 5.3e-5, z-normalised frame scores 9.9e-3 on the
+    240-frame golden, AUROC 2.1e-4): training scores 1.5e-3, loss 2e-4, frame scores 2e-2, AUROC 1e-3 -- the fp32 path's own bars
+    except for the frame scores (x4: the z-normalisation amplifies a per-cube deviation by mu / sigma ~ 140)."""
     monkeypatch.setenv('VV_PRECISION', precision)
-    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=5e-3, auc=1e-3), 'bf16': dict(train=5e-2, loss=1e-2, frame=1e-1, auc=2e-2)}[precision]
+    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=5e-3, auc=1e-3), 'bf16': dict(train=1.5e-3, loss=2e-4, frame=2e-2, auc=1e-3)}[precision]
     from oracle import unet_oracle as O
     import train as T
     import test as S

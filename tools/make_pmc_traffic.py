@@ -45,6 +45,20 @@ def main():
                         'hbm_bytes_per_launch_corrected': int(sum(k['hbm_bytes_per_launch_corrected'] * k['launches'] for k in fam) / max(n, 1))},
         'kernels': kernels[:40],
     }
+    # optional 4th argument: number of forward passes / steps the profiled command ran -> whole-run HBM bytes per pass
+    if len(sys.argv) > 4:
+        n_runs = int(sys.argv[4])
+        tot = sum((2 * fetch[k] + write.get(k, 0.0)) * 1024 for k in fetch)
+        out['runs'] = n_runs
+        out['total_hbm_bytes_per_run_corrected'] = int(tot / n_runs)
+    # the library build the counters were taken on (content hash of the kernel sources): bench.py reports a mismatch as STALE
+    try:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from vec_vad_amd import build as _B
+        out['library_build'] = _B.wanted()[1][:16]
+    except Exception:
+        out['library_build'] = None
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(out['conv_family']))
 

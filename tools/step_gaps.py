@@ -2,12 +2,12 @@
 
     python tools/step_gaps.py <kernel_trace.csv>
 
-Takes the last 10 occurrences of `adam_kernel` as step boundaries and prints, per step: wall time between two optimizer launches,
+Takes the last 10 occurrences of the optimiser kernel (`adam_bucketed_kernel`) as step boundaries and prints, per step: wall time between two optimizer launches,
 the sum of kernel durations inside, and their difference (= launch gaps + host stalls)."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-ad = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+ad = [i for i, r in enumerate(rows) if 'adam_bucketed_kernel' in r['Kernel_Name'] or 'adam_kernel' in r['Kernel_Name']]
 for a, b in list(zip(ad[:-1], ad[1:]))[-10:]:
     seg = rows[a + 1:b + 1]
     wall = int(seg[-1]['End_Timestamp']) - int(rows[a]['End_Timestamp'])
