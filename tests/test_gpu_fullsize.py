@@ -94,10 +94,9 @@ def test_net4_b256_train_step_gradients_vs_oracle():
 
 def test_full_bank_bf16_b512_vs_mixed_oracle(monkeypatch):
     """BASELINE config 4 at full size: SelfCompleteNetFull (10 UNets), mixed bf16, B = 512.
-    Train-mode forward of the whole batch: loss_raw / loss_of rel <= 2e-3 of the mixed oracle on the same 512 cubes (the bar of
-    the small-batch mixed tests; rounding-boundary flips average out over 512 cubes: observed ~1e-4); per-cube train-mode scores
-    rel <= 2e-2 for every cube and rms <= 3e-3.  Eval-mode scores of a 4-cube subset rel <= 1e-2 (bar of
-    test_bf16_forward_matches_mixed_oracle).  One train step then leaves finite parameters that moved by <= 2*lr."""
+    Train-mode forward of the whole batch: loss_raw / loss_of rel <= 5e-5 of the mixed oracle on the same 512 cubes (observed
+    5.5e-7 / 2.4e-6: rounding-boundary flips average out over 512 cubes); per-cube train-mode scores rel <= 2e-2 for every cube and
+    rms <= 3e-3.  Eval-mode scores of a 4-cube subset rel <= 1e-4 (observed 1.7e-6).  One train step then leaves finite parameters that moved by <= 2*lr."""
     from oracle import unet_oracle as O
     from test_gpu_bf16 import _build_bf16
     from vec_vad_amd.trainer import FusedTrainer
@@ -119,8 +118,8 @@ def test_full_bank_bf16_b512_vs_mixed_oracle(monkeypatch):
     from _util import observe
     observe('full_bf16_b512 eval scores vs mixed oracle', raw=float(np.max(np.abs(r.cpu().numpy() - rs) / np.abs(rs))),
             of=float(np.max(np.abs(o.cpu().numpy() - os_) / np.abs(os_))))
-    np.testing.assert_allclose(r.cpu().numpy(), rs, rtol=1e-2)
-    np.testing.assert_allclose(o.cpu().numpy(), os_, rtol=1e-2)
+    np.testing.assert_allclose(r.cpu().numpy(), rs, rtol=1e-4)          # observed 1.7e-6 / 6.5e-7 (round 3); round 2's bar was 1e-2
+    np.testing.assert_allclose(o.cpu().numpy(), os_, rtol=1e-4)
     # train-mode forward of the full batch
     net.train()
     p0 = tr.bank.params.clone()
@@ -131,7 +130,8 @@ def test_full_bank_bf16_b512_vs_mixed_oracle(monkeypatch):
         _, lr_, lo_ = O.train_loss(oo, ro, ot, rt)
     lr_, lo_ = float(lr_), float(lo_)
     observe('full_bf16_b512 train losses vs mixed oracle', raw=abs(l_raw - lr_) / lr_, of=abs(l_of - lo_) / lo_)
-    assert abs(l_raw - lr_) <= 2e-3 * lr_ and abs(l_of - lo_) <= 2e-3 * lo_, (l_raw, lr_, l_of, lo_)
+    # observed 5.5e-7 / 2.4e-6 (round 3; rounding-boundary flips average out over 512 cubes); round 2's bar was 2e-3
+    assert abs(l_raw - lr_) <= 5e-5 * lr_ and abs(l_of - lo_) <= 5e-5 * lo_, (l_raw, lr_, l_of, lo_)
     r, o = tr.bank.cube_scores(ws)
     for got, ref in ((r.cpu().numpy(), O.cube_scores(ro, rt).numpy()), (o.cpu().numpy(), O.cube_scores(oo, ot).numpy())):
         rel = np.abs(got - ref) / ref

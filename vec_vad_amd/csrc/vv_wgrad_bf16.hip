@@ -464,45 +464,47 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   if (producer) {
     // ---- sources.  A block j covers input channels (cit2*CB + j)*32 ..: skip-concat layers take it from src0 (activated) or src1
     const VVSrc sa = vv_make_src(p, g, H, W);
-    __amdgpu_buffer_rsrc_t rsA[CB];
-    int csA[CB], coA[CB];
+    const char* ptrA[CB];          // channel 0 of block j at pixel 0 (bf16 elements)
+    int csA[CB];
     bool actA[CB];
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
       const int c0 = (cit2 * CB + j) * 32;
       const bool second = (sa.mode == VV_IN_CAT) && c0 >= sa.csplit;
-      rsA[j] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? sa.p1 : sa.p0), 0, 0x7FFFFFFF, 0x00020000);
       csA[j] = second ? sa.cs1 : sa.cs0;
-      coA[j] = (second ? sa.co1 - sa.csplit : sa.co0) + c0;
+      ptrA[j] = reinterpret_cast<const char*>(second ? sa.p1 : sa.p0) + 2 * (int64_t)((second ? sa.co1 - sa.csplit : sa.co0) + c0);
       actA[j] = (sa.mode == VV_IN_ACT) || (sa.mode == VV_IN_CAT && !second);
     }
-    const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy.ptr + (int64_t)g * p.dy.gstride), 0, 0x7FFFFFFF, 0x00020000);
-    const int csB = p.dy.cstride, coB = p.dy.coff + cot2 * OB * 32;
+    const int csB = p.dy.cstride;
+    const char* ptrB = reinterpret_cast<const char*>(p.dy.ptr + (int64_t)g * p.dy.gstride) + 2 * (int64_t)(p.dy.coff + cot2 * OB * 32);
     constexpr unsigned OOB = 0x80000000u;
-    // this lane's part of piece i of a tile (i is compile time): pixel (piece*16 + lane/4), 8 channels (lane%4)*8
+    // this lane's part of piece i of a tile (i is compile time): pixel (piece*16 + lane/4), 8 channels (lane%4)*8.  Its byte offset
+    // from the tile's first halo pixel never changes (the buffer descriptor moves with the tile), only its validity does: halo row 0 /
+    // AHH-1 of a tile at the top / bottom of its image, images past the batch.
     const int lq = lane & 3, lp = lane >> 2;
-    int pixA[NLA];             // (im*H + hy)*W + hx relative to the tile origin, or < 0: never valid (x outside / pad pixel)
+    unsigned voffA[NLA];
     short hyA[NLA], imA[NLA];
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
+      const int j = i / NPA;
       const int piece = (i % NPA) * 4 + wave;
       const int px = piece * 16 + lp;
       const int hx = px % AHW, t = px / AHW;
       hyA[i] = (short)(t % AHH);
       imA[i] = (short)(t / AHH);
-      const bool ok = piece < NA && px < APX && (unsigned)(hx - 1) < (unsigned)W;
-      pixA[i] = ok ? (imA[i] * H + hyA[i]) * W + hx : -(1 << 30);
+      const bool ok = piece < NA && px < APX && (unsigned)(hx - 1) < (unsigned)W && (cit2 * CB + j) * 32 + lq * 8 < p.CinP;
+      voffA[i] = ok ? (unsigned)(((imA[i] * H + hyA[i]) * W + hx) * csA[j] + lq * 8) * 2u : OOB;
     }
-    int pixB[NLB];
+    unsigned voffB[NLB];
     short imB[NLB];
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
+      const int j = i / NPB;
       const int piece = (i % NPB) * 4 + wave;
       const int px = piece * 16 + lp;
       const int t = px / TW;
       imB[i] = (short)(t / TH);
-      pixB[i] = piece < NB ? (imB[i] * H + t % TH) * W + px % TW : -(1 << 30);
+      voffB[i] = piece < NB ? (unsigned)(((imB[i] * H + t % TH) * W + px % TW) * csB + j * 32 + lq * 8) * 2u : OOB;
     }
     // BatchNorm scale / shift of this lane's 8 channels, packed for v_pk_fma_f32
     v2f sa2[CB][4], sb2[CB][4];
@@ -527,27 +529,32 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     // no memory traffic, zeros into a slot nobody reads -- the vmcnt arithmetic holds in the pipeline's tail)
     auto issue = [&](const int pt, const int slot, const bool live) __attribute__((always_inline)) {
       const int img0 = (pt / tpi) * NI;
-      const int ty0 = (pt % tpi) * TH;
-      const int tileA = (img0 * H + ty0 - 1) * W - 1;            // may be negative (top halo row of image 0)
-      const int tileB = (img0 * H + ty0) * W;
+      const int trow = pt % tpi;
+      const bool top = trow == 0, bot = trow == tpi - 1;        // (wave-uniform)
+      const int nimg = live ? p.B - img0 : 0;                   // images of this tile inside the batch
+      const int64_t pix0 = ((int64_t)img0 * H + trow * TH) * W;    // first output pixel of the tile in the [B][H][W] tensor
       const unsigned sl = (unsigned)(size_t)(lbase + slot * TB + wave * 1024);
       const unsigned dump = (unsigned)(size_t)(lbase + DUMP);
 #pragma unroll
-      for (int i = 0; i < NLA; ++i) {
-        const int j = i / NPA;                                    // A block of this piece (compile time)
-        const bool exists = (i % NPA) * 4 + wave < NA;            // (wave-uniform)
-        const int y = ty0 - 1 + hyA[i];
-        const bool ok = live && pixA[i] >= 0 && (unsigned)y < (unsigned)H && img0 + imA[i] < p.B && (cit2 * CB + j) * 32 + lq * 8 < p.CinP;
-        const unsigned off = ok ? (unsigned)((tileA + pixA[i]) * csA[j] + coA[j] + lq * 8) * 2u : OOB;
-        vv_glds16(rsA[j], __builtin_amdgcn_readfirstlane(exists ? sl + j * ASZB + (i % NPA) * 4096 : dump), off);
+      for (int j = 0; j < CB; ++j) {
+        // descriptor at the tile's first HALO pixel (one row and one column before its first output pixel; for the first tile of the
+        // tensor that is in front of the allocation -- those lanes are out of range by construction and never dereferenced)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(ptrA[j] + 2 * ((pix0 - W - 1) * (int64_t)csA[j])), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int ii = 0; ii < NPA; ++ii) {
+          const int i = j * NPA + ii;
+          const bool exists = ii * 4 + wave < NA;               // (wave-uniform)
+          const bool ok = !(top && hyA[i] == 0) && !(bot && hyA[i] == AHH - 1) && imA[i] < nimg;
+          vv_glds16(rs, __builtin_amdgcn_readfirstlane(exists ? sl + j * ASZB + ii * 4096 : dump), ok ? voffA[i] : OOB);
+        }
       }
+      const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ptrB + 2 * (pix0 * (int64_t)csB)), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NLB; ++i) {
         const int j = i / NPB;
         const bool exists = (i % NPB) * 4 + wave < NB;
-        const bool ok = live && pixB[i] >= 0 && img0 + imB[i] < p.B;
-        const unsigned off = ok ? (unsigned)((tileB + pixB[i]) * csB + coB + j * 32 + lq * 8) * 2u : OOB;
-        vv_glds16(rsB, __builtin_amdgcn_readfirstlane(exists ? sl + CB * ASZB + j * BSZB + (i % NPB) * 4096 : dump), off);
+        vv_glds16(rsB, __builtin_amdgcn_readfirstlane(exists ? sl + CB * ASZB + j * BSZB + (i % NPB) * 4096 : dump), imB[i] < nimg ? voffB[i] : OOB);
       }
     };
     // BatchNorm+ReLU of the producing layer, in place, on the 16 bytes this lane transferred of every activated A piece; zero
@@ -555,15 +562,15 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     // packed fp32 multiply-add, round to bf16 pairs, ReLU as a packed signed 16-bit max with 0 (negative bf16 = negative int16)
     auto activate = [&](const int pt, const int slot) __attribute__((always_inline)) {
       const int img0 = (pt / tpi) * NI;
-      const int ty0 = (pt % tpi) * TH;
+      const int trow = pt % tpi;
+      const bool top = trow == 0, bot = trow == tpi - 1;
       const vv_lds_t sl = lbase + slot * TB + wave * 1024 + lane * 16;
 #pragma unroll
       for (int i = 0; i < NLA; ++i) {
         const int j = i / NPA;
         if (!actA[j] || (i % NPA) * 4 + wave >= NA) continue;
         uint4* q = (uint4*)(sl + j * ASZB + (i % NPA) * 4096);
-        const int y = ty0 - 1 + hyA[i];
-        const bool ok = pixA[i] >= 0 && (unsigned)y < (unsigned)H && img0 + imA[i] < p.B;
+        const bool ok = voffA[i] != OOB && !(top && hyA[i] == 0) && !(bot && hyA[i] == AHH - 1) && img0 + imA[i] < p.B;
         const uint4 u = *q;
         const unsigned in[4] = {u.x, u.y, u.z, u.w};
         unsigned o[4];
