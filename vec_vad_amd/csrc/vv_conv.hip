@@ -44,7 +44,7 @@ struct Geo {
 // MR: 32-pixel row blocks per wave (2 = 256-pixel tiles; 1 = 128-pixel tiles, four workgroups per CU: the bf16 kernels on the 8x8 / 4x4
 // levels, where a launch has few, long workgroups and is bound by the chunk round trips)
 template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, int S16, int MR>      // S16: 0 fp32 sources, 1 plain bf16 src0, 2 ALL sources bf16
-__global__ void __launch_bounds__(VV_WG, MR == 1 ? 4 : ((BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2)))
+__global__ void __launch_bounds__(VV_WG, (MR == 1 && BF) ? 4 : ((BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2)))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
   constexpr int HH = G_::HH, HW = G_::HW, SP = G_::SP;
@@ -253,6 +253,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     bias[n] = p.bias ? p.bias[(int64_t)g * p.bias_gstride + co0 + n * 32 + l31] : 0.f;
     s1[n] = 0.f; s2[n] = 0.f;
   }
+  // VV_CONV_RELU: clamp at 0, else at -inf = a no-op that leaves every value bit-identical (the flag test hoisted out of the
+  // store loops: tested per element it cost the 64-wide bf16 data gradient at 32x32 85 us of 270)
+  const float relu_lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();
   bool tile_out = false;
   if constexpr (BF && KIND != VV_CONVT_FWD) tile_out = o16;
   if (tile_out) {
@@ -272,7 +275,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             float v = acc[m][n][i] + bias[n];
-            if (p.pad0 & VV_CONV_RELU) v = v < 0.f ? 0.f : v;      // NaN-propagating (fmaxf would drop a NaN)
+            v = v < relu_lo ? relu_lo : v;      // ReLU of the folded eval path; compare + select keeps a NaN (fmaxf would drop it)
             const __bf16 hv = (__bf16)v;
             lo[pp * ORS + n * 32 + l31] = __builtin_bit_cast(unsigned short, hv);
             v = ok ? (float)hv : 0.f;
@@ -323,7 +326,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             float v = acc[m][n][i] + bias[n];
-            if (p.pad0 & VV_CONV_RELU) v = v < 0.f ? 0.f : v;      // NaN-propagating (fmaxf would drop a NaN)      // eval mode: BatchNorm folded into the filter, ReLU in the epilogue
+            v = v < relu_lo ? relu_lo : v;      // eval mode: BatchNorm folded into the filter, ReLU in the epilogue (NaN-propagating: fmaxf would drop a NaN)
             if (o16) {
               const __bf16 hv = (__bf16)v;
               outh[e + n * 32] = hv;
@@ -407,6 +410,14 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   // K chunk: 16 channels (fp32: 8 for the stride-2 gather and the 16-image 4x4 tiles, whose halo tiles are large)
   constexpr int CKD = BF ? (KIND == VV_CONVT_DGRAD ? 16 : CK) : (KIND == VV_CONVT_DGRAD ? 8 : 16);   // bf16: 16 or 32 (template CK)
   constexpr int CK4 = BF ? 16 : 8;
+  if constexpr (!BF && KIND != VV_CONV3) {
+    // small batches (the per-rank batches of the reference's DataParallel split, train.py:375): a launch of the transposed conv on
+    // the 8x8 / 4x4 level has a few dozen 256-pixel tiles with 16-32 serial K chunks each -- 128-pixel tiles double the workgroups
+    if ((int64_t)p->G * nt * (p->Cout / 32) < 256) {
+      if (p->H == 8) return launch<8, 8, 2, 1, KIND, CKD, BF, S16, 1>(p, st);
+      if (p->H == 4) return launch<4, 4, 8, 1, KIND, CK4, BF, S16, 1>(p, st);
+    }
+  }
   if constexpr (KIND == VV_CONVT_FWD) {        // four phase accumulators: 32-wide N tiles only
     switch (p->H) {
       case 32: return launch<8, 32, 1, 1, KIND, CKD, BF, S16>(p, st);
