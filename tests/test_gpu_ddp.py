@@ -317,3 +317,30 @@ def test_uneven_global_batch_is_the_global_mean_gradient():
         num += float(((got - tot[name].double()) ** 2).sum())
         den += float((tot[name].double() ** 2).sum())
     assert num <= (2e-2 ** 2) * den, (num, den)          # 3- and 2-cube train-mode BatchNorm: tie flips dominate (cf. the small-batch tests)
+
+
+def test_bench_two_ranks_on_one_gpu_prints_one_valid_line():
+    """bench.py's N > 1 path end to end (the driver's SCALE run): two ranks under torch.distributed.run -- both on GPU 0 with the gloo
+    backend, the bring-up mode of bench.py (one GPU on this box; RCCL with N > 1 is the driver's to run) -- captured step in four
+    hipGraph segments with the three gradient exchanges between them.  Rank 0 prints ONE JSON line with the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VV_SINGLE_DEVICE='1', VV_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    port = 31900 + (os.getpid() % 1000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--batch', '16',
+           '--pool', '64', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['unit'] == 'cubes/s'
+    assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 32 * 6 / (d['ms_per_step'] * 6e-3)) <= 1e-6 * d['value']
+    assert d['comm']['rccl_ranks'] == 2 and len(d['comm']['buckets']) == 3
+    assert 0 < d['comm']['per_rank_cubes_per_s']['min'] <= d['comm']['per_rank_cubes_per_s']['max']
+    assert '4 segment' in d['execution']['mode'], d['execution']
+    assert 'configs' not in d and np.isfinite(d['config']['loss_raw'])
