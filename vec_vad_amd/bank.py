@@ -601,7 +601,9 @@ class UNetBank:
             nci, nco = (l.cinp + 31) // 32, l.cout // 32
             nt = lib.vv_wgrad_ntiles(L.CONV3, B, l.H, l.H)
             if self.wino_wgrad and not self.cflag:
-                ks = _pick_ksplit(Ga * nci * nco, nt, ncu=768, max_wg=3072)      # three workgroups per CU
+                # three workgroups per CU; 768 slots also at small batches (swept 256 / 384 / 512 / 768 at B = 32 and 256: fewer slabs
+                # shorten the grouped reduction but lengthen the weight-gradient launches by more)
+                ks = _pick_ksplit(Ga * nci * nco, nt, ncu=768, max_wg=3072)
             else:
                 ks = _pick_ksplit(Ga * nci * nco, nt)
             wplan['c%d' % l.idx] = (ks, nci * nco * ks)

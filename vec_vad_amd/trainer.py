@@ -204,14 +204,24 @@ class FusedTrainer:
                 after[label](events)
         main.wait_stream(self.side)
 
-    def _step(self, ws):
+    def _forward_train(self, ws):
+        """train-mode forward + its bookkeeping (BatchNorm's num_batches_tracked, folded eval model invalidated, backward plan built):
+        the part every kind of step shares"""
         bank = self.bank
-        stream = bank._stream()
-        self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], stream)
+        self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], bank._stream())
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
         bank.mark_dirty()
         if ws.bwd is None:
             ws.bwd = bank._plan_backward(ws, ws.B)
+
+    def _adam(self):
+        bank = self.bank
+        bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+
+    def _step(self, ws):
+        bank = self.bank
+        stream = bank._stream()
+        self._forward_train(ws)
         if self.overlap:
             if self.buckets is None:
                 self._run_dual(ws.bwd)
@@ -234,11 +244,11 @@ class FusedTrainer:
         if self.event_hook is not None and (self.event_labels is None or 'adam' in self.event_labels):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+            self._adam()
             e1.record()
             self.event_hook('adam', e0, e1)
         else:
-            bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+            self._adam()
         return ws
 
     def _finish_exchange(self):
@@ -367,20 +377,18 @@ class FusedTrainer:
         bank = self.bank
         b = int(idx.numel())
         ws = None
+        # (the bucketed exchange of the previous step has been joined by its finish(): nothing of it is pending on the comm stream)
+        assert self.buckets is None or not self.buckets.pending
         if b:
             ws = bank.set_input_cubes(raw_u8, flow, idx)
-            self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], bank._stream())
-            bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
-            bank.mark_dirty()
-            if ws.bwd is None:
-                ws.bwd = bank._plan_backward(ws, ws.B)
+            self._forward_train(ws)
             self._run(ws.bwd, bank._stream())
             bank.grads.mul_(b * self.world / float(n_global))
         else:
             bank.grads.zero_()
         if self.world > 1:
             dist.all_reduce(bank.grads, op=dist.ReduceOp.SUM, group=self.group)
-        bank.adam_step(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=1.0 / self.world)
+        self._adam()
         return ws
 
     def step_nchw(self, x, x_of):
