@@ -411,12 +411,13 @@ int dispatch(const vv_conv_params* p, hipStream_t st) {
   constexpr int CKD = BF ? (KIND == VV_CONVT_DGRAD ? 16 : CK) : (KIND == VV_CONVT_DGRAD ? 8 : 16);   // bf16: 16 or 32 (template CK)
   constexpr int CK4 = BF ? 16 : 8;
   if constexpr (!BF && KIND != VV_CONV3) {
-    // small batches (the per-rank batches of the reference's DataParallel split, train.py:375): a launch of the transposed conv on
-    // the 8x8 / 4x4 level has a few dozen 256-pixel tiles with 16-32 serial K chunks each -- 128-pixel tiles double the workgroups
-    if ((int64_t)p->G * nt * (p->Cout / 32) < 256) {
-      if (p->H == 8) return launch<8, 8, 2, 1, KIND, CKD, BF, S16, 1>(p, st);
-      if (p->H == 4) return launch<4, 4, 8, 1, KIND, CK4, BF, S16, 1>(p, st);
-    }
+    // fp32 transposed conv, 128-pixel tiles (one 32-pixel row block per wave, 64 accumulator registers per phase set): measured at
+    // B = 256 against the 256-pixel tiles -- forward 170 -> 131 us (4x4 level) and 155 -> 137 (8x8), 147 -> 158 at 16x16 (kept at 256
+    // there); stride-2 gather 178 -> 146 / 191 -> 155 / 188 -> 176 on the three levels.  At the per-rank batches of the reference's
+    // DataParallel split (train.py:375) they also double the workgroup count of launches that had a few dozen (B = 32: 99 -> 59 us).
+    if (p->H == 16 && KIND == VV_CONVT_DGRAD) return launch<8, 16, 1, 1, KIND, CKD, BF, S16, 1>(p, st);
+    if (p->H == 8) return launch<8, 8, 2, 1, KIND, CKD, BF, S16, 1>(p, st);
+    if (p->H == 4) return launch<4, 4, 8, 1, KIND, CK4, BF, S16, 1>(p, st);
   }
   if constexpr (KIND == VV_CONVT_FWD) {        // four phase accumulators: 32-wide N tiles only
     switch (p->H) {
