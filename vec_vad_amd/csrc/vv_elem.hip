@@ -939,6 +939,13 @@ static inline int bn_bp(int C) {
   bp = bp > 256 ? 256 : (bp < 16 ? 16 : bp);
   return bp & ~3;                       // whole 2x2 pooling windows
 }
+// the all-bf16 kernel (8 channels per lane, four pixels' loads in flight) likes blocks twice as large: swept 4096 / 8192 / 16384 per
+// C on BASELINE config 4: 2.86 / 2.36 / 2.26 ms of BatchNorm backward per step (the fp32 kernel: 1.08 / 1.08 / 1.11)
+static inline int bn_bp16(int C) {
+  int bp = 16384 / (C > 0 ? C : 1);
+  bp = bp > 512 ? 512 : (bp < 16 ? 16 : bp);
+  return bp & ~3;
+}
 
 // workgroups (= partial-sum blocks) per UNet: one per chunk of bn_bp(C) pixels, at most VV_BN_MAXBLK persistent ones.  Measured
 // with 256 persistent workgroups per UNet: the passes over the 32x32 tensors already run at 5.5-6 TB/s with one chunk per
@@ -951,19 +958,28 @@ extern "C" int vv_bn_bwd_nblk(int32_t B, int32_t H, int32_t W, int32_t C) {
   return (int)(n < VV_BN_MAXBLK ? n : VV_BN_MAXBLK);
 }
 
+// pixel block / block count of a launch with these parameters (<= vv_bn_bwd_nblk, which sizes the partial-sum buffer)
+static inline int bn_bp_of(const vv_bnbwd_params* p) { return bn_all16(p) ? bn_bp16(p->C) : bn_bp(p->C); }
+static inline int bn_nblk_of(const vv_bnbwd_params* p) {
+  const int64_t M = (int64_t)p->B * p->H * p->W;
+  const int bp = bn_bp_of(p);
+  const int64_t n = (M + bp - 1) / bp;
+  return (int)(n < VV_BN_MAXBLK ? n : VV_BN_MAXBLK);
+}
+
 extern "C" int vv_bn_bwd_reduce(const vv_bnbwd_params* p, vv_stream stream) {
   if (!p || !p->y || !p->dA.ptr || !p->dz || !p->partial) return VV_ERR_BAD_ARG;
   if (p->C % 4 || p->C > 1024 || VV_WG % (p->C / 4)) return VV_ERR_UNSUPPORTED;
-  const int nblk = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  const int nblk = bn_nblk_of(p);
   if (bn_all16(p)) {
     if (p->dpool)
-      VV_LAUNCH((bn_bwd16_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
+      VV_LAUNCH((bn_bwd16_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp_of(p), nullptr, 0, nullptr);
     else
-      VV_LAUNCH((bn_bwd16_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
+      VV_LAUNCH((bn_bwd16_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp_of(p), nullptr, 0, nullptr);
   } else if (p->dpool)
-    VV_LAUNCH((bn_bwd_reduce_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp_of(p), nullptr, 0, nullptr);
   else
-    VV_LAUNCH((bn_bwd_reduce_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp(p->C), nullptr, 0, nullptr);
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 0>), dim3(nblk, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk, bn_bp_of(p), nullptr, 0, nullptr);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -974,22 +990,22 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
   // VV_BNBWD_PARTIALS_PER_CUBE: the partials were left by vv_outconv_bwd (one block per cube), not by vv_bn_bwd_reduce
   // VV_BNBWD_PARTIALS_PER_TILE: ... by the Winograd data-gradient launch that produced dA (one block per pixel tile)
   const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B
-                   : (p->flags & VV_BNBWD_PARTIALS_PER_TILE) ? vv_wino_ntiles(p->B, p->H) : vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+                   : (p->flags & VV_BNBWD_PARTIALS_PER_TILE) ? vv_wino_ntiles(p->B, p->H) : bn_nblk_of(p);
   if (nblk <= 0) return VV_ERR_BAD_ARG;
-  const int nblk_apply = vv_bn_bwd_nblk(p->B, p->H, p->W, p->C);
+  const int nblk_apply = bn_nblk_of(p);
   const int64_t M = (int64_t)p->B * p->H * p->W;
   VV_LAUNCH(bn_bwd_sum_kernel, dim3((p->C + 31) / 32, p->G), dim3(32 * VV_NP), 0, (hipStream_t)stream, p->C, nblk, (double)M,
             p->partial, dgamma, dbeta, grad_gstride, scratch);
   VV_CHECK_LAUNCH();
   if (bn_all16(p)) {
     if (p->dpool)
-      VV_LAUNCH((bn_bwd16_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
+      VV_LAUNCH((bn_bwd16_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp_of(p), gamma, param_gstride, scratch);
     else
-      VV_LAUNCH((bn_bwd16_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
+      VV_LAUNCH((bn_bwd16_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp_of(p), gamma, param_gstride, scratch);
   } else if (p->dpool)
-    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
+    VV_LAUNCH((bn_bwd_reduce_kernel<true, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp_of(p), gamma, param_gstride, scratch);
   else
-    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp(p->C), gamma, param_gstride, scratch);
+    VV_LAUNCH((bn_bwd_reduce_kernel<false, 1>), dim3(nblk_apply, p->G), dim3(VV_WG), 0, (hipStream_t)stream, *p, nblk_apply, bn_bp_of(p), gamma, param_gstride, scratch);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
