@@ -355,7 +355,11 @@ int vv_channelnorm_fwd(const float* in, float* out, int32_t B, int32_t C, int32_
  * Generic NHWC MFMA convolution: kind 0 = nn.Conv2d(k=R in {1,3,5,7}, stride in {1,2}, padding=(R-1)/2),
  * kind 1 = nn.ConvTranspose2d(k4, s2, p1); optional bias; y = v > 0 ? v : slope*v  (slope 0.1 = LeakyReLU, 1.0 = none).
  * src: NHWC with cstride % 4 == 0 and coff % 4 == 0 (pad channels must hold finite values); out: any channel slice of
- * the consumer's concat buffer.  Weights packed by vv_pack_conv2d: [taps][CinP/8][2][CoutP][4], zero padded. */
+ * the consumer's concat buffer.  Weights packed by vv_pack_conv2d: [taps][CinP/8][2][CoutP][4], zero padded.
+ * kind 2 = the same nn.Conv2d in "row-K" form for the few-channel first layers (FlowNetC.py conv1: 7x7 s2 on 3 channels;
+ * FlowNetSD.py conv0: 3x3 s1 on 6): src.cstride = 4 (R = 7, stride 2) or 8 (R = 3, stride 1), src.coff = 0; K runs over the
+ * flattened (kx, c) run of one filter row, Cin = CinP = ceil8(R * cstride) (32 / 24), and the panel is packed with taps = R from a
+ * weight tensor rearranged to [N][kx * cstride + c][ky] (zeros at the pad channels and beyond kx = R - 1). */
 typedef struct vv_conv2d_params {
   int32_t kind, R, stride;
   int32_t B, H, W;          /* input size */

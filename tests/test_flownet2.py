@@ -42,6 +42,11 @@ CONV_CASES = [  # (kind, R, stride, Cin, Cout, H, W, relu)
     ('conv', 3, 1, 473, 256, 16, 24, True), ('conv', 3, 2, 256, 512, 16, 24, True), ('conv', 1, 1, 256, 32, 16, 24, True),
     ('conv', 3, 1, 1026, 2, 4, 6, False), ('conv', 3, 1, 194, 64, 32, 48, False), ('conv', 3, 1, 11, 64, 24, 40, True),
     ('conv', 3, 1, 82, 16, 20, 36, False), ('conv', 3, 1, 6, 64, 9, 33, True),
+    # the few-channel first layers take the row-K form of the kernel (vv_conv2d_mfma kind 2): ragged sizes, several tiles per row
+    ('conv', 7, 2, 3, 64, 37, 139, True), ('conv', 3, 1, 6, 64, 17, 70, False), ('conv', 7, 2, 3, 64, 16, 66, False),
+    # predict_flow heads at the small pyramid levels: one wave per filter tap (conv3x3_n2_tap_kernel with 32 / 16 / 64 lanes per pixel)
+    ('conv', 3, 1, 770, 2, 28, 20, False), ('conv', 3, 1, 386, 2, 40, 56, False), ('conv', 3, 1, 128, 2, 7, 9, False),
+    ('conv', 3, 1, 194, 2, 104, 100, False), ('conv', 3, 1, 16, 2, 120, 100, False), ('conv', 3, 1, 32, 2, 101, 103, False),
     ('deconv', 4, 2, 1024, 512, 2, 3, True), ('deconv', 4, 2, 1026, 256, 4, 6, True), ('deconv', 4, 2, 2, 2, 4, 6, False),
     ('deconv', 4, 2, 162, 16, 12, 20, True),
 ]

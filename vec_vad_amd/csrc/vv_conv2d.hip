@@ -15,7 +15,14 @@
 
 namespace {
 
-template <int R, int STRIDE, int DECONV, int NR, int CK>
+// CP > 0: "row-K" form for the few-channel first layers (FlowNetC conv1 7x7 s2 on 3 channels, FlowNetSD conv0 3x3 on 6): the source
+// pixels are exactly CP floats apart, so the R pixels under a filter ROW are one contiguous run of R*CP floats -- K walks that run
+// ((kx, c) flattened, padded to CK = ceil8(R*CP) with zero weights) and a "tap" is a filter row: 7 x 32 K steps instead of 49 taps
+// x 16 zero-padded channels (3.5x fewer MFMAs), 3 x 24 instead of 9 x 16 for the 6-channel layer.
+// N16: layers of at most 16 output channels (FlowNetSD / FlowNetFusion: 82 -> 16 3x3 and 162 -> 16 deconv at full / half
+// resolution) contract on v_mfma_f32_16x16x4_f32 -- 16 pixels x 16 channels x 4 K per instruction, a wave's 64 pixels as four M
+// blocks against one 16-wide N block -- instead of padding N to the 32 of the 32x32x2 tile (half the MFMA cycles; same panel).
+template <int R, int STRIDE, int DECONV, int NR, int CK, int CP = 0, int N16 = 0>
 __global__ void __launch_bounds__(VV_WG, 2)
 conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY, const int NN, const int total,
                    const int nper) {
@@ -23,20 +30,27 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
   constexpr int HH = DECONV ? TH + 2 : (TH - 1) * STRIDE + R;
   constexpr int HW = DECONV ? TW + 2 : (TW - 1) * STRIDE + R;
   constexpr int SP = DECONV ? 1 : STRIDE;
-  constexpr int S = CK + 4, S4 = S / 4;
+  constexpr int S = CP ? CP : CK + 4, S4 = S / 4;
+  constexpr int NCH = CP ? CP : CK;              // channels staged per halo pixel and chunk
   constexpr int MR = 2, TN = NR * 32;
-  constexpr int NTAP = DECONV ? 4 : R * R;
+  constexpr int NTAP = DECONV ? 4 : (CP ? R : R * R);
+  static_assert(!CP || (!DECONV && CP % 4 == 0 && CK % 8 == 0 && CK >= R * CP && CK < R * CP + 8), "row-K geometry");
   // 3x3 convolutions and the transposed convolution run the software pipeline of the UNet kernel (vv_conv.hip): the
   // activation halo tile AND the chunk's weight panel go global -> registers -> LDS one chunk ahead of the MFMA loop,
   // which reads only LDS, one ds_read_b128 after every group of 4 MFMAs.  5x5 / 7x7 (two layers per sub-network, weight
   // panels of 51 / 100 KB per chunk) keep the direct form: tile staged per chunk, weights from global/L2.
-  constexpr bool PIPE = DECONV || R == 3;
+  constexpr bool PIPE = (DECONV || R == 3) && !CP;
+  static_assert(!N16 || (PIPE && NR == 1 && CK % 16 == 0), "16-wide N: pipelined form, one N block");
   constexpr int KGC = CK / 8;
   constexpr int A4 = HH * HW * S4;
   constexpr int B4 = PIPE ? NTAP * KGC * 2 * TN : 0;
   constexpr int NBT = PIPE ? (B4 + VV_WG - 1) / VV_WG : 1;
-  __shared__ float4 lds4[A4 + B4];
+  __shared__ float4 lds4[A4 + B4 + (CP ? 2 : 0)];
   float* lds = reinterpret_cast<float*>(lds4);
+  if constexpr (CP != 0) {
+    // the K padding of the tile's last pixel reads past the tile: finite zeros there (they meet zero weights)
+    if (threadIdx.x < 2) lds4[A4 + B4 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
   const int KS = p.pad0 > 1 ? p.pad0 : 1;        // split-K over input-channel chunks (tiny-M, huge-K layers)
@@ -79,6 +93,10 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
     for (int n = 0; n < NR; ++n)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  v4f acc16[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc16[mb] = v4f{0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = CinP / CK;
   const int cbeg = (nchunk * ks / KS) * CK, cend = (nchunk * (ks + 1) / KS) * CK;
@@ -145,12 +163,48 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
       // (pinned by the sched_barrier of its MFMA group; an asm "+v"(v) here would force an lgkmcnt(0) wait right behind the read)
       return v;
     };
+    // ---- 16-wide N (v_mfma_f32_16x16x4_f32): lane = (pixel or channel l15, K quarter q); a K step is 16 channels
+    const int q16 = lane >> 4, l15 = lane & 15;
+    int ab16[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int pp = wave * 64 + mb * 16 + l15;
+      ab16[mb] = (((pp / TW) * SP) * HW + (pp % TW) * SP) * S4 + q16;
+    }
     if (cbeg < cend) issue(cbeg);
     for (int c0 = cbeg; c0 < cend; c0 += CK) {
       if (c0 != cbeg) __syncthreads();      // every wave finished reading the previous chunk
       commit();
       __syncthreads();
       if (c0 + CK < cend) issue(c0 + CK);
+      if constexpr (N16 != 0) {
+        constexpr int KG16 = CK / 16, NIT16 = NTAP * KG16;
+        auto rdA16 = [&](const int it, const int mb) -> v4f { return ldsA[ab16[mb] + aofft[it / KG16] + (it % KG16) * 4]; };
+        auto rdB16 = [&](const int it) -> v4f {
+          return ldsB[(((it / KG16) * KGC + 2 * (it % KG16) + (q16 >> 1)) * 2 + (q16 & 1)) * TN + l15];
+        };
+        v4f ga[2][4], gb[2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) ga[0][mb] = rdA16(0, mb);
+        gb[0] = rdB16(0);
+#pragma unroll
+        for (int it = 0; it < NIT16; ++it) {
+          const int cur = it & 1, nxt = cur ^ 1;
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            acc16[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[cur][mb].x, gb[cur].x, acc16[mb], 0, 0, 0);
+            acc16[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[cur][mb].y, gb[cur].y, acc16[mb], 0, 0, 0);
+            acc16[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[cur][mb].z, gb[cur].z, acc16[mb], 0, 0, 0);
+            acc16[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[cur][mb].w, gb[cur].w, acc16[mb], 0, 0, 0);
+            if (it + 1 < NIT16) {              // the next step's five fragments, spread over this step's four MFMA groups
+              ga[nxt][mb] = rdA16(it + 1, mb);
+              if (mb == 3) gb[nxt] = rdB16(it + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        continue;
+      }
       v4f fa[2][MR], fb[2][NR];
 #pragma unroll
       for (int m = 0; m < MR; ++m) fa[0][m] = rdA(0, m);
@@ -185,13 +239,13 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
     // 100 KB for 7x7) does not fit beside it in LDS, so the B fragments come from global/L2 -- two steps ahead of their
     // use (ring of three register sets), while the A fragments of the next step are read from LDS under the MFMAs.
     const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
-    VVStagerB<1, HH, HW, S, CK> stA;
+    VVStagerB<1, HH, HW, S, NCH> stA;
     stA.init(s, ox0, tid);
     constexpr int NST = NTAP * KGC;
     const int tapstride = KQ * 2 * CoutP * 4;                     // floats between consecutive taps of the packed panel
     auto rdA = [&](const int st, const int m) -> v4f {
       const int t = st / KGC, kg = st % KGC;
-      v4f v = ldsA[abase[m] + ((t / R) * HW + (t % R)) * S4 + kg * 2];
+      v4f v = ldsA[abase[m] + (CP ? t * HW : (t / R) * HW + (t % R)) * S4 + kg * 2];
       // (pinned by the sched_barrier of its MFMA group; an asm "+v"(v) here would force an lgkmcnt(0) wait right behind the read)
       return v;
     };
@@ -246,6 +300,31 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
   const int OH = DECONV ? 2 * H : (H + 2 * pad - R) / STRIDE + 1;
   const int OW = DECONV ? 2 * W : (W + 2 * pad - R) / STRIDE + 1;
   const int LH = DECONV ? H : OH, LW = DECONV ? W : OW;      // extent of the tile coordinate space
+  if constexpr (N16 != 0) {
+    // D of the 16x16 tile: lane (channel l15, row quarter q) holds pixels mb*16 + 4q + i, i = 0..3
+    const int q16 = lane >> 4, l15 = lane & 15;
+    const int co = co0 + l15;
+    const bool split = KS > 1;
+    float* base = split ? p.out.ptr + (int64_t)ks * p.B * OH * OW * CoutP : p.out.ptr + p.out.coff;
+    const int ocs = split ? CoutP : p.out.cstride;
+    const bool cok = split ? true : co < p.Cout;
+    const float b = (!split && p.bias && cok) ? p.bias[co] : 0.f;
+    const float slope = split ? 1.f : p.slope;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pp = wave * 64 + mb * 16 + q16 * 4 + i;
+        const int r = ty0 + pp / TW, c = tx0 + pp % TW;
+        if (r < LH && c < LW && cok) {
+          const int oy = DECONV ? 2 * r + py : r, ox = DECONV ? 2 * c + px : c;
+          float v = acc16[mb][i] + b;
+          v = v > 0.f ? v : v * slope;
+          base[((int64_t)(img * OH + oy) * OW + ox) * ocs + co] = v;
+        }
+      }
+    return;
+  }
   if (KS > 1) {
     // raw partial sums -> workspace [ks][B*OH*OW][CoutP]; vv_conv2d_splitk_finish adds them up (+ bias, activation)
     float* ws = p.out.ptr + (int64_t)ks * p.B * OH * OW * CoutP;
@@ -473,6 +552,145 @@ conv3x3_n2_split_kernel(const float* __restrict__ src, const int scs, const int 
   }
 }
 
+// The same layer on 4 x 16 pixel tiles for the 16 / 32-channel heads at full / half resolution: 4 waves x 64 pixels, wave v takes
+// channel slice v of the halo tile in LDS (its weights stay wave-uniform: scalar loads), the four slice sums meet in LDS in wave
+// order.  Four times the workgroups of the 8 x 32 form and no zero-padded channels: 29 -> 20 us (16 channels, 448 x 1024), 18 -> 11 us
+// (32 channels, 224 x 512).  With 64-channel chunks on the quarter-resolution maps it measured slower than the split form below.
+template <int CK>
+__global__ void __launch_bounds__(VV_WG)
+conv3x3_n2_tile_kernel(const float* __restrict__ src, const int scs, const int B, const int H, const int W, const int Cin,
+                       const float* __restrict__ wq, const int C4P, const float* __restrict__ bias, const float slope,
+                       float* __restrict__ out, const int ocs, const int tilesX, const int tilesY) {
+  constexpr int TH = 4, TW = 16, HH = TH + 2, HW = TW + 2, S4 = CK / 4 + 1, Q = CK / 4, QW = Q / 4;
+  static_assert(QW >= 1, "a float4 group per wave");
+  __shared__ float4 lds4[HH * HW * S4];
+  __shared__ float2 part[4][64];
+  int w = blockIdx.x;
+  const int tx = w % tilesX; w /= tilesX;
+  const int ty = w % tilesY;
+  const int img = w / tilesY;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane / TW, c = lane % TW;
+  const int C4 = (Cin + 3) >> 2;              // source pixels hold ceil4(Cin) finite floats
+  const float4* wq4 = reinterpret_cast<const float4*>(wq);
+  float a0 = 0.f, a1 = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    if (c0) __syncthreads();
+    // (all of a thread's loads in flight before its first LDS write)
+    constexpr int NIT = (HH * HW * Q + VV_WG - 1) / VV_WG;
+    float4 stg[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * VV_WG;
+      const int hp = it / Q, q = it % Q;
+      const int y = ty * TH - 1 + hp / HW, x = tx * TW - 1 + hp % HW;
+      stg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < HH * HW * Q && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (c0 >> 2) + q < C4)
+        stg[k] = *reinterpret_cast<const float4*>(src + ((int64_t)(img * H + y) * W + x) * scs + c0 + q * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * VV_WG;
+      if (it < HH * HW * Q) lds4[(it / Q) * S4 + it % Q] = stg[k];
+    }
+    __syncthreads();
+    const int g0 = (c0 >> 2) + wave * QW;      // this wave's first channel group of the chunk
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4* pa = lds4 + ((r + t / 3) * HW + (c + t % 3)) * S4 + wave * QW;
+      const float4* pw = wq4 + ((int64_t)t * C4P + g0) * 2;
+#pragma unroll
+      for (int k = 0; k < QW; ++k) {
+        if (g0 + k < C4P) {                     // (wave-uniform; the panel ends at C4P groups)
+          const float4 v = pa[k], w0 = pw[2 * k], w1 = pw[2 * k + 1];
+          a0 = fmaf(v.w, w0.w, fmaf(v.z, w0.z, fmaf(v.y, w0.y, fmaf(v.x, w0.x, a0))));
+          a1 = fmaf(v.w, w1.w, fmaf(v.z, w1.z, fmaf(v.y, w1.y, fmaf(v.x, w1.x, a1))));
+        }
+      }
+    }
+  }
+  part[wave][lane] = make_float2(a0, a1);
+  __syncthreads();
+  const int oy = ty * TH + r, ox = tx * TW + c;
+  if (wave == 0 && oy < H && ox < W) {
+    float v0 = ((part[0][lane].x + part[1][lane].x) + part[2][lane].x) + part[3][lane].x + (bias ? bias[0] : 0.f);
+    float v1 = ((part[0][lane].y + part[1][lane].y) + part[2][lane].y) + part[3][lane].y + (bias ? bias[1] : 0.f);
+    float* o = out + ((int64_t)(img * H + oy) * W + ox) * ocs;
+    o[0] = v0 > 0.f ? v0 : v0 * slope;
+    o[1] = v1 > 0.f ? v1 : v1 * slope;
+  }
+}
+
+// The small pyramid levels (under 20k pixels, up to 1026 channels) are chains of L2 round trips: the layer is launched as one
+// WAVE PER FILTER TAP -- a workgroup of nine waves owns 64 / LPT pixels, wave t multiplies tap t for all of them, LPT lanes share a
+// pixel and split its channel groups (all their loads in flight together), a shuffle tree sums the lanes, and the nine tap sums meet
+// in LDS in tap order (fixed order: bitwise reproducible).  Nine times the workgroups' worth of loads in flight of the form above.
+template <int LPT>
+__global__ void __launch_bounds__(576)
+conv3x3_n2_tap_kernel(const float* __restrict__ src, const int scs, const int B, const int H, const int W, const int Cin,
+                      const float* __restrict__ wq, const int C4P, const float* __restrict__ bias, const float slope,
+                      float* __restrict__ out, const int ocs) {
+  constexpr int PP = 64 / LPT;                // pixels per workgroup
+  __shared__ float2 part[9][PP];
+  const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+  const int sub = lane % LPT, pl = lane / LPT;
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t pix = (int64_t)blockIdx.x * PP + pl;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), img = (int)(pix / ((int64_t)W * H));
+  const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+  const bool live = pix < npix && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+  const int C4 = (Cin + 3) >> 2;
+  float a0 = 0.f, a1 = 0.f;
+  if (live) {
+    const float4* pa = reinterpret_cast<const float4*>(src + ((int64_t)(img * H + yy) * W + xx) * scs);
+    const float4* pw = reinterpret_cast<const float4*>(wq) + (int64_t)t * C4P * 2;
+    int k = sub;
+    for (; k + 3 * LPT < C4; k += 4 * LPT) {
+      float4 v[4], w0[4], w1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = pa[k + u * LPT];
+        w0[u] = pw[2 * (k + u * LPT)];
+        w1[u] = pw[2 * (k + u * LPT) + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 = fmaf(v[u].w, w0[u].w, fmaf(v[u].z, w0[u].z, fmaf(v[u].y, w0[u].y, fmaf(v[u].x, w0[u].x, a0))));
+        a1 = fmaf(v[u].w, w1[u].w, fmaf(v[u].z, w1[u].z, fmaf(v[u].y, w1[u].y, fmaf(v[u].x, w1[u].x, a1))));
+      }
+    }
+    for (; k < C4; k += LPT) {
+      const float4 v = pa[k], w0 = pw[2 * k], w1 = pw[2 * k + 1];
+      a0 = fmaf(v.w, w0.w, fmaf(v.z, w0.z, fmaf(v.y, w0.y, fmaf(v.x, w0.x, a0))));
+      a1 = fmaf(v.w, w1.w, fmaf(v.z, w1.z, fmaf(v.y, w1.y, fmaf(v.x, w1.x, a1))));
+    }
+  }
+#pragma unroll
+  for (int o = LPT / 2; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o);
+    a1 += __shfl_xor(a1, o);
+  }
+  if (sub == 0) part[t][pl] = make_float2(a0, a1);
+  __syncthreads();
+  if (threadIdx.x < PP) {
+    const int64_t q = (int64_t)blockIdx.x * PP + threadIdx.x;
+    if (q < npix) {
+      float v0 = part[0][threadIdx.x].x, v1 = part[0][threadIdx.x].y;
+#pragma unroll
+      for (int u = 1; u < 9; ++u) {
+        v0 += part[u][threadIdx.x].x;
+        v1 += part[u][threadIdx.x].y;
+      }
+      v0 += bias ? bias[0] : 0.f;
+      v1 += bias ? bias[1] : 0.f;
+      float* o = out + q * ocs;
+      o[0] = v0 > 0.f ? v0 : v0 * slope;
+      o[1] = v1 > 0.f ? v1 : v1 * slope;
+    }
+  }
+}
+
 // upsampled_flow*: nn.ConvTranspose2d(2, 2, 4, 2, 1[, bias]) (FlowNetC.py:53-60, FlowNetS.py:40-47, FlowNetSD.py:45-52,
 // FlowNetFusion.py:35-36): 2x2 taps x 2 channels per output -- one thread per output pixel.
 __global__ void __launch_bounds__(VV_WG)
@@ -507,7 +725,7 @@ deconv4x4_c2_kernel(const float* __restrict__ src, const int scs, const int B, c
   o[1] = v1 > 0.f ? v1 : v1 * slope;
 }
 
-template <int R, int STRIDE, int DECONV, int CK>
+template <int R, int STRIDE, int DECONV, int CK, int CP = 0>
 int launch2d(const vv_conv2d_params* p, hipStream_t st) {
   const int pad = (R - 1) / 2;
   const int LH = DECONV ? p->H : (p->H + 2 * pad - R) / STRIDE + 1;
@@ -515,13 +733,18 @@ int launch2d(const vv_conv2d_params* p, hipStream_t st) {
   const int tilesY = (LH + 7) / 8, tilesX = (LW + 31) / 32;
   const bool wide = p->CoutP % 64 == 0 && p->Cout > 32;
   const int NN = p->CoutP / (wide ? 64 : 32);
+  constexpr bool CAN16 = (DECONV || (R == 3 && STRIDE == 1)) && !CP && CK % 16 == 0;
   const int total = p->B * (DECONV ? 4 : 1) * NN * tilesY * tilesX * (p->pad0 > 1 ? p->pad0 : 1);
   const int nper = (total + 7) / 8;
   if (wide)
-    VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 2, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
+    VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 2, CK, CP>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
               total, nper);
-  else
-    VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 1, CK>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
+  else if (CAN16 && p->Cout <= 16 && p->CoutP == 32) {
+    if constexpr (CAN16)
+      VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 1, CK, 0, 1>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
+                total, nper);
+  } else
+    VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 1, CK, CP>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
               total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
@@ -531,10 +754,18 @@ int launch2d(const vv_conv2d_params* p, hipStream_t st) {
 
 extern "C" int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream) {
   if (!p || !p->src.ptr || !p->w || !p->out.ptr) return VV_ERR_BAD_ARG;
-  if (p->CinP % 16 || p->CoutP % 32 || p->src.cstride % 4 || p->src.coff % 4) return VV_ERR_BAD_ARG;
+  if ((p->kind != 2 && p->CinP % 16) || p->CoutP % 32 || p->src.cstride % 4 || p->src.coff % 4) return VV_ERR_BAD_ARG;
   if ((int64_t)p->B * p->H * p->W * p->src.cstride >= (1ll << 31)) return VV_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (p->kind == 1) return launch2d<4, 2, 1, 16>(p, st);
+  if (p->kind == 2) {
+    // row-K form (see conv2d_mfma_kernel, CP): pixels exactly cstride floats apart, Cin = CinP = ceil8(R * cstride) flattened
+    // (kx, c) indices per filter row, the panel packed with taps = R; split-K does not apply
+    if (p->src.coff != 0 || p->pad0 > 1 || p->Cin != p->CinP) return VV_ERR_BAD_ARG;
+    if (p->R == 7 && p->stride == 2 && p->src.cstride == 4 && p->CinP == 32) return launch2d<7, 2, 0, 32, 4>(p, st);
+    if (p->R == 3 && p->stride == 1 && p->src.cstride == 8 && p->CinP == 24) return launch2d<3, 1, 0, 24, 8>(p, st);
+    return VV_ERR_UNSUPPORTED;
+  }
   if (p->kind != 0) return VV_ERR_BAD_ARG;
   switch (p->R * 10 + p->stride) {
     case 11: return launch2d<1, 1, 0, 16>(p, st);
@@ -553,13 +784,32 @@ extern "C" int vv_conv3x3_n2(const float* src, int32_t src_cstride, int32_t B, i
   if ((int64_t)B * H * W * src_cstride >= (1ll << 31)) return VV_ERR_UNSUPPORTED;
   const int64_t npix = (int64_t)B * H * W;
   hipStream_t st = (hipStream_t)stream;
-  if (npix >= 100000) {                     // full / half resolution: enough pixels to fill the chip one per thread
+  if (npix >= 20000 && Cin <= 32) {
+    // the 16 / 32-channel heads at full / half resolution: 4 x 16 tiles, the four waves split the channels
+    const int tilesY = (H + 3) / 4, tilesX = (W + 15) / 16;
+    const dim3 grid(B * tilesY * tilesX);
+    if (Cin <= 16)
+      VV_LAUNCH(conv3x3_n2_tile_kernel<16>, grid, dim3(VV_WG), 0, st, src, src_cstride, B, H, W, Cin, wq, C4P, bias, slope,
+                out + out_coff, out_cstride, tilesX, tilesY);
+    else
+      VV_LAUNCH(conv3x3_n2_tile_kernel<32>, grid, dim3(VV_WG), 0, st, src, src_cstride, B, H, W, Cin, wq, C4P, bias, slope,
+                out + out_coff, out_cstride, tilesX, tilesY);
+  } else if (npix >= 100000) {              // full / half resolution, more channels: 8 x 32 tiles, one thread per pixel
     const int tilesY = (H + 7) / 8, tilesX = (W + 31) / 32;
     VV_LAUNCH(conv3x3_n2_kernel, dim3(B * tilesY * tilesX), dim3(VV_WG), 0, st, src, src_cstride, B, H, W, Cin, wq, C4P, bias,
               slope, out + out_coff, out_cstride, tilesX, tilesY);
-  } else if (npix >= 20000) {
+  } else if (npix >= 20000) {               // quarter resolution: 8 lanes per pixel, the 9x re-read served by L2
     VV_LAUNCH(conv3x3_n2_split_kernel<8>, dim3((unsigned)((npix * 8 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,
               src_cstride, B, H, W, Cin, wq, C4P, bias, slope, out + out_coff, out_cstride);
+  } else if (Cin >= 320) {
+    // many channels on a small map: one wave per filter tap (fewer channels leave its lanes idle: the split form below)
+    const int lpt = npix >= 4096 ? 16 : (npix >= 1024 ? 32 : 64);
+    const dim3 grid((unsigned)((npix * lpt + 63) / 64));
+#define VV_N2_TAP(L_)                                                                                                        \
+    VV_LAUNCH(conv3x3_n2_tap_kernel<L_>, grid, dim3(576), 0, st, src, src_cstride, B, H, W, Cin, wq, C4P, bias, slope,       \
+              out + out_coff, out_cstride)
+    if (lpt == 16) VV_N2_TAP(16); else if (lpt == 32) VV_N2_TAP(32); else VV_N2_TAP(64);
+#undef VV_N2_TAP
   } else if (npix >= 4096) {                // H/8: 7168 pixels x up to 386 channels -- 32 lanes per pixel fill the chip
     VV_LAUNCH(conv3x3_n2_split_kernel<32>, dim3((unsigned)((npix * 32 + VV_WG - 1) / VV_WG)), dim3(VV_WG), 0, st, src,
               src_cstride, B, H, W, Cin, wq, C4P, bias, slope, out + out_coff, out_cstride);

@@ -676,8 +676,12 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
         else if constexpr (TW == 16) { im = 0; rbase = 8 * strip; c0 = 8 * half; }
         else { im = 2 * strip + half; rbase = 0; c0 = 0; }
         const int R = rbase + r0;
-        const vv_lds_t xp = xt + ((im * AHH + R) * AHW + c0 + trj) * 64;
-        const vv_lds_t yp = yt + ((im * TH + R) * TW + c0 + trj) * 64;
+        vv_lds_t xp = xt + ((im * AHH + R) * AHW + c0 + trj) * 64;
+        vv_lds_t yp = yt + ((im * TH + R) * TW + c0 + trj) * 64;
+        // one address register per operand stream, opaque to the optimiser: every read below is that register plus an immediate
+        // (left alone, the slot rotation is strength-reduced into ~30 per-read address registers bumped by VALU adds every tile,
+        // which the MFMAs of the same SIMD then wait behind)
+        asm volatile("" : "+v"(xp), "+v"(yp));
         // operands one K step ahead of the MFMAs that consume them: a ring of four halo rows x three column shifts, two dy operands
         v8bf win[4][3], bq[2];
 #pragma unroll
@@ -689,10 +693,16 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
           constexpr int k = KK.value;
           if constexpr (k + 1 < RL) {
             constexpr int ro = (k + 3) * AHW * 64;
+            // (dy first: the next step's first six MFMAs need only it of these eight reads -- their halo rows are older)
+            bq[(k + 1) & 1] = vv_tr8(yp, (k + 1) * TW * 64, ((k + 1) * TW + 4) * 64);
             win[(k + 3) % 4][0] = vv_tr8(xp, ro + 0 * 64, ro + 4 * 64);
+#if defined(VV_EXPR) && VV_EXPR == 7
+            win[(k + 3) % 4][1] = win[(k + 3) % 4][0];             // elimination run: one halo-row read instead of three
+            win[(k + 3) % 4][2] = win[(k + 3) % 4][0];
+#else
             win[(k + 3) % 4][1] = vv_tr8(xp, ro + 1 * 64, ro + 5 * 64);
             win[(k + 3) % 4][2] = vv_tr8(xp, ro + 2 * 64, ro + 6 * 64);
-            bq[(k + 1) & 1] = vv_tr8(yp, (k + 1) * TW * 64, ((k + 1) * TW + 4) * 64);
+#endif
           }
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)

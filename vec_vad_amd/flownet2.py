@@ -11,6 +11,7 @@ output, no fallback.
 
 ``with_bn`` must be False and ``fp16`` False (what VEC_VAD instantiates, flownet2.py:12-17).
 """
+import os
 import ctypes as C
 
 import torch
@@ -18,6 +19,11 @@ import torch.nn as nn
 
 from . import _lib as L
 from .flow_ops import Correlation, Resample2d, ChannelNorm, correlation, resample2d, channelnorm
+
+
+# split-K: a tiny-map layer is split until its workgroups fill the chip ONCE (256 CUs); 512 measured 0.17 ms slower per forward
+# (twice the partial-sum traffic through vv_conv2d_splitk_finish), 128 / 192 leave half the chip idle
+_KS_TARGET = int(os.environ.get('VV_FN2_KS_TARGET', '256'))
 
 
 def _c4(c):
@@ -167,6 +173,38 @@ class _Runner:
                                        bias, slope, dst.t.data_ptr(), dst.cs, dst_coff, stream), 'conv3x3_n2')
         return True
 
+    def _rowk(self, m, src, dst, dst_coff, slope, stream):
+        """Few-channel first layers (FlowNetC conv1: 7x7 s2 on 3 channels; FlowNetSD conv0: 3x3 s1 on 6): vv_conv2d_mfma kind 2,
+        K = the flattened (kx, c) run under one filter row instead of taps x 16 zero-padded channels."""
+        R, stride, cs = m.kernel_size[0], m.stride[0], src.cs
+        if os.environ.get('VV_FN2_ROWK', '1') == '0' or (R, stride, cs) not in ((7, 2, 4), (3, 1, 8)) or m.kernel_size[1] != R:
+            return False
+        pad = (R - 1) // 2
+        if m.padding != (pad, pad) or m.in_channels != src.C or src.C > cs:
+            return False
+        KF = (R * cs + 7) // 8 * 8
+        N = m.out_channels
+        NP = _c32(N)
+        key = ('rowk', id(m))
+        ver = (m.weight.data_ptr(), m.weight._version)
+        ent = self.cache.get(key)
+        if ent is None or ent[0] != ver:
+            w = m.weight.detach().float()                                  # [N][Cin][ky][kx]
+            wr = torch.zeros(N, KF, R, device=w.device, dtype=torch.float32)
+            wr[:, :R * cs].view(N, R, cs, R)[:, :, :m.in_channels] = w.permute(0, 3, 1, 2)      # [N][kx][c][ky]
+            packed = torch.empty(R * KF * NP, device=w.device, dtype=torch.float32)
+            L.check(self.lib.vv_pack_conv2d(wr.data_ptr(), packed.data_ptr(), R, KF, KF, N, NP, 0,
+                                            torch.cuda.current_stream(w.device).cuda_stream), 'pack_conv2d (row-K)')
+            ent = (ver, packed)
+            self.cache[key] = ent
+        OH, OW = (src.H + 2 * pad - R) // stride + 1, (src.W + 2 * pad - R) // stride + 1
+        assert (dst.H, dst.W) == (OH, OW) and dst_coff + N <= dst.cs
+        bias = m.bias.data_ptr() if m.bias is not None else None
+        p = L.Conv2dParams(2, R, stride, src.B, src.H, src.W, KF, KF, N, NP, src.view(0), ent[1].data_ptr(), bias, slope, 0,
+                           dst.view(dst_coff))
+        L.check(self.lib.vv_conv2d_mfma(C.byref(p), stream), 'conv2d row-K %dx%d s%d %d->%d' % (R, R, stride, m.in_channels, N))
+        return True
+
     def __call__(self, layer, src, dst, dst_coff=0):
         if self.hook is None:
             return self._launch(layer, src, dst, dst_coff)
@@ -195,6 +233,8 @@ class _Runner:
         stream = torch.cuda.current_stream(src.t.device).cuda_stream
         if m.out_channels == 2 and self._flow_head(m, de, src, dst, dst_coff, slope, stream):
             return dst
+        if not de and self._rowk(m, src, dst, dst_coff, slope, stream):
+            return dst
         packed = self._packed(m)
         _, _, K, KP, N, NP = self.cache[id(m)]
         assert K == src.C, (K, src.C)
@@ -216,7 +256,7 @@ class _Runner:
         nchunk = KP // (16 if (de or stride == 1) else 8)
         ks = 1
         if wgs < 256 and nchunk >= 4:
-            ks = max(1, min(nchunk // 2, 512 // wgs, 16))
+            ks = max(1, min(nchunk // 2, _KS_TARGET // wgs, 16))
         if ks > 1:
             M = src.B * OH * OW
             ws = torch.empty(ks * M * NP, device=src.t.device, dtype=torch.float32)
