@@ -47,6 +47,9 @@ CONV_CASES = [  # (kind, R, stride, Cin, Cout, H, W, relu)
     # predict_flow heads at the small pyramid levels: one wave per filter tap (conv3x3_n2_tap_kernel with 32 / 16 / 64 lanes per pixel)
     ('conv', 3, 1, 770, 2, 28, 20, False), ('conv', 3, 1, 386, 2, 40, 56, False), ('conv', 3, 1, 128, 2, 7, 9, False),
     ('conv', 3, 1, 194, 2, 104, 100, False), ('conv', 3, 1, 16, 2, 120, 100, False), ('conv', 3, 1, 32, 2, 101, 103, False),
+    # the H/64 level runs 8 x 16 pixel tiles (maps at most 16 wide), with and without split-K
+    ('conv', 3, 1, 1024, 1024, 7, 16, True), ('conv', 3, 2, 512, 1024, 14, 32, True), ('conv', 3, 1, 96, 64, 5, 13, True),
+    ('deconv', 4, 2, 1024, 512, 7, 16, True),
     ('deconv', 4, 2, 1024, 512, 2, 3, True), ('deconv', 4, 2, 1026, 256, 4, 6, True), ('deconv', 4, 2, 2, 2, 4, 6, False),
     ('deconv', 4, 2, 162, 16, 12, 20, True),
 ]

@@ -22,17 +22,19 @@ namespace {
 // N16: layers of at most 16 output channels (FlowNetSD / FlowNetFusion: 82 -> 16 3x3 and 162 -> 16 deconv at full / half
 // resolution) contract on v_mfma_f32_16x16x4_f32 -- 16 pixels x 16 channels x 4 K per instruction, a wave's 64 pixels as four M
 // blocks against one 16-wide N block -- instead of padding N to the 32 of the 32x32x2 tile (half the MFMA cycles; same panel).
-template <int R, int STRIDE, int DECONV, int NR, int CK, int CP = 0, int N16 = 0>
+// TW = 16: 8 x 16 pixel tiles (one 32-pixel M block per wave) for the H/64 level -- a 7 x 16 map fills 44 % of an 8 x 32 tile.
+template <int R, int STRIDE, int DECONV, int NR, int CK, int CP = 0, int N16 = 0, int TW = 32>
 __global__ void __launch_bounds__(VV_WG, 2)
 conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY, const int NN, const int total,
                    const int nper) {
-  constexpr int TH = 8, TW = 32;
+  constexpr int TH = 8;
+  static_assert(TW == 32 || (TW == 16 && !N16 && !CP), "tile width");
   constexpr int HH = DECONV ? TH + 2 : (TH - 1) * STRIDE + R;
   constexpr int HW = DECONV ? TW + 2 : (TW - 1) * STRIDE + R;
   constexpr int SP = DECONV ? 1 : STRIDE;
   constexpr int S = CP ? CP : CK + 4, S4 = S / 4;
   constexpr int NCH = CP ? CP : CK;              // channels staged per halo pixel and chunk
-  constexpr int MR = 2, TN = NR * 32;
+  constexpr int MR = TW / 16, TN = NR * 32;
   constexpr int NTAP = DECONV ? 4 : (CP ? R : R * R);
   static_assert(!CP || (!DECONV && CP % 4 == 0 && CK % 8 == 0 && CK >= R * CP && CK < R * CP + 8), "row-K geometry");
   // 3x3 convolutions and the transposed convolution run the software pipeline of the UNet kernel (vv_conv.hip): the
@@ -82,7 +84,7 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
   int abase[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
-    const int pp = wave * 64 + m * 32 + l31;
+    const int pp = wave * (32 * MR) + m * 32 + l31;
     const int r = pp / TW, c = pp % TW;
     abase[m] = ((r * SP) * HW + c * SP) * S4 + half;
   }
@@ -333,7 +335,7 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-        const int pp = wave * 64 + m * 32 + row;
+        const int pp = wave * (32 * MR) + m * 32 + row;
         const int r = ty0 + pp / TW, c = tx0 + pp % TW;
         if (r < LH && c < LW) {
           const int oy = DECONV ? 2 * r + py : r, ox = DECONV ? 2 * c + px : c;
@@ -360,7 +362,7 @@ conv2d_mfma_kernel(const vv_conv2d_params p, const int tilesX, const int tilesY,
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-      const int pp = wave * 64 + m * 32 + row;
+      const int pp = wave * (32 * MR) + m * 32 + row;
       const int r = ty0 + pp / TW, c = tx0 + pp % TW;
       if (r < LH && c < LW) {
         const int oy = DECONV ? 2 * r + py : r, ox = DECONV ? 2 * c + px : c;
@@ -730,13 +732,18 @@ int launch2d(const vv_conv2d_params* p, hipStream_t st) {
   const int pad = (R - 1) / 2;
   const int LH = DECONV ? p->H : (p->H + 2 * pad - R) / STRIDE + 1;
   const int LW = DECONV ? p->W : (p->W + 2 * pad - R) / STRIDE + 1;
-  const int tilesY = (LH + 7) / 8, tilesX = (LW + 31) / 32;
+  const bool narrow = LW <= 16 && !CP;          // the H/64 level: 8 x 16 tiles
+  const int tilesY = (LH + 7) / 8, tilesX = narrow ? 1 : (LW + 31) / 32;
   const bool wide = p->CoutP % 64 == 0 && p->Cout > 32;
   const int NN = p->CoutP / (wide ? 64 : 32);
   constexpr bool CAN16 = (DECONV || (R == 3 && STRIDE == 1)) && !CP && CK % 16 == 0;
   const int total = p->B * (DECONV ? 4 : 1) * NN * tilesY * tilesX * (p->pad0 > 1 ? p->pad0 : 1);
   const int nper = (total + 7) / 8;
-  if (wide)
+  if (narrow && wide) {
+    if constexpr (CP == 0)
+      VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 2, CK, 0, 0, 16>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
+                total, nper);
+  } else if (wide)
     VV_LAUNCH((conv2d_mfma_kernel<R, STRIDE, DECONV, 2, CK, CP>), dim3(nper * 8), dim3(VV_WG), 0, st, *p, tilesX, tilesY, NN,
               total, nper);
   else if (CAN16 && p->Cout <= 16 && p->CoutP == 32) {
