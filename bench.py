@@ -485,10 +485,16 @@ def run_flownet2(dev, reps=10):
     # per-family launch timings (eager; events bracket single launches)
     fam = {}
     net._runner.hook = lambda label, flop, a, b: fam.setdefault(label, []).append((flop, a, b))
+    overlap = os.environ.get('VV_FN2_OVERLAP')
+    os.environ['VV_FN2_OVERLAP'] = '0'          # one stream: a launch's events then bracket that launch alone
     for _ in range(2):
         net(x)
     torch.cuda.synchronize()
     net._runner.hook = None
+    if overlap is None:
+        del os.environ['VV_FN2_OVERLAP']
+    else:
+        os.environ['VV_FN2_OVERLAP'] = overlap
     fams = {}
     for k, v in fam.items():
         t = sum(a.elapsed_time(b) for _, a, b in v) * 1e-3

@@ -94,7 +94,7 @@ def test_upsample4_vs_torch():
 
 
 @pytest.mark.gpu
-def test_flownet2_hip_vs_oracle_and_golden():
+def test_flownet2_hip_vs_oracle_and_golden(monkeypatch):
     from oracle import flownet2_oracle as FO
     torch.set_num_threads(8)
     net, sd, g = _seeded_sd()
@@ -112,6 +112,10 @@ def test_flownet2_hip_vs_oracle_and_golden():
     assert torch.equal(out_g, out)
     out_g2 = net.forward_graphed(inp.cuda()).cpu()
     assert torch.equal(out_g2, out)
+    # FlowNetSD runs on a second stream beside the FlowNetC -> S1 -> S2 chain: the serial schedule gives the same bits
+    monkeypatch.setenv('VV_FN2_OVERLAP', '0')
+    assert torch.equal(net(inp.cuda()).cpu(), out)
+    monkeypatch.delenv('VV_FN2_OVERLAP')
     with pytest.raises(Exception):
         net(inp)            # CPU tensor: no fallback
 

@@ -1,5 +1,6 @@
 """Per-layer timing of the FlowNet2 forward (eager, HIP events around every conv / deconv launch): shape, GFLOP, us, TFLOP/s."""
 import os, sys
+os.environ['VV_FN2_OVERLAP'] = '0'          # one stream: a launch's events bracket that launch alone
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vec_vad_amd import flownet2 as F2

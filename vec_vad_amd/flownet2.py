@@ -583,6 +583,7 @@ class FlowNet2(nn.Module):
         self._runner = None
         self._graphs = {}
         self._pool = _Pool()
+        self._side = {}          # device -> the second stream FlowNetSD runs on
 
     @torch.no_grad()
     def forward(self, inputs):
@@ -625,10 +626,28 @@ class FlowNet2(nn.Module):
                                        float(self.div_flow), float(self.div_flow), out.t.data_ptr(), st), 'warp_pack12')
             return out
 
+        # FlowNetSD reads only x (flownet2.py:96-98): it runs on a second HIP stream beside the FlowNetC -> S1 -> S2 chain and
+        # joins in front of the fusion network.  At one image pair most layers below H/8 are a single wave of workgroups (or a
+        # split-K launch sized to one chip fill): two independent sub-networks in flight fill the CUs such launches leave idle.
+        # Same kernels, same per-kernel summation order: the result is bit-identical to the serial schedule (VV_FN2_OVERLAP=0).
+        # Measured 6.00 -> 5.81 ms per forward.  (Finer forks -- each level's flow head beside its deconv -- measured +-0; NESTED
+        # forks, a fork on the already forked FlowNetSD stream, crash hipStreamEndCapture in this ROCm, so there is one level.)
+        main = torch.cuda.current_stream(dev)
+        side = None
+        if os.environ.get('VV_FN2_OVERLAP', '1') != '0':
+            side = self._side.get(dev)
+            if side is None:
+                side = self._side[dev] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sd_flow2 = self.flownets_d.run(run, x6)
         c_flow2 = self.flownetc.run(run, img0, img1)
         s1_flow2 = self.flownets_1.run(run, warp_pack(c_flow2))
         s2_flow2 = self.flownets_2.run(run, warp_pack(s1_flow2))
-        sd_flow2 = self.flownets_d.run(run, x6)
+        if side is None:
+            sd_flow2 = self.flownets_d.run(run, x6)
+        else:
+            main.wait_stream(side)
         cat3 = _Buf(B, H, W, 11, dev)
         L.check(lib.vv_fusion_pack11(x6.t.data_ptr(), img1.t.data_ptr(), s2_flow2.t.data_ptr(), s2_flow2.cs, sd_flow2.t.data_ptr(),
                                      sd_flow2.cs, B, H, W, float(self.div_flow), cat3.t.data_ptr(), st), 'fusion_pack11')
