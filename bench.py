@@ -404,6 +404,10 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
                         else 'eager launch loop (ctypes), HIP events around the conv-family launches in every timed step',
                         'launches_per_step': cap.launches if cap is not None else len(ws.fwd[True].calls) + len(ws.bwd.calls) + 3,
                         'host_enqueue_ms_per_step': 1e3 * t_host / steps}
+    if graph and cap is not None:
+        # 'free': the captured backward pass has two branches (weight gradients beside the data-gradient / BatchNorm chain), so
+        # kernels of the replayed steps overlap; the roofline durations above come from the one-stream eager steps
+        rec['execution']['backward_schedule'] = getattr(cap, 'schedule', 'one stream')
     if small_batch_diag and graph:
         # the same workload on the eager launch loop, for the launch-overhead comparison (outside the timed region)
         trainer.use_graph = False

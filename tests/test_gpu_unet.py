@@ -253,8 +253,9 @@ def test_side_stream_weight_grad_is_bitwise_identical():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize('precision,kind,B', [('fp32', 'net4', 32), ('fp32', 'net4', 16), ('bf16', 'full', 24)])
-def test_hipgraph_step_and_scoring_bitwise_equal_to_eager(monkeypatch, precision, kind, B):
+@pytest.mark.parametrize('precision,kind,B,sched', [('fp32', 'net4', 32, None), ('fp32', 'net4', 16, '0'), ('bf16', 'full', 24, None),
+                                                   ('fp32', 'net4', 24, 'paired'), ('bf16', 'net4', 40, 'free')])
+def test_hipgraph_step_and_scoring_bitwise_equal_to_eager(monkeypatch, precision, kind, B, sched):
     """The captured train step (cube gather + forward + backward + Adam with device-side step scalars) and the captured scoring
     pass replay bit for bit what the eager launch loop computes -- with different cubes every step (static index buffer), over
     enough steps that Adam's bias corrections matter, at the per-rank batch sizes of the reference's DataParallel split
@@ -262,6 +263,9 @@ def test_hipgraph_step_and_scoring_bitwise_equal_to_eager(monkeypatch, precision
     from oracle import unet_oracle as O
     from vec_vad_amd.trainer import FusedTrainer
     monkeypatch.setenv('VV_PRECISION', precision)
+    # the captured step's backward pass runs the weight gradients as a parallel graph branch (default 'free'; '0': one stream)
+    if sched is not None:
+        monkeypatch.setenv('VV_GRAPH_OVERLAP', sched)
     tot_of = 1 if kind == 'net4' else 5
     raw, flow = O.seeded_cubes(3 * B, tot_of, 21)
     rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
