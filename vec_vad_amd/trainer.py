@@ -165,8 +165,10 @@ class FusedTrainer:
             if after is not None and label in after:
                 after[label]()
 
-    def _run_dual(self, plan, after=None):
-        """Two-stream executor of a plan: meta = (stream id, events to wait for, event to record)."""
+    def _run_dual(self, plan, after=None, lo=0, hi=None):
+        """Two-stream executor of a plan: meta = (stream id, events to wait for, event to record).  lo / hi: run calls [lo, hi) only
+        (a segment of a captured multi-rank step; the side stream is joined at the end of every segment, so an event recorded in an
+        earlier segment has completed by stream order and is not waited for)."""
         dev = self.bank.device
         main = torch.cuda.current_stream(dev)
         streams = (main, self.side)
@@ -174,14 +176,14 @@ class FusedTrainer:
         events = {}
         hook, labels = self.event_hook, self.event_labels
         paired = self.overlap == 'paired'
-        for (fn, args, label), (sid, waits, rec, pwaits) in zip(plan.calls, plan.meta):
+        for (fn, args, label), (sid, waits, rec, pwaits) in list(zip(plan.calls, plan.meta))[lo:hi]:
             st = streams[sid]
             for w in (pwaits if paired else waits):
                 if w == '*main':
                     st.wait_stream(main)
                 elif w == '*side':
                     st.wait_stream(self.side)
-                else:
+                elif w in events or lo == 0:
                     st.wait_event(events[w])
             timed = hook is not None and (labels is None or label in labels)
             if timed:
@@ -274,9 +276,8 @@ class FusedTrainer:
         weight gradients (one workgroup per CU, MFMA-bound) are a parallel branch of the hipGraph beside the data-gradient /
         BatchNorm-backward chain -- measured 9.41 -> 9.22 ms at B = 256, 2.12 -> 1.95 ms at B = 32, 1.66 -> 1.52 ms at B = 16
         (fp32 Net4), bit-identical to the one-stream order; 'paired' measured slower than one stream.  VV_GRAPH_OVERLAP =
-        0 | free | paired overrides.  With a gradient exchange (world > 1) the step stays one stream per segment."""
-        if self.buckets is not None:
-            return None
+        0 | free | paired overrides.  With a gradient exchange (world > 1) every captured segment between two bucket launches forks
+        and joins on its own."""
         v = os.environ.get('VV_GRAPH_OVERLAP', 'free')
         return v if v in ('free', 'paired') else None
 
@@ -322,24 +323,32 @@ class FusedTrainer:
         seg.append(nbt)
         segments = []
         dual = self._graph_dual(B)
-        if dual:
-            # two-stream backward inside the captured step (one rank): the weight gradients become a parallel branch of the hipGraph
-            # (plan.meta: their stream, the events they wait for / record)
-            def bwd_dual(st, mode=dual):
+
+        def bwd_dual(lo, hi, mode=dual):
+            # two-stream backward inside the captured step: the weight gradients of calls [lo, hi) become a parallel branch of the
+            # hipGraph (plan.meta: their stream, the events they wait for / record), joined at the end of the range
+            def run(st):
                 if self.side is None:
                     self.side = torch.cuda.Stream(device=bank.device)
                 keep_mode, self.overlap = self.overlap, mode
                 try:
-                    self._run_dual(ws.bwd)
+                    self._run_dual(ws.bwd, lo=lo, hi=hi)
                 finally:
                     self.overlap = keep_mode
-            seg.append(bwd_dual)
-        for c in (() if dual else ws.bwd.calls):
-            seg.append(self._thunk(*c))
+            return run
+        lo = 0
+        for i, c in enumerate(ws.bwd.calls):
+            if not dual:
+                seg.append(self._thunk(*c))
             if self.buckets is not None and c[2] in (self.split_label, self.split_label_mid):
                 k = 2 if c[2] == self.split_label else 1
+                if dual:
+                    seg.append(bwd_dual(lo, i + 1))
+                    lo = i + 1
                 segments.append((seg, (lambda k=k: self.buckets.launch(k))))
                 seg = []
+        if dual:
+            seg.append(bwd_dual(lo, len(ws.bwd.calls)))
         if self.buckets is not None:
             segments.append((seg, self._finish_exchange))
             seg = []
@@ -354,7 +363,8 @@ class FusedTrainer:
         segments.append((seg, None))
         cap = type('Captured', (), {})()
         cap.ws, cap.idx, cap.keep = ws, idx, keep
-        cap.launches = sum(len(t) for t, _ in segments) + (len(ws.bwd.calls) - 1 if dual else 0)
+        nseg_bwd = 1 + (2 if self.buckets is not None else 0)
+        cap.launches = sum(len(t) for t, _ in segments) + (len(ws.bwd.calls) - nseg_bwd if dual else 0)
         cap.schedule = dual or 'one stream'
         cap.segments = self._capture(segments)
         return cap
