@@ -19,6 +19,11 @@ pmc() {  # pmc <tag> <runs> <cmd...>: FETCH_SIZE / WRITE_SIZE passes -> pmc_hbm_
   python $R/tools/make_pmc_mfma.py $O/pm/*/*counter_collection.csv $O/pmc_mfma_busy$tag.json > $O/mfma$tag.txt
   rm -rf $O/pf $O/pw $O/pm
 }
+# Per-kernel counters and per-kernel durations are collected on the ONE-STREAM schedule (VV_GRAPH_OVERLAP=0: the captured train step
+# without its parallel weight-gradient branch; VV_FN2_OVERLAP=0: FlowNetSD behind the FlowNetC -> S1 -> S2 chain): with two kernels
+# in flight a device-wide counter or a launch duration no longer belongs to one kernel.  bench.py's roofline durations are measured
+# the same way (its eager, one-stream event steps).  The default (overlapped) schedules are profiled separately below (*_overlap).
+export VV_GRAPH_OVERLAP=0 VV_FN2_OVERLAP=0
 pmc "" 5 $B --steps 3 --warmup 2
 pmc _bf16_full_b512 5 $C4 --steps 3 --warmup 2
 pmc _flownet2 13 $F
@@ -36,7 +41,12 @@ stats bf16_full_b512 $C4 --steps 10 --warmup 3
 stats net4_b32 $B --batch 32 --steps 30 --warmup 5
 python $R/tools/step_gaps.py $O/kernel_trace_net4_b32.csv x > $O/step_gaps_net4_b32.txt
 stats flownet2 $F
+unset VV_GRAPH_OVERLAP VV_FN2_OVERLAP
+stats net4_b256_overlap $B --steps 20 --warmup 5
+stats net4_b32_overlap $B --batch 32 --steps 30 --warmup 5
+stats flownet2_overlap python $R/tools/bench_flownet2.py
 rm -f $O/kernel_trace_*.csv
+python $R/tools/profile_flownet2_layers.py 2> /dev/null > $O/flownet2_layers.txt
 $B --batch 32 --steps 30 --no-graph --breakdown > /dev/null 2> $O/breakdown_net4_b32.txt
 $B --steps 10 --no-graph --breakdown > /dev/null 2> $O/breakdown_net4_b256.txt
 $C4 --steps 10 --warmup 3 --no-graph --breakdown > /dev/null 2> $O/breakdown_bf16_full_b512.txt
