@@ -252,7 +252,7 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
 
 
 def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap='none', breakdown=False, pool=4096,
-             measure_forward=True, graph=True, ev_steps=2, small_batch_diag=False):
+             measure_forward=True, graph=True, ev_steps=1, small_batch_diag=False):
     """W untimed + exactly K timed train steps; returns the record (rank 0) -- value is the whole-job rate.
 
     graph=True (default): the train step is replayed from a hipGraph (FusedTrainer, captured during the warm-up).  The first

@@ -263,6 +263,12 @@ class UNetBank:
             mx = max(mx, 9 * KP * N)
         self.pack_table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(d)
         self.pack_n, self.pack_max = len(direct), mx
+        # the panels of the first two conv layers come first in both tables: the forward plan packs them on the main stream and the
+        # rest (every later layer's forward panel, all data-gradient and transposed-conv panels) as a parallel branch that joins in
+        # front of the third conv (two-stream / captured schedules; a one-stream executor simply runs them in plan order)
+        head = lambda k: k[0] == 'c' and int(k[1:k.index('.')]) <= 1
+        self.pack_head_n = sum(1 for k, _ in direct if head(k))
+        assert all(head(k) for k, _ in direct[:self.pack_head_n])
         wents = (L.PackEntry * len(lay.pkw))()
         wmx = 0
         for i, (k, (off, mode, K, KP, N, src)) in enumerate(lay.pkw.items()):
@@ -270,6 +276,8 @@ class UNetBank:
             wmx = max(wmx, KP * N)
         self.pack_table_w = torch.frombuffer(bytearray(bytes(wents)), dtype=torch.uint8).to(d)
         self.pack_w_n, self.pack_w_max = len(lay.pkw), wmx
+        self.pack_w_head_n = sum(1 for k in lay.pkw if head(k))
+        assert all(head(k) for k in list(lay.pkw)[:self.pack_w_head_n])
         # ---- eval mode (test.py:255-257,312-345; train.py:413-427): running-statistics BatchNorm is a constant affine map, so it is
         # folded into the filter + bias of the convolution in front of it ONCE per model state (vv_fold_bn -> params_eval ->
         # packed_eval), the producing conv applies the ReLU (VV_CONV_RELU) and every consumer reads plain values: no per-forward
@@ -429,10 +437,22 @@ class UNetBank:
         U, UB, UP = lay.U, lay.UB, lay.UP
         P = _Plan()
         pbase, bbase, kbase = self._p(self.params, g0 * U), self._p(self.bufs, g0 * UB), self._p(self.packed, g0 * UP)
-        P.add(lib.vv_pack_weights, (self.pack_table.data_ptr(), self.pack_n, Ga, pbase, U, kbase, UP, self.pack_max), 'pack')
-        if self.wino:
-            P.add(lib.vv_pack_wino, (self.pack_table_w.data_ptr(), self.pack_w_n, Ga, pbase, U, kbase, UP, self.pack_w_max),
-                  'pack_wino')
+        es = C.sizeof(L.PackEntry)
+        hn, whn = self.pack_head_n, self.pack_w_head_n
+        pack_tail = []          # events the third conv layer waits for (the tail packs run on the side stream)
+        ts = 0 if os.environ.get('VV_PACK_TAIL_MAIN', '0') == '1' else 1      # A/B switch: 1 = everything on the main stream
+        if hn:
+            P.add(lib.vv_pack_weights, (self.pack_table.data_ptr(), hn, Ga, pbase, U, kbase, UP, self.pack_max), 'pack')
+        if self.wino and whn:
+            P.add(lib.vv_pack_wino, (self.pack_table_w.data_ptr(), whn, Ga, pbase, U, kbase, UP, self.pack_w_max), 'pack_wino')
+        if self.pack_n > hn:
+            P.add(lib.vv_pack_weights, (self.pack_table.data_ptr() + hn * es, self.pack_n - hn, Ga, pbase, U, kbase, UP, self.pack_max),
+                  'pack_tail', stream=ts, record='pack_tail')
+            pack_tail.append('pack_tail')
+        if self.wino and self.pack_w_n > whn:
+            P.add(lib.vv_pack_wino, (self.pack_table_w.data_ptr() + whn * es, self.pack_w_n - whn, Ga, pbase, U, kbase, UP,
+                                     self.pack_w_max), 'pack_wino_tail', stream=ts, record='pack_wino_tail')
+            pack_tail.append('pack_wino_tail')
         abg = lay.cmax
 
         def conv(l):
@@ -443,7 +463,8 @@ class UNetBank:
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
-            P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
+            P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx,
+                  wait=tuple(pack_tail) if l.idx == 2 else ())
             nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag)
             P.add(lib.vv_bn_finalize,
                   (Ga, l.cout, nt, B * l.H * l.H, 1 if train else 0, 0.1, 1e-5, ws.stats.data_ptr(), nt * 2 * l.cout,

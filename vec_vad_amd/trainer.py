@@ -316,26 +316,31 @@ class FusedTrainer:
         seg = [self._thunk(lib.vv_cube_gather, (B, bank.tot_raw, bank.tot_of, HWp, idx.data_ptr(), raw_u8.data_ptr(),
                                                 flow.data_ptr() if flow is not None else None, ws.cube.data_ptr(),
                                                 ws.flow.data_ptr()), 'cube_gather')]
-        seg += [self._thunk(*c) for c in (ws.fwd if self.keep_outputs else ws.fwdq)[True].calls]
-
-        def nbt(st):           # torch op on the capturing stream: BatchNorm's num_batches_tracked (views of bank.nbt)
-            bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
-        seg.append(nbt)
-        segments = []
+        fwd = (ws.fwd if self.keep_outputs else ws.fwdq)[True]
         dual = self._graph_dual(B)
 
-        def bwd_dual(lo, hi, mode=dual):
-            # two-stream backward inside the captured step: the weight gradients of calls [lo, hi) become a parallel branch of the
-            # hipGraph (plan.meta: their stream, the events they wait for / record), joined at the end of the range
+        def dual_range(plan, lo, hi, mode=dual):
+            # two-stream execution of plan calls [lo, hi) inside the capture: launches the plan marks for the side stream (the
+            # weight gradients of the backward pass, the packing of the later layers' weight panels in the forward pass) become a
+            # parallel branch of the hipGraph (plan.meta: stream, events waited for / recorded), joined at the end of the range
             def run(st):
                 if self.side is None:
                     self.side = torch.cuda.Stream(device=bank.device)
                 keep_mode, self.overlap = self.overlap, mode
                 try:
-                    self._run_dual(ws.bwd, lo=lo, hi=hi)
+                    self._run_dual(plan, lo=lo, hi=hi)
                 finally:
                     self.overlap = keep_mode
             return run
+        if dual:
+            seg.append(dual_range(fwd, 0, len(fwd.calls)))
+        else:
+            seg += [self._thunk(*c) for c in fwd.calls]
+
+        def nbt(st):           # torch op on the capturing stream: BatchNorm's num_batches_tracked (views of bank.nbt)
+            bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+        seg.append(nbt)
+        segments = []
         lo = 0
         for i, c in enumerate(ws.bwd.calls):
             if not dual:
@@ -343,12 +348,12 @@ class FusedTrainer:
             if self.buckets is not None and c[2] in (self.split_label, self.split_label_mid):
                 k = 2 if c[2] == self.split_label else 1
                 if dual:
-                    seg.append(bwd_dual(lo, i + 1))
+                    seg.append(dual_range(ws.bwd, lo, i + 1))
                     lo = i + 1
                 segments.append((seg, (lambda k=k: self.buckets.launch(k))))
                 seg = []
         if dual:
-            seg.append(bwd_dual(lo, len(ws.bwd.calls)))
+            seg.append(dual_range(ws.bwd, lo, len(ws.bwd.calls)))
         if self.buckets is not None:
             segments.append((seg, self._finish_exchange))
             seg = []
@@ -364,7 +369,7 @@ class FusedTrainer:
         cap = type('Captured', (), {})()
         cap.ws, cap.idx, cap.keep = ws, idx, keep
         nseg_bwd = 1 + (2 if self.buckets is not None else 0)
-        cap.launches = sum(len(t) for t, _ in segments) + (len(ws.bwd.calls) - nseg_bwd if dual else 0)
+        cap.launches = sum(len(t) for t, _ in segments) + (len(ws.bwd.calls) - nseg_bwd + len(fwd.calls) - 1 if dual else 0)
         cap.schedule = dual or 'one stream'
         cap.segments = self._capture(segments)
         return cap
