@@ -323,6 +323,9 @@ class _Decoder:
         return flow_of(net.predict_flow2, src)
 
 
+_TOWER_STREAMS = {}
+
+
 class FlowNetC(nn.Module):
     def __init__(self, with_bn=False, fp16=False):
         super().__init__()
@@ -361,12 +364,24 @@ class FlowNetC(nn.Module):
         nb = lambda h, w, c: _Buf(B, h, w, c, dev)
         cat2 = nb(H // 4, W // 4, 194)
         c1a, c1b = nb(H // 2, W // 2, 64), nb(H // 2, W // 2, 64)
-        run(self.conv1, img0, c1a); run(self.conv1, img1, c1b)
         c2b = nb(H // 4, W // 4, 128)
         c2a_view = _SliceView(cat2, 0, 128)
-        run(self.conv2, c1a, cat2, 0); run(self.conv2, c1b, c2b)
         c3a, c3b = nb(H // 8, W // 8, 256), nb(H // 8, W // 8, 256)
-        run(self.conv3, c2a_view, c3a); run(self.conv3, c2b, c3b)
+        # the two towers of the siamese front end are independent up to the correlation: the second image's tower runs on its own
+        # stream (a sibling of the FlowNetSD branch, forked from the same stream -- not nested).  conv2 / conv3 are 224-workgroup
+        # launches at one image pair: two of them together fill the 256 CUs twice instead of 7/8 once
+        main = torch.cuda.current_stream(dev)
+        tower = None
+        if os.environ.get('VV_FN2_OVERLAP', '1') not in ('0', 'sd'):
+            tower = _TOWER_STREAMS.get(str(dev))
+            if tower is None:
+                tower = _TOWER_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+            tower.wait_stream(main)
+        with torch.cuda.stream(tower if tower is not None else main):
+            run(self.conv1, img1, c1b); run(self.conv2, c1b, c2b); run(self.conv3, c2b, c3b)
+        run(self.conv1, img0, c1a); run(self.conv2, c1a, cat2, 0); run(self.conv3, c2a_view, c3a)
+        if tower is not None:
+            main.wait_stream(tower)
         in31 = nb(H // 8, W // 8, 473)
         # corr + corr_activation + the cat with conv_redir (FlowNetC.py:88-96,120): one launch on the NHWC maps, written
         # into channels [32, 473) of conv3_1's input; widths the specialised kernel does not cover take the generic op
@@ -630,19 +645,29 @@ class FlowNet2(nn.Module):
         # joins in front of the fusion network.  At one image pair most layers below H/8 are a single wave of workgroups (or a
         # split-K launch sized to one chip fill): two independent sub-networks in flight fill the CUs such launches leave idle.
         # Same kernels, same per-kernel summation order: the result is bit-identical to the serial schedule (VV_FN2_OVERLAP=0).
-        # Measured 6.00 -> 5.81 ms per forward.  (Finer forks -- each level's flow head beside its deconv -- measured +-0; NESTED
-        # forks, a fork on the already forked FlowNetSD stream, crash hipStreamEndCapture in this ROCm, so there is one level.)
+        # Forked when FlowNetC is done (VV_FN2_SD_AT=1): beside FlowNetC's full-chip front end it only contends, beside S1 -> S2 it
+        # fills gaps.  Measured per forward: serial 6.00 ms; forked at the start 5.83, after FlowNetC 5.71, after S1 5.74.
+        # (Finer forks -- each level's flow head beside its deconv -- measured +-0; NESTED forks, a fork on the already forked
+        # FlowNetSD stream, crash hipStreamEndCapture in this ROCm, so there is one level: this one and FlowNetC's second tower.)
         main = torch.cuda.current_stream(dev)
         side = None
         if os.environ.get('VV_FN2_OVERLAP', '1') != '0':
             side = self._side.get(dev)
             if side is None:
                 side = self._side[dev] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                sd_flow2 = self.flownets_d.run(run, x6)
+            at = int(os.environ.get('VV_FN2_SD_AT', '1'))
+
+        def fork_sd(point):
+            if side is not None and at == point:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    return self.flownets_d.run(run, x6)
+            return None
+        sd_flow2 = fork_sd(0)
         c_flow2 = self.flownetc.run(run, img0, img1)
+        sd_flow2 = fork_sd(1) or sd_flow2
         s1_flow2 = self.flownets_1.run(run, warp_pack(c_flow2))
+        sd_flow2 = fork_sd(2) or sd_flow2
         s2_flow2 = self.flownets_2.run(run, warp_pack(s1_flow2))
         if side is None:
             sd_flow2 = self.flownets_d.run(run, x6)
