@@ -19,6 +19,11 @@ pmc() {  # pmc <tag> <runs> <cmd...>: FETCH_SIZE / WRITE_SIZE passes -> pmc_hbm_
   python $R/tools/make_pmc_mfma.py $O/pm/*/*counter_collection.csv $O/pmc_mfma_busy$tag.json > $O/mfma$tag.txt
   rm -rf $O/pf $O/pw $O/pm
 }
+# The bench line first, on the fresh box, the way the driver runs it (after ten minutes of profiling runs the same command measured
+# 1-2 % lower); its `traffic` comes from the counter files already in profiles/ -- `traffic_source` says STALE if the kernels changed
+# since they were taken, in which case run this script twice.
+python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+tail -c 400 $O/bench.err
 # Per-kernel counters and per-kernel durations are collected on the ONE-STREAM schedule (VV_GRAPH_OVERLAP=0: the captured train step
 # without its parallel weight-gradient branch; VV_FN2_OVERLAP=0: FlowNetSD behind the FlowNetC -> S1 -> S2 chain): with two kernels
 # in flight a device-wide counter or a launch duration no longer belongs to one kernel.  bench.py's roofline durations are measured
@@ -50,8 +55,6 @@ python $R/tools/profile_flownet2_layers.py 2> /dev/null > $O/flownet2_layers.txt
 $B --batch 32 --steps 30 --no-graph --breakdown > /dev/null 2> $O/breakdown_net4_b32.txt
 $B --steps 10 --no-graph --breakdown > /dev/null 2> $O/breakdown_net4_b256.txt
 $C4 --steps 10 --warmup 3 --no-graph --breakdown > /dev/null 2> $O/breakdown_bf16_full_b512.txt
-python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-tail -c 400 $O/bench.err
 python - <<PY
 import json
 d=json.load(open('$O/bench.json'))
