@@ -106,7 +106,13 @@ def test_bank_layout_and_plan_construction():
     units = [UnitSpec('raw', i, i) for i in range(5)] + [UnitSpec('of', 4, 0)]
     b = UNetBank(units, nf=32, device='cpu')
     ws = b.workspace(5)
-    assert len(ws.fwd[True].calls) == 37 + int(b.wino)   # pack (+ pack_wino), cube_erase, 14 x (conv + bn), 3 pool, 3 convT, 1x1 out
+    fl = [c[2] for c in ws.fwd[True].calls]
+    packs = [x for x in fl if x.startswith('pack')]
+    # the weight panels: the first two conv layers on the main stream, the rest as a side branch that joins in front of conv2
+    assert packs == (['pack_wino', 'pack_tail', 'pack_wino_tail'] if b.wino else ['pack', 'pack_tail']) and fl[:len(packs)] == packs
+    meta = dict(zip(fl, ws.fwd[True].meta))
+    assert meta['pack_tail'][0] == 1 and 'pack_tail' in meta['conv2'][1] and meta['conv1'][1] == ()
+    assert len(fl) - len(packs) == 36                    # cube_erase, 14 x (conv + bn), 3 pool, 3 convT, 1x1 out
     ws.bwd = b._plan_backward(ws, 5)
     labels = [c[2] for c in ws.bwd.calls]
     assert labels.index('dgradT0') < labels.index('bn_bwd_reduce7')      # decoder bucket is complete before the encoder
