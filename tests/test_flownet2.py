@@ -116,6 +116,10 @@ def test_flownet2_hip_vs_oracle_and_golden(monkeypatch):
     monkeypatch.setenv('VV_FN2_OVERLAP', '0')
     assert torch.equal(net(inp.cuda()).cpu(), out)
     monkeypatch.delenv('VV_FN2_OVERLAP')
+    for at in ('0', '2'):          # ... and so does every fork point of the FlowNetSD branch (default: after FlowNetC)
+        monkeypatch.setenv('VV_FN2_SD_AT', at)
+        assert torch.equal(net(inp.cuda()).cpu(), out)
+    monkeypatch.delenv('VV_FN2_SD_AT')
     with pytest.raises(Exception):
         net(inp)            # CPU tensor: no fallback
 
