@@ -228,7 +228,9 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
     b_alg = sum(by[k] * len(v) for k, v in per.items() if k in fl)
     common = {'launches_timed': n, 'avg_launch_us': 1e6 * t / n, 'algorithmic_gflop_per_launch': f_alg / n / 1e9,
               'algorithmic_mbytes_per_launch': b_alg / n / 1e6, 'traffic': traffic[0], 'traffic_source': traffic[1],
-              'side_stream_weight_grad': overlap}
+              # the launches above were timed in eager steps on ONE stream (overlap == 'none') or on the eager two-stream
+              # executor (--overlap); the graph-replayed steps of the timed region follow execution.backward_schedule
+              'timed_on': 'one stream (eager event steps)' if overlap == 'none' else 'eager two-stream executor (%s)' % overlap}
     if precision == 'fp32':
         r = {'bound': 'mfma',
              'kernel': ('wino_conv_kernel<H>: 3x3 conv forward + data-gradient as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32'
