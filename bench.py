@@ -22,7 +22,9 @@ Rank 0 prints ONE JSON line.
                 thread count, best-of sweep AND the all-cores figure, train step and eval forward.
   configs       secondary records measured in the same run (N=1 only): BASELINE config 4 (SelfCompleteNetFull, B=512, mixed
                 bf16), config 5 (FlowNet2 forward on a 1024x448 pair) and the eval-mode scoring pass, each with its own roofline.
-  comm          (N>1) rccl_ranks, per-bucket all-reduce time and the exposed communication per step.
+  comm          (N>1) ranks + backend, per-bucket all-reduce time and the exposed communication per step.
+The scalar headline of every secondary record is repeated inside ``config`` (cfg4_cubes_per_s, flownet2_ms_per_pair, net4_b32_ms ...)
+so that a consumer that keeps only the top-level keys of the line still has them.
 """
 import argparse
 import json
@@ -84,7 +86,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed.  This is a
     number read from profiles/, not something this run measured (PMC collection needs rocprofv3 around the process)."""
-    for n in (name, name.replace('r03_', 'r02_'), name.replace('r03_', 'r01_')):
+    for n in (name, name.replace('r04_', 'r03_'), name.replace('r04_', 'r02_'), name.replace('r04_', 'r01_')):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], _profile_tag(n, d)
@@ -254,13 +256,15 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
 
 
 def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap='none', breakdown=False, pool=4096,
-             measure_forward=True, graph=True, ev_steps=1, small_batch_diag=False):
+             measure_forward=True, graph=True, ev_steps=1, small_batch_diag=False, ev_extra=4):
     """W untimed + exactly K timed train steps; returns the record (rank 0) -- value is the whole-job rate.
 
     graph=True (default): the train step is replayed from a hipGraph (FusedTrainer, captured during the warm-up).  The first
     ``ev_steps`` of the K timed steps run the eager launch loop with HIP events around every launch of the dominant kernel family
-    (the roofline's live per-launch durations); the remaining steps replay the captured step.  graph=False / --breakdown / a
-    side-stream schedule: every timed step is eager with events (the round-2 behaviour)."""
+    (the roofline's live per-launch durations); the remaining steps replay the captured step.  ``ev_extra`` further eager event
+    steps run right AFTER the timed region (same trainer, next batches) so that the roofline rests on (ev_steps + ev_extra) x 27
+    launches instead of one sample per layer -- the record says how many were inside and how many after.  graph=False /
+    --breakdown / a side-stream schedule: every timed step is eager with events (the round-2 behaviour)."""
     from vec_vad_amd.trainer import FusedTrainer
     net, tot_of = build_net(model, precision, dev)
     trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
@@ -273,7 +277,8 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     raw = torch.randint(0, 256, (pool, 5, 32, 32, 3), dtype=torch.uint8, generator=g).to(dev)
     flow = (torch.randn((pool, tot_of, 32, 32, 2), generator=g) * 2.0).to(dev)
-    perm = torch.stack([torch.randperm(pool, generator=g)[:B] for _ in range(steps + warmup)]).to(dev)
+    ev_extra = ev_extra if graph else 0
+    perm = torch.stack([torch.randperm(pool, generator=g)[:B] for _ in range(steps + warmup + ev_extra)]).to(dev)
     for it in range(warmup):
         trainer.step_cubes(raw, flow, perm[it])
     torch.cuda.synchronize()
@@ -310,10 +315,16 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
         allt = [torch.zeros_like(tl) for _ in range(world)]
         dist.all_gather(allt, tl)
         per_rank = [B * steps / float(x.item()) for x in allt]
+    n_in = len(ev)
+    if ev_extra and n_ev > 0:          # more samples for the roofline, outside the timed region (the step itself is unchanged)
+        trainer.event_hook = hook
+        for it in range(ev_extra):
+            trainer.step_cubes(raw, flow, perm[warmup + steps + it])
+        torch.cuda.synchronize()
     trainer.event_hook = None
     comm = None
     if trainer.buckets is not None and not diag_comm:
-        comm = {'rccl_ranks': world, 'backend': dist.get_backend() if dist is not None else None,
+        comm = {'ranks': world, 'backend': dist.get_backend() if dist is not None else None,
                 'buckets': [{'bucket': k, 'columns': [trainer.buckets.bounds[k], trainer.buckets.bounds[k + 1]],
                              'mbytes': 4e-6 * bank.G * (trainer.buckets.bounds[k + 1] - trainer.buckets.bounds[k])} for k in (2, 1, 0)],
                 'note': 'in-place all-reduce of three contiguous ranges of the bucket-major gradient buffer, launched between the '
@@ -325,7 +336,7 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
         exposed = [a.elapsed_time(b) * 1e3 for a, b in trainer.comm_timing]
         lay = bank.lay
         bounds = trainer.buckets.bounds
-        comm = {'rccl_ranks': world, 'backend': dist.get_backend() if dist is not None else None,
+        comm = {'ranks': world, 'backend': dist.get_backend() if dist is not None else None,
                 'buckets': [{'bucket': k, 'columns': [bounds[k], bounds[k + 1]], 'mbytes': 4e-6 * bank.G * (bounds[k + 1] - bounds[k]),
                              'allreduce_us_avg': sum(v) / len(v), 'launched_after': {2: 'decoder half of backward', 1: 'deep-encoder '
                              'weight gradients', 0: 'last backward launch'}[k]} for k, v in sorted(bt.items(), reverse=True)],
@@ -366,9 +377,9 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     tag = 'fp32' if precision == 'fp32' else 'bf16'
     # the committed PMC passes: default workload (net4, B=256) and BASELINE config 4 (full, B=512, bf16)
     if model == 'net4' and B == 256:
-        traffic = pmc_traffic('r03_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16'))
+        traffic = pmc_traffic('r04_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16'))
     elif model == 'full' and B == 512 and precision == 'bf16':
-        traffic = pmc_traffic('r03_pmc_hbm_traffic_bf16_full_b512.json')
+        traffic = pmc_traffic('r04_pmc_hbm_traffic_bf16_full_b512.json')
     else:
         traffic = (None, None)
     rec = {'value': value, 'unit': 'cubes/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
@@ -382,6 +393,10 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
                       'frac_of_%s_mfma_peak_whole_step_algorithmic' % tag: value / world * train_flop / peak,
                       'loss_raw': float(l_raw), 'loss_of': float(l_of) if l_of is not None else 0.0},
            'roofline': conv_roofline(bank, B, per, precision, overlap, traffic)}
+    if rec['roofline'] is not None and graph:
+        n_fam = sum(1 for label, _, _ in ev[:n_in] if label in fl)
+        rec['roofline']['launches_timed_where'] = ('%d inside the timed region (its first %d step(s) run the eager loop), %d in %d further '
+                                                   'eager event step(s) right after it' % (n_fam, n_ev, rec['roofline']['launches_timed'] - n_fam, ev_extra))
     if precision == 'bf16':
         rec['config']['precision'] = 'mixed bf16 (BASELINE config 4): conv / transposed-conv operands and stored activations bf16, ' \
                                      'parameters / BatchNorm statistics / loss / Adam fp32'
@@ -459,11 +474,13 @@ def run_scoring(dev, B=512, n=8192, reps=3):
 
 
 def _fn2_traffic():
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic_flownet2.json')))
-        return d['total_hbm_bytes_per_run_corrected'], _profile_tag('r03_pmc_hbm_traffic_flownet2.json', d)
-    except Exception:
-        return None, None
+    for n in ('r04_pmc_hbm_traffic_flownet2.json', 'r03_pmc_hbm_traffic_flownet2.json'):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', n)))
+            return d['total_hbm_bytes_per_run_corrected'], _profile_tag(n, d)
+        except Exception:
+            continue
+    return None, None
 
 
 def run_flownet2(dev, reps=10):
@@ -551,6 +568,8 @@ def main():
     ap.add_argument('--cpu-child-limit', type=float, default=10.0, help=argparse.SUPPRESS)
     ap.add_argument('--no-graph', action='store_true', help='eager launch loop in every timed step (default: hipGraph replay)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-4 / config-5 / scoring records')
+    ap.add_argument('--no-forward-timing', action='store_true', help='skip the forward-only passes (counter profiles: the process '
+                    'then runs train steps alone, so whole-process HBM bytes / Adam launches = bytes per step)')
     ap.add_argument('--breakdown', action='store_true', help='print a per-launch time table to stderr')
     ap.add_argument('--overlap', nargs='?', const='free', default='none', choices=('none', 'free', 'paired'),
                     help="side stream for the weight-gradient kernels: 'free' = under everything that follows (conv launches "
@@ -581,7 +600,8 @@ def main():
     if dist is not None and dist.get_world_size() != args.gpus:
         raise SystemExit('process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
     rec = run_unet(args.model, args.precision, args.batch, args.steps, args.warmup, dev, rank, world, dist, args.overlap,
-                   args.breakdown, args.pool, graph=not args.no_graph)
+                   args.breakdown, args.pool, graph=not args.no_graph, measure_forward=not args.no_forward_timing,
+                   ev_extra=0 if args.no_forward_timing else 4)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -614,6 +634,17 @@ def main():
             sec[nm]['baseline_config'] = 'per-rank workload of %s, measured on 1 GPU without the gradient exchange' % per
         sec['flownet2_1024x448']['baseline_config'] = 'configs[4]: FlowNet2 correlation+conv forward on 1024x436 frame pairs, 1xMI355X'
         out['configs'] = sec
+        # scalar copies of the secondary headlines inside `config` (the driver's parsed record keeps top-level objects only)
+        def _g(name, key):
+            v = sec.get(name, {}).get(key)
+            return None if v is None else float(v)
+        out['config'].update({'cfg4_cubes_per_s': _g('full_b512_bf16', 'value'), 'cfg4_ms_per_step': _g('full_b512_bf16', 'ms_per_step'),
+                              'cfg4_conv_family_us': (sec['full_b512_bf16'].get('roofline') or {}).get('avg_launch_us'),
+                              'cfg4_conv_family_frac_hbm': (sec['full_b512_bf16'].get('roofline') or {}).get('frac'),
+                              'net4_b32_ms': _g('net4_b32', 'ms_per_step'), 'net4_b32_cubes_per_s': _g('net4_b32', 'value'),
+                              'net4_b16_ms': _g('net4_b16', 'ms_per_step'), 'net4_b16_cubes_per_s': _g('net4_b16', 'value'),
+                              'flownet2_ms_per_pair': _g('flownet2_1024x448', 'ms_per_pair'),
+                              'eval_scoring_cubes_per_s': _g('net4_eval_scoring', 'value')})
     if not args.no_cpu_baseline and world == 1:
         try:
             out['cpu_baseline'] = cpu_baseline()

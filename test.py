@@ -42,6 +42,34 @@ def load_model(net, state_dict, device):
     return net
 
 
+def load_artifacts(base, fg, method, shanghai, build_net, device, h_block=1, w_block=1):
+    """test.py:230-266: the three files train.py wrote (torch pickles despite the .npy suffix, train.py:432-436) -> (net_set,
+    raw statistics, flow statistics) with the reference's nesting -- [h][w] for UCSDped2 / avenue, [scene][h][w] for ShanghaiTech;
+    a block without a trained model is an empty list (train.py:370 skips blocks with <= 1 cube).  Works on files written by the
+    reference itself (tests/test_ref_written_files.py): 'module.'-prefixed keys, aliased storages, int64 num_batches_tracked."""
+    weights = torch.load(base + 'model_{}_{}.npy'.format(fg, method), map_location='cpu', weights_only=False)
+    raw_tr = torch.load(base + 'raw_training_scores_{}_{}.npy'.format(fg, method), weights_only=False)
+    of_tr = torch.load(base + 'of_training_scores_{}_{}.npy'.format(fg, method), weights_only=False)
+
+    def build(wl):
+        return [load_model(build_net(), wl[0], device)] if len(wl) > 0 else []
+
+    def stat(a):
+        a = np.asarray(a)
+        return (np.mean(a), np.std(a)) if a.size else (0.0, 1.0)      # population std, test.py:264-266
+
+    if shanghai:
+        net_set = [[[build(weights[s][hh][ww]) for ww in range(len(weights[s][hh]))] for hh in range(len(weights[s]))]
+                   for s in range(len(weights))]
+        st_r = [[[stat(raw_tr[s][hh][ww]) for ww in range(w_block)] for hh in range(h_block)] for s in range(len(weights))]
+        st_o = [[[stat(of_tr[s][hh][ww]) for ww in range(w_block)] for hh in range(h_block)] for s in range(len(weights))]
+    else:
+        net_set = [[build(weights[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+        st_r = [[stat(raw_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+        st_o = [[stat(of_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+    return net_set, st_r, st_o
+
+
 def score_cubes_device(trainer, cube_list, flow_list, score_batch, chunk_cubes=None):
     """cube_list / flow_list: per-frame arrays [n_i,5,32,32,3] uint8 / [n_i,(Tf,)32,32,2] fp32 (n_i may be 0).
     The cubes go to the GPU in bounded super-chunks (``chunk_cubes``, default 32 launches' worth, >= 4096: ~55 KB per cube for the
@@ -216,26 +244,7 @@ def main(config_path='config.cfg'):
         fset2 = np.load(base + 'foreground_test_{}-flow.npy'.format(fg), allow_pickle=True)
         bset = np.load(base + 'foreground_bbox_test_{}.npy'.format(fg), allow_pickle=True)
         scene_idx = np.load(base + 'scene_idx.npy') if shanghai else None
-        weights = torch.load(base + 'model_{}_{}.npy'.format(fg, method), map_location='cpu', weights_only=False)
-        raw_tr = torch.load(base + 'raw_training_scores_{}_{}.npy'.format(fg, method), weights_only=False)
-        of_tr = torch.load(base + 'of_training_scores_{}_{}.npy'.format(fg, method), weights_only=False)
-
-        def build(wl):
-            return [load_model(build_network(c), wl[0], device)] if len(wl) > 0 else []
-
-        def stat(a):
-            a = np.asarray(a)
-            return (np.mean(a), np.std(a)) if a.size else (0.0, 1.0)      # population std, test.py:264-266
-
-        if shanghai:
-            net_set = [[[build(weights[s][hh][ww]) for ww in range(len(weights[s][hh]))] for hh in range(len(weights[s]))]
-                       for s in range(len(weights))]
-            st_r = [[[stat(raw_tr[s][hh][ww]) for ww in range(c['w_block'])] for hh in range(c['h_block'])] for s in range(len(weights))]
-            st_o = [[[stat(of_tr[s][hh][ww]) for ww in range(c['w_block'])] for hh in range(c['h_block'])] for s in range(len(weights))]
-        else:
-            net_set = [[build(weights[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
-            st_r = [[stat(raw_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
-            st_o = [[stat(of_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
+        net_set, st_r, st_o = load_artifacts(base, fg, method, shanghai, lambda: build_network(c), device, c['h_block'], c['w_block'])
         mask_dir = os.path.join(results_dir, ds, 'score_mask') if c['save_score_masks'] else None
         fs = score_frames(net_set, st_r, st_o, fset, fset2, bset, h, w, c['w_raw'], c['w_of'], c['useFlow'], device,
                           c['score_batch'], scene_idx, mask_dir)

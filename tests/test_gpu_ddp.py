@@ -340,7 +340,32 @@ def test_bench_two_ranks_on_one_gpu_prints_one_valid_line():
     assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['unit'] == 'cubes/s'
     assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 32 * 6 / (d['ms_per_step'] * 6e-3)) <= 1e-6 * d['value']
-    assert d['comm']['rccl_ranks'] == 2 and len(d['comm']['buckets']) == 3
+    assert d['comm']['ranks'] == 2 and len(d['comm']['buckets']) == 3
     assert 0 < d['comm']['per_rank_cubes_per_s']['min'] <= d['comm']['per_rank_cubes_per_s']['max']
     assert '4 segment' in d['execution']['mode'], d['execution']
     assert 'configs' not in d and np.isfinite(d['config']['loss_raw'])
+
+
+def test_bench_eight_ranks_on_one_gpu_dataparallel_split():
+    """BASELINE configs[2] host logic before the first real SCALE run: `bench.py --gpus 8 --batch 4` under torch.distributed.run,
+    all eight ranks on GPU 0 over gloo (bring-up mode; RCCL with N > 1 is the driver's to run).  One JSON line, 8 ranks in `comm`,
+    global batch 32, the captured step in four segments with the three exchanges between them."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VV_SINGLE_DEVICE='1', VV_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    port = 32900 + (os.getpid() % 1000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '3', '--batch', '4',
+           '--pool', '32', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp8'
+    assert d['comm']['ranks'] == 8 and d['comm']['backend'] == 'gloo' and len(d['comm']['buckets']) == 3
+    assert abs(d['value'] - 32 * 4 / (d['ms_per_step'] * 4e-3)) <= 1e-6 * d['value']
+    assert '4 segment' in d['execution']['mode'], d['execution']
+    assert np.isfinite(d['config']['loss_raw'])

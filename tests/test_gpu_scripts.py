@@ -33,10 +33,10 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
     statement there; on the 10-frame golden it only says the ranking is identical.
     bf16 (`[mi355x] precision = bf16`, BASELINE config 4): bars at ~2x what round 3 observed against the REFERENCE's fp32 golden
     (gpurun_out/observed.jsonl: per-cube training scores 6.4e-4 / 2.2e-4, first loss 5.3e-5, z-normalised frame scores 9.9e-3 on the
-    240-frame golden, AUROC 2.1e-4): training scores 1.5e-3, loss 2e-4, frame scores 2e-2, AUROC 1e-3 -- the fp32 path's own bars
+    240-frame golden, AUROC 2.1e-4): training scores 1e-3 (the north star's bar; round 3 had 1.5e-3), loss 2e-4, frame scores 2e-2, AUROC 1e-3 -- the fp32 path's own bars
     except for the frame scores (x4: the z-normalisation amplifies a per-cube deviation by mu / sigma ~ 140)."""
     monkeypatch.setenv('VV_PRECISION', precision)
-    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=5e-3, auc=1e-3), 'bf16': dict(train=1.5e-3, loss=2e-4, frame=2e-2, auc=1e-3)}[precision]
+    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=5e-3, auc=1e-3), 'bf16': dict(train=1e-3, loss=2e-4, frame=2e-2, auc=1e-3)}[precision]
     from oracle import unet_oracle as O
     import train as T
     import test as S

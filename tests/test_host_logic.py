@@ -152,6 +152,71 @@ def test_grad_buckets_gloo_world2():
     assert res[0][2].tolist() == [0, 1, 2, 3] and res[1][2].tolist() == [4, 5, 6, 7]
 
 
+def _world8_worker(rank, world, port, q):
+    """One rank of an 8-rank group on the REAL bucket geometry of the Net4 bank (BankLayout(32, 12): G = 6, bounds
+    [0, c4.w, c8.w, U]) + the even shard and DataParallel's uneven last-batch scatter of train.train_block."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vec_vad_amd.bank import BankLayout
+    from vec_vad_amd.trainer import GradBuckets, shard_batch
+    lay = BankLayout(32, 12)
+    G = 6
+    bounds = [0, lay.p['c4.w'][0], lay.p['c8.w'][0], lay.U]
+    # bucket-major buffer; element value = rank-dependent so that the sum identifies every contribution
+    n = G * lay.U
+    g = torch.full((n,), float(rank + 1))
+    g[::1000] += torch.arange(0, n, 1000, dtype=torch.float32) * 1e-3
+    b = GradBuckets(g, G, bounds, dist.group.WORLD)
+    for k in (2, 1, 0):                         # the order the backward pass completes them
+        b.launch(k)
+    b.finish()
+    even = shard_batch(torch.arange(256), rank, world)
+    # the uneven last batch (train.train_block): chunks of ceil(n / world); trailing ranks may get nothing
+    out = {}
+    for n_glob in (250, 9, 3):
+        per = -(-n_glob // world)
+        out[n_glob] = torch.arange(n_glob)[rank * per:(rank + 1) * per].tolist()
+    try:
+        shard_batch(torch.arange(250), rank, world)
+        raised = False
+    except ValueError:
+        raised = True
+    q.put((rank, float(g[1]), float(g[1000]), float(g[-1]), [v.numel() for v in b.views], even.tolist(), out, raised, bounds, G * lay.U))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_and_sharding_gloo_world8():
+    """BASELINE configs[2]: 8 ranks.  The three in-place bucket all-reduces cover the whole gradient buffer of the real Net4
+    geometry exactly once, a 256-cube batch shards 32 per rank, and the last partial batch follows DataParallel's scatter
+    (chunks of ceil(n / 8), empty shards for trailing ranks) and covers every cube exactly once."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 1000)
+    W = 8
+    ps = [ctx.Process(target=_world8_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+    tot = sum(range(1, W + 1))
+    bounds, n = res[0][8], res[0][9]
+    assert bounds[0] == 0 and bounds == sorted(bounds) and 6 * bounds[-1] == n
+    for r, g1, g1000, glast, widths, even, uneven, raised, _, _ in res:
+        assert g1 == tot and glast == tot and abs(g1000 - (tot + W * 1.0)) < 1e-4      # every element summed over all 8 ranks once
+        assert sum(widths) == n and widths == [6 * (b - a) for a, b in zip(bounds[:-1], bounds[1:])]
+        assert even == list(range(32 * r, 32 * r + 32)) and raised
+    for n_glob in (250, 9, 3):
+        got = [i for r in res for i in r[6][n_glob]]
+        assert got == list(range(n_glob))                                                # every cube once, in order
+    assert [len(r[6][3]) for r in res] == [1, 1, 1, 0, 0, 0, 0, 0]                        # ranks without cubes
+    assert [len(r[6][9]) for r in res] == [2, 2, 2, 2, 1, 0, 0, 0]
+
+
 def _extract_worker(rank, world, port, root, fail, q):
     import time
     import torch.distributed as dist

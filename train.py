@@ -131,15 +131,18 @@ def _extract_once(c, device, dist=None, timeout_h=48.0):
     import datetime
     side = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=timeout_h))
     err = None
-    if rank == 0:
-        try:
-            from foreground import extract_train
-            extract_train(c, device)
-        except Exception as e:          # the other ranks must not wait 48 h for a rank that died
-            err = e
-    flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
-    dist.broadcast(flag, src=0, group=side)          # = the barrier; carries rank 0's verdict
-    dist.destroy_process_group(side)
+    try:
+        if rank == 0:
+            try:
+                from foreground import extract_train
+                extract_train(c, device)
+            except BaseException as e:      # incl. KeyboardInterrupt / SystemExit: the other ranks must not wait 48 h for a rank that
+                err = e                     # is on its way out (a SIGKILL cannot be announced: gloo then fails the peers' broadcast
+                                            # when the socket closes)
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
+        dist.broadcast(flag, src=0, group=side)          # = the barrier; carries rank 0's verdict
+    finally:
+        dist.destroy_process_group(side)                 # also when the broadcast itself raised
     if err is not None:
         raise err
     if int(flag.item()):
@@ -170,6 +173,8 @@ def train_block(net, segments, epochs, batch_size, lambda_raw=1.0, lambda_of=1.0
 
     def store(i):
         if stores[i] is None or len(segments) > 1:
+            if len(segments) > 1:
+                trainer.release_graphs()      # the captured steps pin the previous segment's store: free it before the next upload
             raw, flow = segments[i]()
             s = CubeStore(raw, flow, device)
             if len(segments) == 1:

@@ -412,6 +412,7 @@ class UNetBank:
         ws.fwdq = {True: self._plan_forward(ws, B, True, out4=False),
                    False: self._plan_eval(ws, B, out4=False) if self.eval_fold else self._plan_forward(ws, B, False, out4=False)}
         ws.bwd = None
+        ws.out4_valid = False          # True while ws.out4 holds the reconstructions of the LAST forward on this workspace
         return ws
 
     def _src_for(self, ws, l):
@@ -868,6 +869,7 @@ class UNetBank:
         if not train and self.eval_fold:
             self.prepare_eval()
         (ws.fwd if outputs else ws.fwdq)[bool(train)].run(self._stream())
+        ws.out4_valid = bool(outputs)
         if train:
             self.nbt[self.g0:self.g0 + self.Ga] += 1
             self.mark_dirty()
@@ -916,6 +918,9 @@ class UNetBank:
 
     def outputs_nchw(self, ws):
         """(of_out [B,2*n_of,32,32], raw_out [B,3*n_raw,32,32]) in the reference's channel order."""
+        if not getattr(ws, 'out4_valid', False):
+            raise RuntimeError('the last forward on this workspace did not store the reconstructions (fused train / scoring steps skip '
+                               'that store): use forward(ws, train, outputs=True) or FusedTrainer.keep_outputs = True')
         B, HWp = ws.B, HW0 * HW0
         units = self.units[self.g0:self.g0 + self.Ga]
         raw_o = torch.empty(B, RAW_C * ws.n_raw, HW0, HW0, device=self.device)

@@ -211,6 +211,7 @@ class FusedTrainer:
         the part every kind of step shares"""
         bank = self.bank
         self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], bank._stream())
+        ws.out4_valid = bool(self.keep_outputs)
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
         bank.mark_dirty()
         if ws.bwd is None:
@@ -374,11 +375,33 @@ class FusedTrainer:
         cap.segments = self._capture(segments)
         return cap
 
+    def release_graphs(self, keep_store=None):
+        """Drop every captured step / scoring graph (and 'warm' marker) except those of cube store ``keep_store`` = (raw pointer,
+        flow pointer).  A captured graph pins the cube store it gathers from (cap.keep) and its workspace: a caller that replaces
+        its store (train.py's per-segment stores of ShanghaiTech) calls this so that the old store's memory is freed with it."""
+        if keep_store is None:
+            self._graphs = {}
+        else:
+            self._graphs = {k: v for k, v in self._graphs.items() if k[2:4] == keep_store}
+
+    def _graph_lookup(self, key):
+        """Cache entry of ``key`` = (kind, B, raw pointer, flow pointer, ...).  Entries are pinned per cube STORE, and at most one
+        store is kept: a key of a new store evicts every entry (captured or 'warm') of the others, so a trainer fed a fresh store
+        per data segment holds one store's graphs, not one set per segment it has ever seen.  Within a store the
+        distinct (kind, B, hyper-parameter) keys are bounded at 8."""
+        cap = self._graphs.get(key)
+        if cap is None:
+            if any(k[2:4] != key[2:4] for k in self._graphs):
+                self.release_graphs(keep_store=key[2:4])
+            if len(self._graphs) >= 8:
+                self._graphs = {}
+        return cap
+
     def _step_graphed(self, raw_u8, flow, idx):
         bank = self.bank
         B = int(idx.numel())
         key = ('train', B, raw_u8.data_ptr(), flow.data_ptr() if flow is not None else 0, self.lr, self.eps, self.betas, self.keep_outputs)
-        cap = self._graphs.get(key)
+        cap = self._graph_lookup(key)
         if cap is None or cap == 'warm':
             # the first step of a (batch size, cube store) runs the eager loop: it builds the workspace, the backward plan and the
             # Adam moments and loads every kernel; the second one captures
@@ -387,8 +410,6 @@ class FusedTrainer:
                 self._graphs[key] = 'warm'
                 return ws
             torch.cuda.current_stream(bank.device).synchronize()
-            if len(self._graphs) > 8:
-                self._graphs = {}
             self._graphs[key] = self._capture_train(raw_u8, flow, B)
             return ws
         cap.idx.copy_(idx)
@@ -398,6 +419,7 @@ class FusedTrainer:
                 after()
         bank._adam_t += 1            # host mirror of the device step counter (vv_adam_tick advanced it inside the graph)
         bank.mark_dirty()
+        cap.ws.out4_valid = bool(self.keep_outputs)      # part of the cache key: the captured plan stores them or not
         return cap.ws
 
     def step_cubes(self, raw_u8, flow, idx):
@@ -454,7 +476,7 @@ class FusedTrainer:
         bank, lib = self.bank, self.bank.lib
         B = int(idx.numel()) if idx is not None else (batch if batch is not None else raw_u8.shape[0])
         key = ('eval', B, raw_u8.data_ptr(), flow.data_ptr() if flow is not None else 0)
-        cap = self._graphs.get(key)
+        cap = self._graph_lookup(key)
         if cap is None or cap == 'warm':
             ws = bank.set_input_cubes(raw_u8, flow, idx, batch)
             bank.forward(ws, False, outputs=False)
@@ -473,8 +495,6 @@ class FusedTrainer:
             cap.ws, cap.idx, cap.keep = ws, sidx, (raw_u8, flow)
             cap.launches = len(seg)
             cap.segments = self._capture([(seg, None)])
-            if len(self._graphs) > 8:
-                self._graphs = {}
             self._graphs[key] = cap
             return out
         if bank.eval_fold:
@@ -487,6 +507,7 @@ class FusedTrainer:
             cap.idx.copy_(idx)
             cap.identity = False
         cap.segments[0][0].replay()
+        cap.ws.out4_valid = False
         return bank.cube_scores(cap.ws)
 
     @torch.no_grad()
