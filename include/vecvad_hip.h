@@ -84,6 +84,10 @@ typedef struct vv_view {
  * running-statistics BatchNorm the affine map is a constant of the model, so vv_fold_bn folds it into the filter and the bias once per
  * loaded model, the producing convolution applies the ReLU, and every consumer reads its input as VV_IN_PLAIN. */
 #define VV_CONV_RELU 32
+/* A/B switch: an all-bf16 3x3 launch (VV_CONV_BF16 | VV_CONV_OUT_BF16 | VV_CONV_ALLSRC_BF16 or VV_CONV_SRC_BF16) normally runs the
+ * GEMM-shaped kernel of round 4 (vv_conv_bf16.hip, 256-pixel tiles on every level); with this flag it stays on the round-3
+ * kernel (128-pixel tiles on the 16x16 / 8x8 / 4x4 levels).  vv_conv_ntiles2 follows the same flags. */
+#define VV_CONV_NO_GEMM16 64
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */

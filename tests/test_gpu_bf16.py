@@ -485,3 +485,66 @@ def test_bf16_scores_and_auc_close_to_fp32(monkeypatch):
     aucs = [O.roc_auc(res[p][0] + res[p][1], labels) for p in ('fp32', 'bf16')]
     assert abs(aucs[0] - aucs[1]) <= 1e-2, aucs
     assert aucs[0] > 0.6                                                        # the labelled set is separable at all
+
+
+@pytest.mark.parametrize('H,Cin,Cout,B,mode', [
+    (32, 16, 32, 3, 'plain'), (32, 32, 32, 2, 'act'), (32, 64, 32, 2, 'cat'), (32, 32, 64, 1, 'plain'),
+    (16, 32, 64, 3, 'plain'), (16, 64, 64, 5, 'act'), (16, 128, 64, 2, 'cat'), (16, 64, 128, 1, 'plain'), (16, 64, 32, 2, 'plain'),
+    (8, 64, 128, 9, 'plain'), (8, 128, 128, 6, 'act'), (8, 256, 128, 5, 'cat'), (8, 128, 256, 3, 'plain'), (8, 128, 64, 7, 'plain'),
+    (4, 128, 256, 33, 'plain'), (4, 256, 256, 17, 'act'), (4, 256, 128, 40, 'plain'), (4, 32, 32, 5, 'act')])
+def test_bf16_gemm_conv_all_bf16_tensors(H, Cin, Cout, B, mode):
+    """vv_conv_bf16.hip (round 4): the GEMM-shaped 3x3 kernel that all-bf16 launches run (VV_CONV_BF16 | VV_CONV_OUT_BF16 |
+    VV_CONV_ALLSRC_BF16) -- every tile shape (TN = 32 / 64 / 128 on all four pyramid levels), every input mode it serves (plain =
+    data gradient / pooled / frame-erased input, BatchNorm+ReLU on load, skip concat), ragged batches (tiles of 4 / 16 images).
+    (a) against an fp64 convolution of the bf16-rounded operands: 2e-4 of the tensor maximum before the output rounding, i.e.
+        the stored bf16 value is within one bf16 ulp (2^-8 relative) of the rounded reference;
+    (b) BIT-EQUAL to the round-3 kernel (VV_CONV_NO_GEMM16) on the same inputs: both accumulate chunk -> tap -> one 16-channel
+        MFMA in fp32 in the same order, so the new data path (filter fragments from L2, permuted two-plane LDS tile) must not move
+        a single bit;
+    (c) per-tile column sums / sums of squares of the stored values add up to the tensor's."""
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G = 2
+    g = torch.Generator(device='cpu').manual_seed(H * 1000 + Cin + Cout)
+    st = torch.cuda.current_stream().cuda_stream
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    bias = torch.randn(G, Cout, generator=g).cuda()
+    csplit = Cin // 2 if mode == 'cat' else Cin
+    x0 = _r(torch.randn(G, B * H * H, csplit, generator=g)).cuda()
+    x1 = _r(torch.randn(G, B * H * H, Cin - csplit, generator=g)).cuda() if mode == 'cat' else None
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    x0s = _as_bf16_storage(x0)
+    x1s = _as_bf16_storage(x1) if x1 is not None else None
+    pk = _pack(lib, L, w, G, 0, Cin, Cout, st)
+    in_mode = {'plain': L.IN_PLAIN, 'act': L.IN_ACT, 'cat': L.IN_CAT}[mode]
+    res = []
+    for extra in (0, L.CONV_NO_GEMM16):
+        flags = L.CONV_BF16 | L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16 | extra
+        nt = lib.vv_conv_ntiles2(B, H, H, L.CONV3, flags)
+        y = torch.full((G, B * H * H * Cout // 2 + 8,), 3.0, device='cuda')
+        s_ = torch.full((G, nt, 2, Cout), -7.0, device='cuda')
+        cp = L.ConvParams(L.CONV3, in_mode, G, B, H, H, Cin, Cin, Cout, L.View(x0s.data_ptr(), x0s.stride(0), csplit, 0),
+                          a.data_ptr() if mode != 'plain' else None, b.data_ptr() if mode != 'plain' else None, Cin,
+                          L.View(x1s.data_ptr(), x1s.stride(0), Cin - csplit, 0) if x1s is not None else L.NULL_VIEW, csplit, flags, None,
+                          pk.data_ptr(), pk.stride(0), bias.data_ptr(), Cout, L.View(y.data_ptr(), y.stride(0), Cout, 0), s_.data_ptr())
+        L.check(lib.vv_conv_mfma(C.byref(cp), st), 'conv')
+        stored = y.view(torch.bfloat16)[:, :B * H * H * Cout].float().view(G, B * H * H, Cout)
+        assert float(y[0, -1]) == 3.0                                   # nothing written past the tensor
+        res.append((stored, s_))
+    assert lib.vv_conv_ntiles2(B, H, H, L.CONV3, L.CONV_BF16 | L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16) == lib.vv_conv_ntiles(B, H, H)
+    new, old = res[0][0], res[1][0]
+    assert torch.equal(new, old), (new - old).abs().max().item()       # (b)
+    for gi in range(G):
+        xin = x0[gi].view(B, H, H, csplit).permute(0, 3, 1, 2)
+        if mode != 'plain':
+            xin = torch.relu(torch.addcmul(b[gi, :csplit].view(1, -1, 1, 1), xin, a[gi, :csplit].view(1, -1, 1, 1)))
+        if mode == 'cat':
+            xin = torch.cat([xin, x1[gi].view(B, H, H, Cin - csplit).permute(0, 3, 1, 2)], 1)
+        ref = F.conv2d(_r(xin).double(), _r(w[gi]).double(), bias[gi].double(), padding=1)
+        got = new[gi].view(B, H, H, Cout).permute(0, 3, 1, 2).double()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= (2e-4 + 2 ** -8) * scale, ((got - ref).abs().max().item(), scale)     # (a)
+        tot = res[0][1][gi].sum(0).double()                              # (c)
+        torch.testing.assert_close(tot[0], new[gi].double().sum(0), rtol=1e-4, atol=1e-3 * scale * B)
+        torch.testing.assert_close(tot[1], (new[gi].double() ** 2).sum(0), rtol=1e-4, atol=1e-3)

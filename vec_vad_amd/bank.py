@@ -238,6 +238,8 @@ class UNetBank:
         if self.precision not in ('fp32', 'bf16'):
             raise ValueError("VV_PRECISION / [mi355x] precision must be 'fp32' or 'bf16', got %r" % self.precision)
         self.cflag = L.CONV_BF16 if self.precision == 'bf16' else 0
+        if self.cflag and os.environ.get('VV_CONV_GEMM16', '1') == '0':      # A/B switch: the round-3 bf16 3x3 kernel
+            self.cflag |= L.CONV_NO_GEMM16
         self.bf16_wgrad = os.environ.get('VV_BF16_WGRAD', '1') != '0'      # 0: keep the fp32 (Winograd) weight gradient in bf16 mode
         # BatchNorm backward stores dy as bf16 when both of its consumers round it to bf16 anyway (bit-identical results)
         self.dz16 = bool(self.cflag) and self.bf16_wgrad and os.environ.get('VV_BF16_DZ', '1') != '0'
@@ -386,7 +388,8 @@ class UNetBank:
         ws.t = [f(Ga, B * (2 * H) * (2 * H), co) for (_, H, ci, co) in lay.convT]
         ws.pooled = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.mode == L.IN_POOL}
         ws.erased = f(Ga, B * HWp, lay.convs[0].cinp)
-        nt = [max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_wino_ntiles(B, l.H)) for l in lay.convs]
+        nt = [max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag),
+                  lib.vv_wino_ntiles(B, l.H)) for l in lay.convs]
         ws.stats = f(Ga, max(n * 2 * l.cout for n, l in zip(nt, lay.convs)))
         ws.ab = torch.zeros(4, len(lay.convs), Ga, lay.cmax, device=d)
         ws.out4 = f(Ga, B * HWp, 4)
@@ -466,7 +469,7 @@ class UNetBank:
             P.keep.append(cp)
             P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx,
                   wait=tuple(pack_tail) if l.idx == 2 else ())
-            nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag)
+            nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag)
             P.add(lib.vv_bn_finalize,
                   (Ga, l.cout, nt, B * l.H * l.H, 1 if train else 0, 0.1, 1e-5, ws.stats.data_ptr(), nt * 2 * l.cout,
                    pbase + 4 * lay.p['c%d.g' % l.idx][0], pbase + 4 * lay.p['c%d.beta' % l.idx][0], U,
@@ -614,8 +617,8 @@ class UNetBank:
         ws.bnscr = f(Ga, 2 * lay.cmax)
         ws.ocpart = f(Ga, B, 4 * nf + 4)
         ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
-        ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin
-                              for l in lay.convs if l.mode == L.IN_CAT))
+        ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_conv_ntiles(B, l.H, l.H),
+                                  lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin for l in lay.convs if l.mode == L.IN_CAT))
         # wgrad split-K choice: ~1024 workgroups per launch
         wplan = {}
         wmax = 0
@@ -727,6 +730,12 @@ class UNetBank:
 
         fused = {fused_producer(l) for l in lay.convs} - {None}
 
+        def dgrad_flags(i):
+            # pad0 of layer i's data-gradient launch (also decides its tile count: vv_conv_ntiles2)
+            dz16 = bool(self.dz16 and len(wplan['c%d' % i]) > 2)
+            return (self.cflag | ((L.CONV_ALLSRC_BF16 if self.y16 else L.CONV_SRC_BF16) if dz16 else 0) |
+                    (L.CONV_OUT_BF16 if self.da16 else 0))
+
         def conv_bwd(l):
             i = l.idx
             y = ws.y[i]
@@ -758,8 +767,7 @@ class UNetBank:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
-                                  self.cflag | ((L.CONV_ALLSRC_BF16 if self.y16 else L.CONV_SRC_BF16) if dz16 else 0) |
-                                  (L.CONV_OUT_BF16 if self.da16 else 0), None,
+                                  dgrad_flags(i), None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
@@ -809,7 +817,7 @@ class UNetBank:
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
-            ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles2(B, m.H, m.H, L.CONV3, self.cflag)
+            ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles2(B, m.H, m.H, L.CONV3, dgrad_flags(m.idx))
             P.add(lib.vv_bias_from_partials, (Ga, m.cin, ntd, skipc, co, ws.dstats.data_ptr(), ntd * 2 * m.cin)
                   + self._g('t%d.b' % u), 'convT_bias%d' % u)
             y = ws.y[sidx]

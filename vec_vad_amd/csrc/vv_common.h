@@ -35,6 +35,14 @@ __device__ __forceinline__ void vv_static_for(F&& f) {
     if (e__ != hipSuccess) return VV_HIP_STATUS(e__);       \
   } while (0)
 
+// vv_conv_bf16.hip: the GEMM-shaped 3x3 kernel of the all-bf16 launches (forward: VV_CONV_ALLSRC_BF16, data gradient: also
+// VV_CONV_SRC_BF16; output bf16).  vv_conv_mfma routes to it, vv_conv_ntiles2 reports its (256-pixel) tiles, under ONE predicate.
+int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st);
+inline bool vv_gemm16_flags(int kind, int flags) {
+  return kind == VV_CONV3 && (flags & VV_CONV_BF16) && (flags & VV_CONV_OUT_BF16) && (flags & (VV_CONV_SRC_BF16 | VV_CONV_ALLSRC_BF16)) &&
+         !(flags & VV_CONV_NO_GEMM16);
+}
+
 // XCD-aware work-item remap: the dispatcher places block b on XCD b%8 (observed, MI355X_MICROARCH.md);
 // give every XCD one contiguous chunk of the work list so that workgroups sharing a UNet's weight panel
 // share an L2.  nper = ceil(total/8); grid = 8*nper; caller drops w >= total.

@@ -446,6 +446,7 @@ extern "C" int vv_conv_ntiles(int32_t B, int32_t H, int32_t W) {
 }
 
 extern "C" int vv_conv_ntiles2(int32_t B, int32_t H, int32_t W, int32_t kind, int32_t flags) {
+  if (vv_gemm16_flags(kind, flags)) return vv_conv_ntiles(B, H, W);          // vv_conv_bf16.hip: 256-pixel tiles everywhere
   if ((flags & VV_CONV_BF16) && kind == VV_CONV3 && H == W && H == 16) return B * 2;
   if ((flags & VV_CONV_BF16) && kind == VV_CONV3 && H == W && (H == 8 || H == 4)) return (B + (H == 8 ? 1 : 7)) / (H == 8 ? 2 : 8);
   return vv_conv_ntiles(B, H, W);
@@ -463,6 +464,9 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   if ((p->pad0 & VV_CONV_ALLSRC_BF16) && (!bf || p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
   const int sm = !bf ? 0 : ((p->pad0 & VV_CONV_ALLSRC_BF16) ? 2 : ((p->pad0 & VV_CONV_SRC_BF16) ? 1 : 0));
+  // all-bf16 3x3 launches: the persistent GEMM-shaped kernel on the 16x16 / 8x8 / 4x4 levels; at 32x32 (HBM-bound, 1 - 2 chunks per
+  // tile) it measured slower than this file's kernel, which has the same 256-pixel tiles there (vv_conv_ntiles2 is unaffected)
+  if (vv_gemm16_flags(p->kind, p->pad0) && p->H <= 16) return vv_conv_gemm16(p, st);
   switch (p->kind) {
     case VV_CONV3:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
