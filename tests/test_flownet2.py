@@ -83,6 +83,41 @@ def test_conv2d_hip_vs_torch_cpu(kind, R, stride, Cin, Cout, H, W, relu):
     assert float(dst.t[..., :4].abs().max()) == 0 and float(dst.t[..., 4 + Cout:].abs().max()) == 0   # neighbours untouched
 
 
+# (Cin, Cout, H, W, relu): sizes that pass the runner's Winograd gate (H % 4 == 0, W % 32 == 0, >= VV_FN2_WINO_MIN_WGS workgroups at
+# batch 2) -- odd channel counts (K padded to 8 inside the panel; 473 = FlowNetC's conv3_1), 32 / 64 / 256 output channels, a
+# one-block-wide and a one-block-high image, plain and LeakyReLU epilogues
+WINO_CASES = [(64, 128, 32, 64, True), (473, 256, 8, 64, True), (162, 32, 56, 64, True), (11, 64, 28, 64, True),
+              (194, 64, 16, 32, False), (128, 128, 4, 512, True), (24, 32, 60, 32, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Cin,Cout,H,W,relu', WINO_CASES)
+def test_conv2d_winograd_vs_torch_cpu(Cin, Cout, H, W, relu, monkeypatch):
+    """vv_conv2d_wino (round 4): FlowNet2's large stride-1 3x3 layers in Winograd F(2x2,3x3) form, against the fp32 torch CPU
+    convolution -- the same 2e-5-of-the-maximum bar as the direct kernel (the transforms add a few ulp; the UNet path's Winograd
+    kernel is held to the same bar against its direct form) -- and that the runner really took the Winograd path."""
+    import torch.nn as nn
+    from vec_vad_amd import flownet2 as FN
+    monkeypatch.setattr(FN, '_WINO_MIN_WGS', 1)
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(2, Cin, H, W, generator=g)
+    m = nn.Conv2d(Cin, Cout, 3, stride=1, padding=1)
+    ref = F.conv2d(x, m.weight, m.bias, padding=1)
+    if relu:
+        ref = F.leaky_relu(ref, 0.1)
+    ref = ref.detach()
+    layer = (nn.Sequential(m, nn.LeakyReLU(0.1)) if relu else m).cuda()
+    src = FN._to_buf(x.cuda())
+    dst = FN._Buf(2, H, W, Cout + 6, 'cuda')
+    run = FN._Runner()
+    run(layer, src, dst, 4)
+    assert ('wino', id(m)) in run.cache
+    out = dst.t[..., 4:4 + Cout].permute(0, 3, 1, 2).cpu()
+    scale = float(ref.abs().max())
+    assert torch.allclose(out, ref, rtol=0, atol=2e-5 * scale + 1e-6), float((out - ref).abs().max())
+    assert float(dst.t[..., :4].abs().max()) == 0 and float(dst.t[..., 4 + Cout:].abs().max()) == 0   # neighbours untouched
+
+
 @pytest.mark.gpu
 def test_upsample4_vs_torch():
     from vec_vad_amd.flownet2 import _upsample4

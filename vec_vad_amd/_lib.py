@@ -96,6 +96,7 @@ class Conv2dParams(C.Structure):
 
 _SIGS = {
     'vv_conv2d_mfma': (c_i32, [C.POINTER(Conv2dParams), c_vp]),
+    'vv_conv2d_wino': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_conv2d_splitk_finish': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_i32, c_i32, c_vp]),
     'vv_pack_conv2d': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'vv_conv3x3_n2': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_f32, c_vp, c_i32, c_i32, c_vp]),

@@ -24,6 +24,8 @@ from .flow_ops import Correlation, Resample2d, ChannelNorm, correlation, resampl
 # split-K: a tiny-map layer is split until its workgroups fill the chip ONCE (256 CUs); 512 measured 0.17 ms slower per forward
 # (twice the partial-sum traffic through vv_conv2d_splitk_finish), 128 / 192 leave half the chip idle
 _KS_TARGET = int(os.environ.get('VV_FN2_KS_TARGET', '256'))
+_WINO = os.environ.get('VV_FN2_WINO', '1') != '0'
+_WINO_MIN_WGS = int(os.environ.get('VV_FN2_WINO_MIN_WGS', '200'))
 
 
 def _c4(c):
@@ -173,6 +175,35 @@ class _Runner:
                                        bias, slope, dst.t.data_ptr(), dst.cs, dst_coff, stream), 'conv3x3_n2')
         return True
 
+    def _wino(self, m, src, dst, dst_coff, slope, stream):
+        """Large stride-1 3x3 layers in Winograd F(2x2,3x3) form (vv_conv2d_wino): the layers that fill the chip -- at least 256
+        workgroups of 4 x 32 pixels x 32 channels -- where 2.25x fewer MFMAs is time (the H/32 and H/64 levels stay on the direct
+        kernel with its split-K).  VV_FN2_WINO=0 switches it off."""
+        if not _WINO or m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1) or m.out_channels % 32:
+            return False
+        if src.H % 4 or src.W % 32 or src.B * (src.H // 4) * (src.W // 32) * (m.out_channels // 32) < _WINO_MIN_WGS:
+            return False
+        if src.t.numel() * 4 >= 2 ** 31 or dst.t.numel() * 4 >= 2 ** 31:
+            return False
+        assert m.in_channels == src.C and (dst.H, dst.W) == (src.H, src.W) and dst_coff + m.out_channels <= dst.cs
+        key = ('wino', id(m))
+        ver = (m.weight.data_ptr(), m.weight._version)
+        ent = self.cache.get(key)
+        if ent is None or ent[0] != ver:
+            w = m.weight.detach().contiguous().float()          # [Cout][Cin][3][3]
+            N, K = w.shape[0], w.shape[1]
+            KP = (K + 7) // 8 * 8
+            panel = torch.empty(16 * KP * N, device=w.device, dtype=torch.float32)
+            tab = torch.frombuffer(bytearray(bytes((L.PackEntry * 1)(L.PackEntry(0, 0, 0, K, KP, N)))), dtype=torch.uint8).to(w.device)
+            L.check(self.lib.vv_pack_wino(tab.data_ptr(), 1, 1, w.data_ptr(), w.numel(), panel.data_ptr(), panel.numel(), KP * N, stream),
+                    'pack_wino')
+            ent = (ver, panel, KP, tab)
+            self.cache[key] = ent
+        bias = m.bias.data_ptr() if m.bias is not None else None
+        L.check(self.lib.vv_conv2d_wino(src.t.data_ptr(), src.cs, 0, src.t.numel(), ent[1].data_ptr(), bias, slope, dst.t.data_ptr(),
+                                        dst.cs, dst_coff, src.B, src.H, src.W, ent[2], m.out_channels, stream), 'conv2d_wino')
+        return True
+
     def _rowk(self, m, src, dst, dst_coff, slope, stream):
         """Few-channel first layers (FlowNetC conv1: 7x7 s2 on 3 channels; FlowNetSD conv0: 3x3 s1 on 6): vv_conv2d_mfma kind 2,
         K = the flattened (kx, c) run under one filter row instead of taps x 16 zero-padded channels."""
@@ -234,6 +265,8 @@ class _Runner:
         if m.out_channels == 2 and self._flow_head(m, de, src, dst, dst_coff, slope, stream):
             return dst
         if not de and self._rowk(m, src, dst, dst_coff, slope, stream):
+            return dst
+        if not de and self._wino(m, src, dst, dst_coff, slope, stream):
             return dst
         packed = self._packed(m)
         _, _, K, KP, N, NP = self.cache[id(m)]
