@@ -25,7 +25,7 @@ from .flow_ops import Correlation, Resample2d, ChannelNorm, correlation, resampl
 # (twice the partial-sum traffic through vv_conv2d_splitk_finish), 128 / 192 leave half the chip idle
 _KS_TARGET = int(os.environ.get('VV_FN2_KS_TARGET', '256'))
 _WINO = os.environ.get('VV_FN2_WINO', '1') != '0'
-_WINO_MIN_WGS = int(os.environ.get('VV_FN2_WINO_MIN_WGS', '200'))
+_WINO_MIN_WGS = int(os.environ.get('VV_FN2_WINO_MIN_WGS', '100'))
 
 
 def _c4(c):
