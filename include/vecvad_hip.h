@@ -380,7 +380,7 @@ int vv_conv2d_mfma(const vv_conv2d_params* p, vv_stream stream);
 /* The same conv(k = 3, stride 1, pad 1) [+ LeakyReLU(slope); slope 1 = none] in Winograd F(2x2, 3x3) form (fp32, a few ulp from the
  * direct form; 2.25x fewer MFMA cycles): FlowNet2's large stride-1 layers (components/misc.py:8-28 as used by FlowNetSD.py:9-103,
  * FlowNetFusion.py:9-64, FlowNetC.py / FlowNetS.py conv3_1 ... conv5_1).  `panel` = vv_pack_wino (mode 0, one entry, G = 1) of the
- * nn.Conv2d weight [Cout][Cin][3][3]: [16][CinP/8][2][Cout][4]; CinP % 8 == 0, Cout % 32 == 0, H % 4 == 0, W % 32 == 0.
+ * nn.Conv2d weight [Cout][Cin][3][3]: [16][CinP/8][2][Cout][4]; CinP % 8 == 0, Cout % 32 == 0, H % 2 == 0, W % 32 == 0.
  * src: NHWC, pixel stride src_cstride floats (multiple of 4), first channel src_coff; src_elems = floats in the source buffer
  * (reads of the K padding past it return zeros; pad channels inside it must be finite).  out: NHWC slice (out_cstride, out_coff). */
 int vv_conv2d_wino(const float* src, int32_t src_cstride, int32_t src_coff, int64_t src_elems, const float* panel, const float* bias,

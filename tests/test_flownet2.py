@@ -84,10 +84,11 @@ def test_conv2d_hip_vs_torch_cpu(kind, R, stride, Cin, Cout, H, W, relu):
 
 
 # (Cin, Cout, H, W, relu): sizes that pass the runner's Winograd gate (H % 4 == 0, W % 32 == 0, >= VV_FN2_WINO_MIN_WGS workgroups at
-# batch 2) -- odd channel counts (K padded to 8 inside the panel; 473 = FlowNetC's conv3_1), 32 / 64 / 256 output channels, a
+# batch 2; H even) -- odd channel counts (K padded to 8 inside the panel; 473 = FlowNetC's conv3_1), 32 / 64 / 256 output channels, a
 # one-block-wide and a one-block-high image, plain and LeakyReLU epilogues
 WINO_CASES = [(64, 128, 32, 64, True), (473, 256, 8, 64, True), (162, 32, 56, 64, True), (11, 64, 28, 64, True),
-              (194, 64, 16, 32, False), (128, 128, 4, 512, True), (24, 32, 60, 32, True)]
+              (194, 64, 16, 32, False), (128, 128, 4, 512, True), (24, 32, 60, 32, True),
+              (512, 512, 14, 32, True), (40, 64, 6, 64, False)]       # H % 4 == 2: the last block's second tile row is masked
 
 
 @pytest.mark.gpu

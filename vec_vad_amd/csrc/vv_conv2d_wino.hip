@@ -1,8 +1,8 @@
 // Winograd F(2x2, 3x3) form of FlowNet2's large stride-1 3x3 convolutions (misc.py:8-28 conv(k=3, s=1) + LeakyReLU(0.1);
 // FlowNetSD.py:9-103 conv1_1 / conv2_1 / conv3_1 ..., FlowNetFusion.py:9-64 conv1_1, FlowNetC.py conv3_1 ...): the same
 // arithmetic as wino_conv_kernel (vv_wino.hip) -- Y = A^T [(G g G^T) . (B^T d B)] A in fp32 on v_mfma_f32_32x32x2_f32, 16 instead
-// of 36 matrix-core K steps per 2x2 outputs -- for images of any size H x W with H % 4 == 0 and W % 32 == 0 (every pyramid level of
-// a 64-aligned frame from H/2 down to H/16), plain NHWC input with any channel count (K zero-padded to 8 in the transformed
+// of 36 matrix-core K steps per 2x2 outputs -- for images of any size H x W with H even and W % 32 == 0 (every pyramid level of
+// a 64-aligned frame from H/2 down to H/32), plain NHWC input with any channel count (K zero-padded to 8 in the transformed
 // panel; the activation buffers are ceil4(C) wide and finite, vec_vad_amd/flownet2.py::_Buf), bias + LeakyReLU epilogue, output
 // into a channel slice of the consumer's concat buffer.  Round 3 ran these layers on conv2d_mfma_kernel at 95 - 105 TFLOP/s
 // (0.6 - 0.67 of the fp32 MFMA peak, direct form): they fill the chip, so 2.25x fewer MFMAs is time, not idle CUs.
@@ -40,7 +40,7 @@ conv2d_wino_kernel(const float* __restrict__ src, const int src_cs, const int sr
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
   const int nn = w % NN; w /= NN;      // the N tiles of one pixel block are neighbours in launch order: they share the halo in L2
-  const int bx = W / (2 * TPI), by = H / (2 * TROWS);
+  const int bx = W / (2 * TPI), by = (H + 2 * TROWS - 1) / (2 * TROWS);      // H % 4 == 2: the last block's second tile row is masked
   const int xb = w % bx; w /= bx;
   const int yb = w % by;
   const int b = w / by;
@@ -187,7 +187,7 @@ conv2d_wino_kernel(const float* __restrict__ src, const int src_cs, const int sr
     ya[0] = ya[0] < 0.f ? ya[0] * slope : ya[0]; ya[1] = ya[1] < 0.f ? ya[1] * slope : ya[1];
     yv[0] = yv[0] < 0.f ? yv[0] * slope : yv[0]; yv[1] = yv[1] < 0.f ? yv[1] * slope : yv[1];
     const int so = (((b * H + oy) * W + ox) * out_cs) * 4;
-    if (nok) {
+    if (nok && oy < H) {
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[0]), rsO, vo, so, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[1]), rsO, vo, so + out_cs * 4, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[0]), rsO, vo, so + W * out_cs * 4, 0);
@@ -199,17 +199,17 @@ conv2d_wino_kernel(const float* __restrict__ src, const int src_cs, const int sr
 }  // namespace
 
 // FlowNet2 conv(k = 3, stride 1, pad 1) [+ LeakyReLU(slope)] in Winograd F(2x2, 3x3) form.  `panel` = vv_pack_wino(mode 0) of the
-// nn.Conv2d weight [Cout][Cin][3][3] with K padded to CinP (multiple of 8), N = Cout (multiple of 32).  H % 4 == 0, W % 32 == 0.
+// nn.Conv2d weight [Cout][Cin][3][3] with K padded to CinP (multiple of 8), N = Cout (multiple of 32).  H % 2 == 0, W % 32 == 0.
 // src_elems: number of floats in the source buffer (loads past it return zeros: the K padding of the last pixel).
 extern "C" int vv_conv2d_wino(const float* src, int32_t src_cstride, int32_t src_coff, int64_t src_elems, const float* panel,
                               const float* bias, float slope, float* out, int32_t out_cstride, int32_t out_coff, int32_t B, int32_t H,
                               int32_t W, int32_t CinP, int32_t Cout, vv_stream stream) {
   if (!src || !panel || !out || B <= 0) return VV_ERR_BAD_ARG;
-  if (H % 4 || W % 32 || CinP % 8 || Cout % 32 || src_cstride % 4 || src_coff % 4) return VV_ERR_UNSUPPORTED;
+  if (H % 2 || W % 32 || CinP % 8 || Cout % 32 || src_cstride % 4 || src_coff % 4) return VV_ERR_UNSUPPORTED;
   // 32-bit byte offsets into the source / output buffers
   if ((int64_t)B * H * W * src_cstride * 4 >= (1ll << 31) || (int64_t)B * H * W * out_cstride * 4 >= (1ll << 31)) return VV_ERR_UNSUPPORTED;
   const int NN = Cout / 32;
-  const int total = B * (H / 4) * (W / 32) * NN;
+  const int total = B * ((H + 3) / 4) * (W / 32) * NN;
   const int nper = (total + 7) / 8;
   VV_LAUNCH(conv2d_wino_kernel, dim3(nper * 8), dim3(WN), 0, (hipStream_t)stream, src, src_cstride, src_coff, src_elems, panel, bias,
             slope, out, out_cstride, out_coff, B, H, W, CinP, Cout, NN, total, nper);

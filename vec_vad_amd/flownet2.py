@@ -181,7 +181,7 @@ class _Runner:
         kernel with its split-K).  VV_FN2_WINO=0 switches it off."""
         if not _WINO or m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1) or m.out_channels % 32:
             return False
-        if src.H % 4 or src.W % 32 or src.B * (src.H // 4) * (src.W // 32) * (m.out_channels // 32) < _WINO_MIN_WGS:
+        if src.H % 2 or src.W % 32 or src.B * ((src.H + 3) // 4) * (src.W // 32) * (m.out_channels // 32) < _WINO_MIN_WGS:
             return False
         if src.t.numel() * 4 >= 2 ** 31 or dst.t.numel() * 4 >= 2 ** 31:
             return False
