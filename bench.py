@@ -247,8 +247,9 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
                                            'VV_FUSE_BN_SUMS=0 times the bare convolutions (frac +0.013, step +0.15 ms)')
     else:
         r = {'bound': 'hbm',
-             'kernel': 'conv_mfma_kernel<..., BF=true>: 3x3 implicit GEMM, bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation, '
-                       'forward + data-gradient; achieved = algorithmic bytes (input once + output once, bf16 tensors) / time',
+             'kernel': 'conv_gemm16p_kernel (16x16 / 8x8 / 4x4 levels: persistent producer / consumer GEMM-shaped kernel, round 4) + '
+                       'conv_mfma_kernel<..., BF=true> (32x32 level): 3x3 conv forward + data-gradient, bf16 operands on '
+                       'v_mfma_f32_32x32x16_bf16, fp32 accumulation; achieved = algorithmic bytes (input once + output once, bf16 tensors) / time',
              'achieved': b_alg / t / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b_alg / t / HBM_PEAK,
              'mfma_tflops': f_alg / t / 1e12, 'frac_of_bf16_mfma_peak': f_alg / t / BF16_MFMA_PEAK}
     r.update(common)

@@ -34,8 +34,9 @@ def main():
         f, w = fetch[k] / nf[k], write[k] / nw[k]
         kernels.append({'kernel': k, 'launches': nf[k], 'FETCH_SIZE_KB_per_launch': round(f, 1), 'WRITE_SIZE_KB_per_launch': round(w, 1),
                         'hbm_bytes_per_launch_corrected': int((2 * f + w) * 1024)})
+    # the 3x3 forward + data-gradient family: Winograd kernels (fp32), or the direct KIND = 0 kernel + the persistent bf16 kernel
     fam = [k for k in kernels if k['kernel'].startswith('wino_conv_kernel')] or \
-          [k for k in kernels if re.match(r'conv_mfma_kernel<\d+, \d+, \d+, \d+, 0,', k['kernel'])]
+          [k for k in kernels if re.match(r'conv_mfma_kernel<\d+, \d+, \d+, \d+, 0,', k['kernel']) or k['kernel'].startswith('conv_gemm16p_kernel')]
     n = sum(k['launches'] for k in fam)
     out = {
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline',
@@ -43,7 +44,7 @@ def main():
                  'wide coalesced reads, MI355X_MICROARCH.md section HBM)',
         'conv_family': {'kernels': sorted(set(k['kernel'] for k in fam)), 'launches': n,
                         'hbm_bytes_per_launch_corrected': int(sum(k['hbm_bytes_per_launch_corrected'] * k['launches'] for k in fam) / max(n, 1))},
-        'kernels': kernels[:40],
+        'kernels': kernels[:60],
     }
     # optional 4th argument: number of forward passes the profiled command ran (FlowNet2: every pass is the same work) -> whole-run
     # HBM bytes per pass.  A UNet bench process is NOT uniform (train steps + forward-only passes + one-off set-up), so for it the

@@ -928,6 +928,18 @@ extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
   if ((p->pad0 & VV_WGRAD_DY_BF16) && p->dy.coff % 2) return VV_ERR_BAD_ARG;
   if ((p->pad0 & VV_WGRAD_X_BF16) && !(p->pad0 & VV_WGRAD_DY_BF16)) return VV_ERR_UNSUPPORTED;
   if (ring_ok(p)) return dispatch_r(p, st);
+  {
+    // vv_wgrad_bf16_plan sizes ksplit / the slabs from (kind, flags, geometry) alone: a launch it planned for the LDS-ring kernel
+    // must not fall through to the register-staged one (other tiles and block shapes: slabs would be missing) -- refuse instead
+    const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
+    if (p->kind == VV_CONV3 && (p->pad0 & both) == both && p->CinP > 0 && p->CinP % 8 == 0) {
+      const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
+      int cbk, obk;
+      ring_block_shape(p->H, NCI, NCO, &cbk, &obk);
+      RGeo r;
+      if (rgeo(p->H, p->W, cbk == 1 && obk == 1, &r)) return VV_ERR_BAD_ARG;      // planned as ring, not ring-launchable (alignment / input mode)
+    }
+  }
   if (p->kind != VV_CONV3) {                   // weight gradient of the transposed conv (H x W = its input resolution)
     switch (p->H == p->W ? p->H : 0) {
       case 16: return dispatch_t<8, 16, 1>(p, st);
