@@ -420,7 +420,7 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     rec['execution'] = {'mode': ('hipGraph replay of the captured step (%d launches in %d segment(s)); timed steps 0..%d ran the eager '
                                  'launch loop with HIP events' % (cap.launches, len(cap.segments), n_ev - 1)) if (graph and cap is not None)
                         else 'eager launch loop (ctypes), HIP events around the conv-family launches in every timed step',
-                        'launches_per_step': cap.launches if cap is not None else len(ws.fwd[True].calls) + len(ws.bwd.calls) + 3,
+                        'launches_per_step': cap.launches if cap is not None else len(ws.fwd[True].calls) + len(getattr(ws, "bwd_cur", ws.bwd).calls) + 3,
                         'host_enqueue_ms_per_step': 1e3 * t_host / steps}
     if graph and cap is not None:
         # 'free': the captured backward pass has two branches (weight gradients beside the data-gradient / BatchNorm chain), so

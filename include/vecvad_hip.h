@@ -279,6 +279,12 @@ int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const float* dou
                    const float* invstd, float* bnpart, int32_t flags /* bit 0: store dA as bf16 (VV_BNBWD_DA_BF16 consumer); bit 1: y holds bf16 elements */,
                    vv_stream stream);
 int vv_outconv_bwd_nblk(int32_t B, int32_t HW);
+/* vv_outconv_fwd followed by vv_outconv_bwd with dout = gscale * (out - target), in ONE pass over y (the fused train step: the
+ * reference's loss.backward() right behind the forward, train.py:385-402): same score / dA / partial / bnpart bits as the two
+ * calls, y read once, d(out) never stored (p->dout4 may be NULL; p->gscale must be given).  flags: bit 0 = dA stored as bf16,
+ * bit 1 = y holds bf16 elements (must equal bit 0 of p->pad0). */
+int vv_outconv_fwdbwd(const vv_outconv_params* p, float* dA, int64_t dA_gstride, float* partial, const float* mean,
+                      const float* invstd, float* bnpart, int32_t flags, vv_stream stream);
 int vv_outconv_bwd_reduce(int32_t G, int32_t C, int32_t nblk, const float* partial, const int32_t* oc,
                           float* dW, float* db, int64_t grad_gstride, vv_stream stream);
 

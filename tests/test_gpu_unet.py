@@ -737,3 +737,31 @@ def test_useflow_false_matches_oracle():
     assert o is None
     rs2, _ = O.score_pass(sdo, spec, x, x_of, 5, useFlow=False)
     np.testing.assert_allclose(r.cpu().numpy(), rs2, rtol=1e-3)
+
+
+@pytest.mark.parametrize('precision,kind,nf,B', [('fp32', 'net4', 32, 6), ('bf16', 'full', 32, 5), ('fp32', '1raw1of', 64, 3)])
+def test_fused_outconv_forward_backward_bitwise_equal_to_two_launches(monkeypatch, precision, kind, nf, B):
+    """vv_outconv_fwdbwd (round 4): the 1x1 output conv's forward and backward in one pass over y -- what the fused train step runs --
+    leaves exactly the bits of vv_outconv_fwd + vv_outconv_bwd: per-cube scores, every parameter gradient of the bank (the
+    output conv's through its partials, all others through dA and the BatchNorm-backward partial sums)."""
+    monkeypatch.setenv('VV_PRECISION', precision)
+    from oracle import unet_oracle as O
+    res = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('VV_FUSE_OUTCONV', fuse)
+        net, sd, tot_of = _build(kind, False, nf=nf)
+        net.train()
+        bank = net.bank()
+        assert bank.fuse_outconv == (fuse == '1')
+        raw, flow = O.seeded_cubes(B, tot_of, 5)
+        ws = bank.set_input_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), torch.arange(B, device='cuda'))
+        bank.forward(ws, True, outputs=False)
+        assert getattr(ws.fwdq[True], 'fused_outconv', False) == (fuse == '1')
+        bank.backward(ws, fused=True)
+        labels = [c[2] for c in bank.backward_plan(ws, fused=bank.fuse_outconv).calls]
+        assert ('outconv_bwd' in labels) == (fuse == '0')
+        torch.cuda.synchronize()
+        res.append((ws.score.clone(), bank.grads.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert float(res[0][1].abs().max()) > 0

@@ -124,6 +124,7 @@ _SIGS = {
     'vv_outconv_bwd': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
                                c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'vv_outconv_bwd_nblk': (c_i32, [c_i32, c_i32]),
+    'vv_outconv_fwdbwd': (c_i32, [C.POINTER(OutconvParams), c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'vv_outconv_bwd_reduce': (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'vv_bias_grad': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'vv_bias_from_partials': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),

@@ -250,6 +250,9 @@ class UNetBank:
         # with them the pooled / frame-erased inputs: every tensor a bf16 kernel stages is then bf16 (VV_CONV_ALLSRC_BF16)
         self.y16 = self.dz16 and self.da16 and os.environ.get('VV_BF16_Y', '1') != '0'
         self.fflag = self.cflag | ((L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16) if self.y16 else 0)      # forward launches
+        # fused train / scoring steps (no reconstruction store): the 1x1 output conv's forward and backward in ONE pass over y
+        # (vv_outconv_fwdbwd); the module API (forward -> outputs -> set_dout -> backward) keeps the two launches
+        self.fuse_outconv = os.environ.get('VV_FUSE_OUTCONV', '1') != '0'
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
@@ -408,6 +411,8 @@ class UNetBank:
                 gs.append(2.0 * self.lambda_of / (B * n_of * OF_C * HWp))
         ws.gscale.copy_(torch.tensor(gs))
         ws.n_raw, ws.n_of = n_raw, n_of
+        if self.fuse_outconv:          # written by the forward plan's vv_outconv_fwdbwd, read by the backward plan
+            self._alloc_outconv_bwd(ws, B)
         ws.fwd = {True: self._plan_forward(ws, B, True),
                   False: self._plan_eval(ws, B) if self.eval_fold else self._plan_forward(ws, B, False)}
         # the same plans without the reconstruction store (FusedTrainer's train step and scoring pass only read the per-cube scores
@@ -415,6 +420,7 @@ class UNetBank:
         ws.fwdq = {True: self._plan_forward(ws, B, True, out4=False),
                    False: self._plan_eval(ws, B, out4=False) if self.eval_fold else self._plan_forward(ws, B, False, out4=False)}
         ws.bwd = None
+        ws.bwdq = None                 # the backward plan without its vv_outconv_bwd launch (behind a fused forward)
         ws.out4_valid = False          # True while ws.out4 holds the reconstructions of the LAST forward on this workspace
         return ws
 
@@ -435,6 +441,34 @@ class UNetBank:
         y, t = ws.y[s.idx], ws.t[l.up]
         return (L.IN_CAT, L.view(y, s.cout, 0, y.stride(0)), self._p(ws.ab[0, s.idx]), self._p(ws.ab[1, s.idx]),
                 L.view(t, t.shape[2], 0, t.stride(0)), s.cout, None)
+
+    def _alloc_outconv_bwd(self, ws, B):
+        if hasattr(ws, 'gA_last'):
+            return
+        lib, lay, Ga = self.lib, self.lay, self.Ga
+        d = self.device
+        f = lambda *shape: torch.empty(*shape, device=d, dtype=torch.float32)
+        HWp = HW0 * HW0
+        ws.gA_last = f(Ga, B * HWp, self.nf)
+        nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
+        ws.bnpart = f(Ga, max(max(n, lib.vv_wino_ntiles(B, l.H)) * 2 * l.cout for n, l in zip(nblk, lay.convs)))
+        ws.ocpart = f(Ga, B, 4 * self.nf + 4)
+
+    def backward_plan(self, ws, fused):
+        """The backward plan; fused = behind a forward that ran vv_outconv_fwdbwd (its vv_outconv_bwd launch is left out)."""
+        if ws.bwd is None:
+            ws.bwd = self._plan_backward(ws, ws.B)
+        if not fused:
+            return ws.bwd
+        if ws.bwdq is None:
+            q = _Plan()
+            q.keep = ws.bwd.keep
+            for c, m in zip(ws.bwd.calls, ws.bwd.meta):
+                if c[2] != 'outconv_bwd':
+                    q.calls.append(c)
+                    q.meta.append(m)
+            ws.bwdq = q
+        return ws.bwdq
 
     def _plan_forward(self, ws, B, train, out4=True):
         lib, lay, Ga, g0 = self.lib, self.lay, self.Ga, self.g0
@@ -506,9 +540,15 @@ class UNetBank:
                              self._p(self.oc, g0), ws.cube.data_ptr(), ws.cube.shape[2], 1 if self.y16 else 0, ws.flow.data_ptr(),
                              ws.flow.shape[2], 0, self._p(self.tsrc, g0), self._p(self.tcoff, g0), ws.out4.data_ptr() if out4 else None,
                              ws.score.data_ptr(), ws.gscale.data_ptr() if train else None,
-                             ws.dout4.data_ptr() if train else None)
+                             ws.dout4.data_ptr() if (train and not (self.fuse_outconv and not out4)) else None)
         P.keep.append(op)
-        P.add(lib.vv_outconv_fwd, (C.byref(op),), 'outconv')
+        if train and self.fuse_outconv and not out4:
+            P.fused_outconv = True
+            P.add(lib.vv_outconv_fwdbwd, (C.byref(op), ws.gA_last.data_ptr(), ws.gA_last.stride(0), ws.ocpart.data_ptr(),
+                                          self._p(ws.ab[2, last.idx]), self._p(ws.ab[3, last.idx]), ws.bnpart.data_ptr(),
+                                          (1 if self.da16 else 0) | (2 if self.y16 else 0)), 'outconv')
+        else:
+            P.add(lib.vv_outconv_fwd, (C.byref(op),), 'outconv')
         return P
 
     def mark_dirty(self):
@@ -607,15 +647,13 @@ class UNetBank:
         HWp = HW0 * HW0
         last = lay.convs[-1]
         # buffers
-        ws.gA_last = f(Ga, B * HWp, nf)
+        self._alloc_outconv_bwd(ws, B)
         ws.D = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.idx > 0}
         ws.DT = [f(Ga, B * H * H, ci) for (_, H, ci, co) in lay.convT]
         ws.dz2 = [f(Ga, B * HWp * nf), f(Ga, B * HWp * nf)]   # dy of consecutive layers alternate (weight-grad runs on a side stream)
         ws.dz = ws.dz2[0]
         nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
-        ws.bnpart = f(Ga, max(max(n, lib.vv_wino_ntiles(B, l.H)) * 2 * l.cout for n, l in zip(nblk, lay.convs)))
         ws.bnscr = f(Ga, 2 * lay.cmax)
-        ws.ocpart = f(Ga, B, 4 * nf + 4)
         ws.bscr = f(Ga, (B * HWp + 1023) // 1024 * lay.cmax)
         ws.dstats = f(Ga, max(max(lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.cflag), lib.vv_conv_ntiles(B, l.H, l.H),
                                   lib.vv_wino_ntiles(B, l.H)) * 2 * l.cin for l in lay.convs if l.mode == L.IN_CAT))
@@ -883,11 +921,11 @@ class UNetBank:
             self.mark_dirty()
         return ws.score
 
-    def backward(self, ws):
-        """Gradients of everything wrt ws.dout4 into self.grads (conv biases in front of BatchNorm get exact zeros)."""
-        if ws.bwd is None:
-            ws.bwd = self._plan_backward(ws, ws.B)
-        ws.bwd.run(self._stream())
+    def backward(self, ws, fused=False):
+        """Gradients of everything wrt ws.dout4 into self.grads (conv biases in front of BatchNorm get exact zeros).
+        fused: the forward was the scores-only train plan (outputs=False), whose vv_outconv_fwdbwd already did the output conv's
+        backward with the loss gradient -- ws.dout4 is then neither written nor read."""
+        self.backward_plan(ws, fused and self.fuse_outconv).run(self._stream())
 
     def losses(self, ws):
         """(loss_raw, loss_of) as device scalars from the per-cube squared errors (train.py:385-392)."""
@@ -967,7 +1005,7 @@ class UNetBank:
     def train_step(self, ws, lr=1e-3, eps=1e-7, grad_scale=1.0, allreduce=None):
         """Fused fast path: forward (train) -> backward -> [gradient all-reduce] -> Adam.  No host sync."""
         self.forward(ws, True, outputs=False)
-        self.backward(ws)
+        self.backward(ws, fused=True)
         if allreduce is not None:
             allreduce(self.grads)
         self.adam_step(lr=lr, eps=eps, grad_scale=grad_scale)

@@ -901,6 +901,159 @@ inline int nblocks(int64_t n, int cap = 1 << 20) {
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+// Forward AND backward of the 1x1 output conv in one pass over y (round 4): the fused train step runs vv_outconv_bwd right behind
+// vv_outconv_fwd with d(loss)/d(out) = gscale * (out - target) -- nothing in between can change it -- so the activation tensor in
+// front of the output conv (the largest of the network: 32 channels at full resolution, 335 MB per launch in BASELINE config 4)
+// crosses HBM once instead of twice and the d(out) tensor never exists.  Per pixel: outconv_fwd_kernel's arithmetic, then
+// outconv_bwd_kernel's with d = gscale * (out - target) taken from registers; same operation order as the two kernels -> the same
+// bits in score, dA, the weight / bias gradient partials and the BatchNorm-backward partial sums.
+template <int CC>
+__global__ void __launch_bounds__(VV_WG)
+outconv_fwdbwd_kernel(const vv_outconv_params p, float* __restrict__ dA, const int64_t dA_gstride, float* __restrict__ partial,
+                      const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ bnpart,
+                      const int flags, const int total, const int nper) {
+  constexpr int C = CC, LPP = CC / 4, NPG = VV_WG / LPP, NOUT = 4 * CC + 4;
+  __shared__ float sh[NPG][LPP * 16 + 4];
+  __shared__ float red[4];
+  const int wi = vv_xcd_remap(blockIdx.x, nper);
+  if (wi >= total) return;
+  const int g = wi % p.G, cube = wi / p.G;
+  const int tid = threadIdx.x, sub = tid % LPP, pg = tid / LPP;
+  const int c = sub * 4;
+  const int oc = p.oc[g];
+  const int64_t abo = (int64_t)g * p.ab_gstride + c;
+  const float4 a4 = *reinterpret_cast<const float4*>(p.a + abo), b4 = *reinterpret_cast<const float4*>(p.b + abo);
+  float4 wv[4];          // forward rows (rows >= oc: zero)
+  float4 wb[4];          // backward rows as outconv_bwd_kernel reads them (rows >= oc hold the next parameter: d is 0 there)
+  float bias[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    wb[co] = *reinterpret_cast<const float4*>(p.w + (int64_t)g * p.param_gstride + co * C + c);
+    if (co < oc) { wv[co] = wb[co]; bias[co] = p.bias[(int64_t)g * p.param_gstride + co]; }
+    else { wv[co] = make_float4(0, 0, 0, 0); bias[co] = 0.f; }
+  }
+  const int tsrc = p.tgt_src[g], tco = p.tgt_coff[g];
+  const float* tgt = tsrc == 0 ? p.tgt0 : p.tgt1;
+  const int tcs = tsrc == 0 ? p.tgt0_cstride : p.tgt1_cstride;
+  const float gs = p.gscale[g];
+  const float* __restrict__ y = p.y + (int64_t)g * p.y_gstride;
+  float* __restrict__ dAg = dA + (int64_t)g * dA_gstride;
+  const int64_t MB = (int64_t)p.B * p.HW;
+  float sse = 0.f;
+  float4 dw[4];
+  float db[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int co = 0; co < 4; ++co) dw[co] = make_float4(0, 0, 0, 0);
+  float4 m4 = make_float4(0, 0, 0, 0), i4 = m4, s1 = m4, s2 = m4;
+  if (bnpart) { m4 = *reinterpret_cast<const float4*>(mean + abo); i4 = *reinterpret_cast<const float4*>(invstd + abo); }
+  auto ldy = [&](const int i) -> float4 {
+    const int64_t pix = (int64_t)cube * p.HW + i;
+    return (p.pad0 & 1) ? vv_unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + pix * C + c))
+                        : *reinterpret_cast<const float4*>(y + pix * C + c);
+  };
+  auto ldt = [&](const int i) -> float4 {      // every lane of the pixel reads the target (the backward half needs d in all of them)
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* q = tgt + ((int64_t)cube * p.HW + i) * tcs + tco;
+    t.x = q[0];
+    if (oc > 1) t.y = q[1];
+    if (oc > 2) t.z = q[2];
+    if (oc > 3) t.w = q[3];
+    return t;
+  };
+  auto body = [&](const int i, const float4 yv, const float4 tq) {
+    const int64_t pix = (int64_t)cube * p.HW + i;
+    const float4 v = vv_act4(yv, a4, b4);
+    float o[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      float d = v.x * wv[co].x;
+      d = fmaf(v.y, wv[co].y, d); d = fmaf(v.z, wv[co].z, d); d = fmaf(v.w, wv[co].w, d);
+#pragma unroll
+      for (int sh_ = 1; sh_ < LPP; sh_ <<= 1) d += __shfl_xor(d, sh_);
+      o[co] = d + bias[co];
+    }
+    const float tv[4] = {tq.x, tq.y, tq.z, tq.w};
+    float e[4] = {0, 0, 0, 0}, dd[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      if (co < oc) e[co] = o[co] - tv[co]; else o[co] = 0.f;
+      dd[co] = gs * e[co];
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co) if (co < oc) sse = fmaf(e[co], e[co], sse);
+      if (p.out4) *reinterpret_cast<float4*>(p.out4 + ((int64_t)g * MB + pix) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      if (p.dout4) *reinterpret_cast<float4*>(p.dout4 + ((int64_t)g * MB + pix) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    }
+    float4 q = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      q.x = fmaf(dd[co], wb[co].x, q.x); q.y = fmaf(dd[co], wb[co].y, q.y);
+      q.z = fmaf(dd[co], wb[co].z, q.z); q.w = fmaf(dd[co], wb[co].w, q.w);
+      dw[co].x = fmaf(dd[co], v.x, dw[co].x); dw[co].y = fmaf(dd[co], v.y, dw[co].y);
+      dw[co].z = fmaf(dd[co], v.z, dw[co].z); dw[co].w = fmaf(dd[co], v.w, dw[co].w);
+      db[co] += dd[co];
+    }
+    if (flags & 1) {
+      const uint2 h = vv_pack_bf16x4(q);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dAg) + pix * C + c) = h;
+      q = vv_unpack_bf16x4(h);
+    } else {
+      *reinterpret_cast<float4*>(dAg + pix * C + c) = q;
+    }
+    if (bnpart) {
+      const float4 gq = make_float4(v.x > 0.f ? q.x : 0.f, v.y > 0.f ? q.y : 0.f, v.z > 0.f ? q.z : 0.f, v.w > 0.f ? q.w : 0.f);
+      s1.x += gq.x; s1.y += gq.y; s1.z += gq.z; s1.w += gq.w;
+      s2.x = fmaf(gq.x, (yv.x - m4.x) * i4.x, s2.x); s2.y = fmaf(gq.y, (yv.y - m4.y) * i4.y, s2.y);
+      s2.z = fmaf(gq.z, (yv.z - m4.z) * i4.z, s2.z); s2.w = fmaf(gq.w, (yv.w - m4.w) * i4.w, s2.w);
+    }
+  };
+  for (int i0 = pg; i0 < p.HW; i0 += 4 * NPG) {
+    float4 yq4[4], tq4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NPG < p.HW) { yq4[u] = ldy(i0 + u * NPG); tq4[u] = ldt(i0 + u * NPG); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NPG < p.HW) body(i0 + u * NPG, yq4[u], tq4[u]);
+  }
+  // per-cube squared error (outconv_fwd_kernel's reduction)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sse += __shfl_xor(sse, off);
+  if ((tid & 63) == 0) red[tid >> 6] = sse;
+  // weight / bias gradient partials and BatchNorm-backward partial sums (outconv_bwd_kernel's reductions)
+#pragma unroll
+  for (int co = 0; co < 4; ++co) *reinterpret_cast<float4*>(&sh[pg][sub * 16 + co * 4]) = dw[co];
+  if (sub == 0) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co) sh[pg][LPP * 16 + co] = db[co];
+  }
+  __syncthreads();
+  if (tid == 0) p.score[(int64_t)g * p.B + cube] = (red[0] + red[1]) + (red[2] + red[3]);
+  float* out = partial + ((int64_t)g * p.B + cube) * NOUT;
+  for (int e = tid; e < NOUT; e += VV_WG) {
+    float s = 0.f;
+    if (e < 4 * CC) {
+      const int co = e / CC, cc = e % CC;
+      for (int k = 0; k < NPG; ++k) s += sh[k][(cc >> 2) * 16 + co * 4 + (cc & 3)];
+    } else {
+      for (int k = 0; k < NPG; ++k) s += sh[k][LPP * 16 + (e - 4 * CC)];
+    }
+    out[e] = s;
+  }
+  if (!bnpart) return;
+  __syncthreads();
+  *reinterpret_cast<float4*>(&sh[pg][sub * 8]) = s1;
+  *reinterpret_cast<float4*>(&sh[pg][sub * 8 + 4]) = s2;
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int which = tid / CC, cc = tid % CC;
+    float s = 0.f;
+    for (int k = 0; k < NPG; ++k) s += sh[k][(cc >> 2) * 8 + which * 4 + (cc & 3)];
+    bnpart[((int64_t)(g * p.B + cube) * 2 + which) * C + cc] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" int vv_pack_weights(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params,
@@ -1017,6 +1170,21 @@ extern "C" int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream) {
   if (p->C == 32) VV_LAUNCH(outconv_fwd_kernel<32>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, total, nper);
   else if (p->C == 64) VV_LAUNCH(outconv_fwd_kernel<64>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, total, nper);
   else return VV_ERR_UNSUPPORTED;      /* features_root 32 (every shipped config) or 64 (SelfCompleteNet1raw1of's default) */
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+extern "C" int vv_outconv_fwdbwd(const vv_outconv_params* p, float* dA, int64_t dA_gstride, float* partial, const float* mean,
+                                 const float* invstd, float* bnpart, int32_t flags, vv_stream stream) {
+  if (!p || !p->y || !p->a || !p->b || !p->w || !p->bias || !p->oc || !p->tgt_src || !p->tgt_coff || !p->score || !p->tgt0 ||
+      !p->gscale || !dA || !partial)
+    return VV_ERR_BAD_ARG;
+  if (bnpart && (!mean || !invstd)) return VV_ERR_BAD_ARG;
+  if (((flags & 2) != 0) != ((p->pad0 & 1) != 0)) return VV_ERR_BAD_ARG;      // one y tensor: both halves must agree on its element type
+  const int total = p->B * p->G, nper = (total + 7) / 8;
+  if (p->C == 32) VV_LAUNCH(outconv_fwdbwd_kernel<32>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, dA, dA_gstride, partial, mean, invstd, bnpart, flags, total, nper);
+  else if (p->C == 64) VV_LAUNCH(outconv_fwdbwd_kernel<64>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, dA, dA_gstride, partial, mean, invstd, bnpart, flags, total, nper);
+  else return VV_ERR_UNSUPPORTED;
   VV_CHECK_LAUNCH();
   return VV_OK;
 }

@@ -212,10 +212,9 @@ class FusedTrainer:
         bank = self.bank
         self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], bank._stream())
         ws.out4_valid = bool(self.keep_outputs)
+        ws.bwd_cur = bank.backward_plan(ws, fused=not self.keep_outputs and bank.fuse_outconv)
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
         bank.mark_dirty()
-        if ws.bwd is None:
-            ws.bwd = bank._plan_backward(ws, ws.B)
 
     def _adam(self):
         bank = self.bank
@@ -227,7 +226,7 @@ class FusedTrainer:
         self._forward_train(ws)
         if self.overlap:
             if self.buckets is None:
-                self._run_dual(ws.bwd)
+                self._run_dual(ws.bwd_cur)
             else:
                 def dec(events):     # decoder bucket: needs the side stream's decoder weight-grads too
                     torch.cuda.current_stream(bank.device).wait_event(events['sideT0'])
@@ -236,12 +235,12 @@ class FusedTrainer:
                 def mid(events):     # deep-encoder bucket: its last weight-grad reduction ran on the side stream
                     torch.cuda.current_stream(bank.device).wait_stream(self.side)
                     self.buckets.launch(1)
-                self._run_dual(ws.bwd, after={self.split_label: dec, self.split_label_mid: mid})
+                self._run_dual(ws.bwd_cur, after={self.split_label: dec, self.split_label_mid: mid})
                 self._finish_exchange()
         elif self.buckets is None:
-            self._run(ws.bwd, stream)
+            self._run(ws.bwd_cur, stream)
         else:
-            self._run(ws.bwd, stream, after={self.split_label: lambda: self.buckets.launch(2),
+            self._run(ws.bwd_cur, stream, after={self.split_label: lambda: self.buckets.launch(2),
                                               self.split_label_mid: lambda: self.buckets.launch(1)})
             self._finish_exchange()
         if self.event_hook is not None and (self.event_labels is None or 'adam' in self.event_labels):
@@ -307,8 +306,7 @@ class FusedTrainer:
     def _capture_train(self, raw_u8, flow, B):
         bank, lib = self.bank, self.bank.lib
         ws = bank.workspace(B)
-        if ws.bwd is None:
-            ws.bwd = bank._plan_backward(ws, B)
+        bwd = bank.backward_plan(ws, fused=not self.keep_outputs and bank.fuse_outconv)
         if bank.adam_m is None:
             bank.adam_m, bank.adam_v = torch.zeros_like(bank.params), torch.zeros_like(bank.params)
         idx = torch.zeros(B, dtype=torch.long, device=bank.device)
@@ -343,18 +341,18 @@ class FusedTrainer:
         seg.append(nbt)
         segments = []
         lo = 0
-        for i, c in enumerate(ws.bwd.calls):
+        for i, c in enumerate(bwd.calls):
             if not dual:
                 seg.append(self._thunk(*c))
             if self.buckets is not None and c[2] in (self.split_label, self.split_label_mid):
                 k = 2 if c[2] == self.split_label else 1
                 if dual:
-                    seg.append(dual_range(ws.bwd, lo, i + 1))
+                    seg.append(dual_range(bwd, lo, i + 1))
                     lo = i + 1
                 segments.append((seg, (lambda k=k: self.buckets.launch(k))))
                 seg = []
         if dual:
-            seg.append(dual_range(ws.bwd, lo, len(ws.bwd.calls)))
+            seg.append(dual_range(bwd, lo, len(bwd.calls)))
         if self.buckets is not None:
             segments.append((seg, self._finish_exchange))
             seg = []
@@ -370,7 +368,7 @@ class FusedTrainer:
         cap = type('Captured', (), {})()
         cap.ws, cap.idx, cap.keep = ws, idx, keep
         nseg_bwd = 1 + (2 if self.buckets is not None else 0)
-        cap.launches = sum(len(t) for t, _ in segments) + (len(ws.bwd.calls) - nseg_bwd + len(fwd.calls) - 1 if dual else 0)
+        cap.launches = sum(len(t) for t, _ in segments) + (len(bwd.calls) - nseg_bwd + len(fwd.calls) - 1 if dual else 0)
         cap.schedule = dual or 'one stream'
         cap.segments = self._capture(segments)
         return cap
@@ -444,7 +442,7 @@ class FusedTrainer:
         if b:
             ws = bank.set_input_cubes(raw_u8, flow, idx)
             self._forward_train(ws)
-            self._run(ws.bwd, bank._stream())
+            self._run(ws.bwd_cur, bank._stream())
             bank.grads.mul_(b * self.world / float(n_global))
         else:
             bank.grads.zero_()
