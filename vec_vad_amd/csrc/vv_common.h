@@ -76,6 +76,23 @@ __device__ __forceinline__ v2f vv_pk_lo_pm_hi(const v2f x, const v2f y) {
   return r;
 }
 
+// Butterfly sum over aligned groups of LPP (8 | 16) lanes, result in every lane -- the same pairings as d += __shfl_xor(d, 1 | 2 |
+// 4 | 8) (so the same bits), but as DPP operand modifiers of three / four VALU adds instead of ds_bpermute round trips through the
+// LDS crossbar: xor 1 / xor 2 = quad permutes; once a quad is uniform, row_half_mirror (l <-> 7 - l) fetches the other quad of the
+// 8-lane group and row_mirror (l <-> 15 - l) the other half of the 16-lane row.
+template <int LPP>
+__device__ __forceinline__ float vv_group_sum(float d) {
+  static_assert(LPP == 8 || LPP == 16, "8 or 16 lanes per group");
+  auto dpp = [](const float v, const auto CTRL) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(CTRL)::value, 0xF, 0xF, false));
+  };
+  d += dpp(d, std::integral_constant<int, 0xB1>{});        // quad_perm [1,0,3,2]
+  d += dpp(d, std::integral_constant<int, 0x4E>{});        // quad_perm [2,3,0,1]
+  d += dpp(d, std::integral_constant<int, 0x141>{});       // row_half_mirror
+  if constexpr (LPP == 16) d += dpp(d, std::integral_constant<int, 0x140>{});      // row_mirror
+  return d;
+}
+
 // 4 floats -> 4 bf16 (round to nearest even), packed in channel order
 __device__ __forceinline__ uint2 vv_pack_bf16x4(float4 v) {
   const v2bf lo = __builtin_convertvector((v2f){v.x, v.y}, v2bf);

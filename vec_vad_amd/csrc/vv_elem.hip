@@ -472,8 +472,7 @@ outconv_fwd_kernel(const vv_outconv_params p, const int total, const int nper) {
     for (int co = 0; co < 4; ++co) {
       float d = v.x * wv[co].x;
       d = fmaf(v.y, wv[co].y, d); d = fmaf(v.z, wv[co].z, d); d = fmaf(v.w, wv[co].w, d);
-#pragma unroll
-      for (int sh_ = 1; sh_ < LPP; sh_ <<= 1) d += __shfl_xor(d, sh_);
+      d = vv_group_sum<LPP>(d);
       o[co] = d + bias[co];
     }
     if (sub == 0) {
@@ -968,8 +967,7 @@ outconv_fwdbwd_kernel(const vv_outconv_params p, float* __restrict__ dA, const i
     for (int co = 0; co < 4; ++co) {
       float d = v.x * wv[co].x;
       d = fmaf(v.y, wv[co].y, d); d = fmaf(v.z, wv[co].z, d); d = fmaf(v.w, wv[co].w, d);
-#pragma unroll
-      for (int sh_ = 1; sh_ < LPP; sh_ <<= 1) d += __shfl_xor(d, sh_);
+      d = vv_group_sum<LPP>(d);
       o[co] = d + bias[co];
     }
     const float tv[4] = {tq.x, tq.y, tq.z, tq.w};
