@@ -82,6 +82,9 @@ def conv_bytes(lay, B, G, y_bytes=4, dy_bytes=4, da_bytes=4):
     return by
 
 
+_STEP_BYTES = {}      # profile name -> whole-step HBM bytes of the same counter passes (train steps only), or None
+
+
 def pmc_traffic(name):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed.  This is a
@@ -89,6 +92,7 @@ def pmc_traffic(name):
     for n in (name, name.replace('r04_', 'r03_'), name.replace('r04_', 'r02_'), name.replace('r04_', 'r01_')):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
+            _STEP_BYTES[name] = d.get('hbm_bytes_per_train_step')
             return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], _profile_tag(n, d)
         except Exception:
             continue
@@ -377,12 +381,12 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     peak = FP32_MFMA_PEAK if precision == 'fp32' else BF16_MFMA_PEAK
     tag = 'fp32' if precision == 'fp32' else 'bf16'
     # the committed PMC passes: default workload (net4, B=256) and BASELINE config 4 (full, B=512, bf16)
+    pname = None
     if model == 'net4' and B == 256:
-        traffic = pmc_traffic('r04_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16'))
+        pname = 'r04_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')
     elif model == 'full' and B == 512 and precision == 'bf16':
-        traffic = pmc_traffic('r04_pmc_hbm_traffic_bf16_full_b512.json')
-    else:
-        traffic = (None, None)
+        pname = 'r04_pmc_hbm_traffic_bf16_full_b512.json'
+    traffic = pmc_traffic(pname) if pname else (None, None)
     rec = {'value': value, 'unit': 'cubes/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
            'dtype': 'f32' if precision == 'fp32' else 'bf16 operands, f32 accumulate',
            'config': {'workload': {'net4': 'UCSDped2-shaped 5raw+1of UNet bank (SelfCompleteNet4, nf=32, padding=False) train step: '
@@ -394,6 +398,10 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
                       'frac_of_%s_mfma_peak_whole_step_algorithmic' % tag: value / world * train_flop / peak,
                       'loss_raw': float(l_raw), 'loss_of': float(l_of) if l_of is not None else 0.0},
            'roofline': conv_roofline(bank, B, per, precision, overlap, traffic)}
+    if rec['roofline'] is not None and pname and _STEP_BYTES.get(pname):
+        # whole train step, same counter passes: HBM bytes per step and the rate that implies at this run's step time
+        rec['roofline']['step_traffic_bytes'] = _STEP_BYTES[pname]
+        rec['roofline']['step_hbm_gbytes_per_s'] = _STEP_BYTES[pname] / (dt / steps) / 1e9
     if rec['roofline'] is not None and graph:
         n_fam = sum(1 for label, _, _ in ev[:n_in] if label in fl)
         rec['roofline']['launches_timed_where'] = ('%d inside the timed region (its first %d step(s) run the eager loop), %d in %d further '
