@@ -111,6 +111,7 @@ struct OutStore {
   // Sum the accumulators over the group's threads and the FOUR waves of the role (wave index w), write the row of the tile, reset.
   // ex: LDS exchange [2][4][TN] floats + one arrival counter behind it.  No workgroup barrier (the other role is elsewhere): the
   // last of the four waves to arrive adds up.
+  template <int NW>
   __device__ __forceinline__ void flush(float* ex, const int w, const int lane, float* row, const int Cout) {
     auto ror = [](const float v, const auto N_) -> float {
       constexpr int ctrl = 0x120 + decltype(N_)::value;                // DPP row_ror:N
@@ -127,27 +128,57 @@ struct OutStore {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         ex[w * TN + lane * 8 + e] = s1[e];
-        ex[4 * TN + w * TN + lane * 8 + e] = s2[e];
+        ex[NW * TN + w * TN + lane * 8 + e] = s2[e];
       }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    unsigned* cnt = reinterpret_cast<unsigned*>(ex + 8 * TN);
+    unsigned* cnt = reinterpret_cast<unsigned*>(ex + 2 * NW * TN);
     unsigned arrived = 0;
     if (lane == 0) arrived = atomicAdd(cnt, 1u);                       // (LDS operations of a wave execute in order: the partials are there)
     arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if ((arrived & 3u) == 3u) {
+    if ((arrived % NW) == NW - 1) {
       for (int c = lane; c < TN; c += 64) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
+        for (int wv = 0; wv < NW; ++wv) {
           t1 += ex[wv * TN + c];
-          t2 += ex[4 * TN + wv * TN + c];
+          t2 += ex[NW * TN + wv * TN + c];
         }
         row[c] = t1;
         row[Cout + c] = t2;
       }
     }
+  }
+};
+
+// A workgroup's position in its strided unit list, unit u = (g * NT + pt) * NN + nn.  Stepping by the stride costs a few scalar
+// adds: decomposing u with run-time divisors cost the single-issue producer waves ~150 instructions per tile and cursor, as
+// much as a whole tile's loads on the 32x32 level.
+struct UnitCur {
+  int u, g, pt, nn;
+  __device__ __forceinline__ void init(const int u_, const int NN, const int NT) {
+    u = u_; nn = u_ % NN;
+    const int q = u_ / NN;
+    pt = q % NT; g = q / NT;
+  }
+};
+struct UnitStep {
+  int du, dg, dpt, dnn, NN, NT;
+  __device__ __forceinline__ void init(const int du_, const int NN_, const int NT_) {
+    du = du_; NN = NN_; NT = NT_; dnn = du_ % NN_;
+    const int q = du_ / NN_;
+    dpt = q % NT_; dg = q / NT_;
+  }
+  __device__ __forceinline__ void step(UnitCur& c) const {
+    c.u += du;
+    c.nn += dnn;
+    const int c1 = c.nn >= NN ? 1 : 0;
+    c.nn -= c1 ? NN : 0;
+    c.pt += dpt + c1;
+    const int c2 = c.pt >= NT ? 1 : 0;
+    c.pt -= c2 ? NT : 0;
+    c.g += dg + c2;
   }
 };
 
@@ -170,8 +201,10 @@ struct OutStore {
 //   CK   16 | 32 channels per chunk (32: two K steps per tap, four LDS planes; the 32x32 level, where a tile has 1 - 2 chunks)
 //   NB   LDS tile buffers (3 where they fit: the producers may run a chunk ahead of the barrier), RS register sets in flight
 //   BRES > 0: the launch's whole filter slice (9 * BRES / 16 fragments, TN = 32, Cin = BRES <= 64) stays in consumer registers
-template <int TH, int TW, int NI, int WM, int MR, int NR, int CK, int OUTB, int NB, int RS, int BRES>
-__global__ void __launch_bounds__(512, 2)
+//   PW   producer waves (4 | 8: the HBM-bound 32x32 level needs twice the loads in flight and twice the issue slots)
+//   OWN  the consumer waves store their own rows (resident filter, PW == 4); else the producers store every tile
+template <int TH, int TW, int NI, int WM, int MR, int NR, int CK, int OUTB, int NB, int RS, int BRES, int PW, bool OWN>
+__global__ void __launch_bounds__(256 + 64 * PW, PW == 8 ? 3 : 2)
 conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = GGeo<TH, TW, NI>;
   constexpr int HH = G_::HH, HW = G_::HW, HWP = G_::HWP, NPIX = G_::NPIX, PLANE = G_::PLANE;
@@ -179,12 +212,14 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   constexpr int BUF = 2 * KS * PLANE;                                  // slots of one buffer: planes [kk][half]
   constexpr int WN = 4 / WM, TN = WN * NR * 32;
   static_assert(WM * MR * 32 == 256 && TH * TW * NI == 256, "256-pixel tiles");
-  constexpr int NTH = 256;                                             // threads per role
+  constexpr int NTH = 64 * PW;                                         // producer threads
+  static_assert(!OWN || BRES > 0, "own-row stores come with the resident filter");
   constexpr int QI = 2 * KS;                                           // 16-byte items per pixel and chunk
   constexpr int NITEMS = NPIX * QI, NIT = (NITEMS + NTH - 1) / NTH;
   constexpr int ORS = TN + 8;                                          // bf16 per row of the output tile (16 B pad)
   constexpr int OUT4 = (256 * ORS * 2 + 15) / 16;
-  constexpr int EX4 = (2 * 4 * TN * 4 + 15) / 16 + 1;                 // partial sums of the four producer waves [2][4][TN] + arrival counter
+  constexpr int NWS = OWN ? 4 : PW;                                    // waves of the role that stores
+  constexpr int EX4 = (2 * NWS * TN * 4 + 15) / 16 + 1;               // partial sums of the storing waves [2][NWS][TN] + arrival counter
   constexpr int BI4 = 4 * TN * 4 / 16;                                 // bias of the tiles in flight [4][TN] (staged by the producers)
   __shared__ uint4 lds4[NB * BUF + OUTB * OUT4 + EX4 + BI4];
   uint4* const ldsO = lds4 + NB * BUF;
@@ -215,7 +250,10 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   float* const optr = p.out.ptr; const int64_t og = p.out.gstride; const int ocs = p.out.cstride, oco = p.out.coff;
   float* const pstats = p.stats;
   float* const pdbg = p.bn_partial;
-  const int tilesX = W / TW, tpi = tilesX * (H / TH);
+  constexpr int TPI = TW / TH;                                         // tiles per image: H == W == TW on every level (vv_conv_gemm16)
+  static_assert(TW % TH == 0 && (TPI & (TPI - 1)) == 0, "a tile is TH full rows of a TW x TW image");
+  UnitStep ustep;
+  ustep.init(wgx, NN, NT);
   const int Cout = p.Cout, CinP = p.CinP, KGT = CinP >> 4;
   const int nchunk = CinP / CK;
   const int F = ntile * nchunk;                                        // chunk iterations of this workgroup
@@ -250,7 +288,9 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
     bool act[RS];
     float rbias[RS];                                                   // bias of the tile whose FIRST chunk the set holds (thread t < TN)
     int bslot[RS];                                                     // its slot in the bias ring, or -1
-    int lu = u0, lc = 0, lf = 0, lt = 0;                               // load cursor: unit, chunk, flat chunk index, tile ordinal
+    UnitCur lu;                                                        // load cursor: unit, chunk, flat chunk index, tile ordinal
+    lu.init(u0, NN, NT);
+    int lc = 0, lf = 0, lt = 0;
     // per-tile state of the load cursor (recomputed when it enters a tile): pixel index and padding mask of every item, the
     // sources' descriptors.  Per chunk and item that leaves 3 VALU: offset = (pixel * 2 cs + 2 (co + c)) | (padding ? 1 << 31 : 0)
     // -- an offset past num_records makes the buffer load return zeros, no branch.
@@ -262,11 +302,10 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       constexpr int S_ = decltype(SET)::value;
       if (lf >= F) return;
       if (lc == 0) {
-        tnn = lu % NN;
-        const int pt = (lu / NN) % NT;
-        tg = lu / (NN * NT);
-        const int img0 = (pt / tpi) * NI, trem = pt % tpi;
-        const int oy0 = (trem / tilesX) * TH - 1, ox0 = (trem % tilesX) * TW - 1;
+        tnn = lu.nn;
+        tg = lu.g;
+        const int img0 = (lu.pt / TPI) * NI, trem = lu.pt % TPI;
+        const int oy0 = trem * TH - 1, ox0 = -1;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int hy = hyx[k] & 255, hx = (hyx[k] >> 8) & 255, im = hyx[k] >> 16;
@@ -309,7 +348,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
         if (t < TN) rbias[S_] = pbias[(int64_t)tg * biasg + tnn * TN + t];
       }
       ++lf;
-      if (++lc == nchunk) { lc = 0; lu += wgx; ++lt; }
+      if (++lc == nchunk) { lc = 0; ustep.step(lu); ++lt; }
     };
     int cf = 0;                                                        // flat index of the next chunk to commit
     auto commit = [&](const auto SET) {
@@ -342,20 +381,23 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
     constexpr int NOUT = OutStore<TH, TW, NI, TN, NTH, 256>::NOUT;
     constexpr int NPARTS = NOUT >= 4 ? 4 : NOUT, KPP = NOUT / NPARTS;  // a tile's items leave in NPARTS parts, spread over the iterations
     int pend = NPARTS;                                                 // next part of the tile being stored (NPARTS: none)
-    int su = u0, sreg = 0;                                             // unit / output region of the next tile to be stored
+    UnitCur su;                                                        // unit / output region of the next tile to be stored
+    su.init(u0, NN, NT);
+    int sreg = 0;
     int st_sbase = 0, st_nimg = 0, st_row = 0;
     bool st_flush = false;
     __amdgpu_buffer_rsrc_t rsO;
     auto begin_tile = [&]() {
-      const int nn = su % NN, pt = (su / NN) % NT, g = su / (NN * NT);
-      const int img0 = (pt / tpi) * NI, trem = pt % tpi;
-      const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+      const int nn = su.nn, pt = su.pt, g = su.g;
+      const int img0 = (pt / TPI) * NI, trem = pt % TPI;
+      const int ty0 = trem * TH, tx0 = 0;
       rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(optr + (int64_t)g * og) + (int64_t)oco * 2, 0, 0x7FFFFFFF, 0x00020000);
       st_sbase = (((img0 * H + ty0) * W + tx0) * ocs + nn * TN) * 2;
       st_nimg = PB - img0;
       st_row = ((g * NT + pt) * 2) * Cout + nn * TN;
-      const int un = su + wgx;                                         // the run of tiles ends when the next unit is another UNet / N tile
-      st_flush = un >= uend || un % NN != nn || un / (NN * NT) != g;
+      UnitCur un = su;                                                 // the run of tiles ends when the next unit is another UNet / N tile
+      ustep.step(un);
+      st_flush = un.u >= uend || un.nn != nn || un.g != g;
       pend = 0;
     };
     auto do_parts = [&](int n) {
@@ -370,15 +412,15 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       }
       if (pend == NPARTS && n >= 0) {                                  // tile done: its stats row, next tile / region
         if (pstats) {
-          if (st_flush) outs.flush(ldsX, wave - 4, lane, pstats + st_row, Cout);
+          if (st_flush) outs.template flush<PW>(ldsX, wave - 4, lane, pstats + st_row, Cout);
           else if (t < TN) { pstats[st_row + t] = 0.f; pstats[st_row + Cout + t] = 0.f; }
         }
-        su += wgx; sreg = (sreg + 1) % OUTB;
+        ustep.step(su); sreg = (sreg + 1) % OUTB;
         pend = NPARTS + 1;
       }
     };
     const int ppi = (NPARTS + (nchunk > 2 ? nchunk - 2 : 0)) / (nchunk > 1 ? nchunk - 1 : 1);      // parts per iteration: done one iteration early
-    if (t == 0) *reinterpret_cast<unsigned*>(ldsX + 8 * TN) = 0u;
+    if (t == 0 && !OWN) *reinterpret_cast<unsigned*>(ldsX + 2 * NWS * TN) = 0u;
 #pragma unroll
     for (int k = 0; k < RS; ++k) { bslot[k] = -1; rbias[k] = 0.f; act[k] = false; }
     // set (f + D) % RS (compile time: the loop is unrolled by RS) of iteration f holds chunk f + D.  Written out by hand: generic
@@ -398,7 +440,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
     {                                                                                                                   \
       PT0();                                                                                                            \
       /* a tile that ended with iteration f - 1 is stored first (its output region is free again before the consumers' next epilogue) */ \
-      if constexpr (BRES == 0) {                                                                                        \
+      if constexpr (!OWN) {                                                                                             \
         if (f > 0 && f % nchunk == 0) begin_tile();                                                                     \
         if (pend < NPARTS) do_parts(ppi);                                                                               \
       }                                                                                                                 \
@@ -422,7 +464,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       }
     }
 #undef VV_PROD_ITER
-    if constexpr (BRES == 0) {
+    if constexpr (!OWN) {
       if (pend < NPARTS) do_parts(NPARTS);                             // (cannot happen: a tile's parts end before the next tile does)
       begin_tile();                                                    // the last tile
       do_parts(NPARTS);
@@ -451,16 +493,21 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
   const int brow = 2 * Cout * 16;
   // filter panel of a unit: descriptor (SGPRs) + this lane's offset
-  auto panel = [&](const int u, __amdgpu_buffer_rsrc_t& rs, unsigned& bvo) {
-    const int uu = u < uend ? u : u0;                                  // past the end: any valid panel (loads are never consumed)
-    const int nn = uu % NN, g = uu / (NN * NT);
+  const int g00 = u0 / (NN * NT), nn00 = u0 % NN;
+  auto panel = [&](const UnitCur& c, __amdgpu_buffer_rsrc_t& rs, unsigned& bvo) {
+    const bool in = c.u < uend;                                        // past the end: any valid panel (loads are never consumed)
+    const int nn = in ? c.nn : nn00, g = in ? c.g : g00;
     rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw_ + (int64_t)g * wgs), 0, 0x7FFFFFFF, 0x00020000);
     bvo = (unsigned)(half * Cout + nn * TN + wn * (NR * 32) + l31) * 16u;
   };
   __amdgpu_buffer_rsrc_t rsW, rsN;
   unsigned bvo, bvoN;
-  panel(u0, rsW, bvo);
-  panel(u0 + wgx, rsN, bvoN);
+  UnitCur cu, cnx;                                                     // this tile's unit, the unit whose panel is fetched next
+  cu.init(u0, NN, NT);
+  cnx = cu;
+  panel(cnx, rsW, bvo);
+  ustep.step(cnx);
+  panel(cnx, rsN, bvoN);
 
   // accumulators: acc[m][n][i] = pixel (block m, column l31) x output channel n*32 + (i & 3) + 8 (i >> 2) + 4 half
   v16f acc[MR][NR];
@@ -560,15 +607,15 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   // memory queue is ever waited for, and it idles at the barrier most of the time (the launch is HBM-bound) -- it stores its own
   // rows and keeps their column sums; the producers only load.
   OutStore<TH, TW, NI, TN, 64, 64> couts;
-  if constexpr (BRES > 0) {
-    static_assert(BRES == 0 || (WM == 4 && MR == 2), "own-row stores: one wave = 64 pixels x the whole N tile");
+  if constexpr (OWN) {
+    static_assert(!OWN || (WM == 4 && MR == 2), "own-row stores: one wave = 64 pixels x the whole N tile");
     couts.init(lane, wm * 64, H, W, ocs);
-    if (tid == 0) *reinterpret_cast<unsigned*>(ldsX + 8 * TN) = 0u;
+    if (tid == 0) *reinterpret_cast<unsigned*>(ldsX + 2 * NWS * TN) = 0u;
   }
-  auto store_own = [&](const int u, const int reg) {
-    const int nn = u % NN, pt = (u / NN) % NT, g = u / (NN * NT);
-    const int img0 = (pt / tpi) * NI, trem = pt % tpi;
-    const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+  auto store_own = [&](const UnitCur& c, const int reg) {
+    const int nn = c.nn, pt = c.pt, g = c.g;
+    const int img0 = (pt / TPI) * NI, trem = pt % TPI;
+    const int ty0 = trem * TH, tx0 = 0;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(optr + (int64_t)g * og) + (int64_t)oco * 2, 0,
                                                                           0x7FFFFFFF, 0x00020000);
     const int sbase = (((img0 * H + ty0) * W + tx0) * ocs + nn * TN) * 2;
@@ -576,8 +623,9 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
                                                                     pstats != nullptr);
     if (pstats) {
       const int row = ((g * NT + pt) * 2) * Cout + nn * TN;
-      const int un = u + wgx;
-      if (un >= uend || un % NN != nn || un / (NN * NT) != g) couts.flush(ldsX, wave, lane, pstats + row, Cout);
+      UnitCur un = c;
+      ustep.step(un);
+      if (un.u >= uend || un.nn != nn || un.g != g) couts.template flush<4>(ldsX, wave, lane, pstats + row, Cout);
       else if (wave == 0 && lane < TN) { pstats[row + lane] = 0.f; pstats[row + Cout + lane] = 0.f; }
     }
   };
@@ -595,13 +643,13 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   const std::integral_constant<int, 0> k0{};
   int f = 0, reg = 0, tile = 0;
   int gcur = u0 / (NN * NT);
-  for (int u = u0; u < uend; u += wgx) {
+  for (; cu.u < uend; ustep.step(cu)) {
     if constexpr (BRES > 0) {
       // the whole Cin is a few compile-time chunks: chunk index static, filter in registers (re-read when the UNet changes)
-      const int g = u / (NN * NT);
+      const int g = cu.g;
       if (g != gcur) {
         gcur = g;
-        panel(u, rsW, bvo);
+        panel(cu, rsW, bvo);
         vv_static_for<0, NBR>([&](auto I) { constexpr int i = decltype(I)::value; fbr[i] = loadB(rsW, bvo, i % 9, i / 9, 0); });
       }
       constexpr int NCH = BRES / CK;
@@ -612,7 +660,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
         PT(tA);
         if constexpr (ci == NCH - 1) {
           epilogue(reg, tile);
-          store_own(u, reg);
+          if constexpr (OWN) store_own(cu, reg);
           PT(tB);
           reg = (reg + 1) % OUTB;
           ++tile;
@@ -648,7 +696,8 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       ++tile;
       ++f;
       rsW = rsN; bvo = bvoN;
-      panel(u + 2 * wgx, rsN, bvoN);
+      ustep.step(cnx);
+      panel(cnx, rsN, bvoN);
       __syncthreads();
       PT(tC);
     }
@@ -661,34 +710,41 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
 #endif
 }
 
-template <int TH, int TW, int NI, int WM, int MR, int NR, int CK, int OUTB, int NB, int RS, int BRES>
+template <int TH, int TW, int NI, int WM, int MR, int NR, int CK, int OUTB, int NB, int RS, int BRES, int PW = 4>
 int launch_p(const vv_conv_params* p, hipStream_t st, const int ncu) {
   constexpr int TN = (4 / WM) * NR * 32;
+  constexpr bool OWN = BRES > 0 && PW == 4;
   const int NT = ((p->B + NI - 1) / NI) * (p->H / TH) * (p->W / TW);
   const int NN = p->Cout / TN;
   const int total = p->G * NN * NT;
   const int nper = (total + 7) / 8;
   int grid = ncu < nper * 8 ? ncu : nper * 8;
   grid = (grid + 7) & ~7;
-  VV_LAUNCH((conv_gemm16p_kernel<TH, TW, NI, WM, MR, NR, CK, OUTB, NB, RS, BRES>), dim3(grid), dim3(512), 0, st, *p, NT, NN, total, nper);
+  VV_LAUNCH((conv_gemm16p_kernel<TH, TW, NI, WM, MR, NR, CK, OWN ? 1 : OUTB, NB, RS, BRES, PW, OWN>), dim3(grid), dim3(256 + 64 * PW), 0, st, *p, NT,
+            NN, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
 
 // NB3: three LDS tile buffers fit beside the output region(s) of every N-tile width at this level
-template <int TH, int TW, int NI, int CK, bool NB3, int RS>
+template <int TH, int TW, int NI, int CK, bool NB3, int RS, int PW = 4>
 int dispatch_p(const vv_conv_params* p, hipStream_t st) {
   int dev = 0, ncu = 0;                                                // one persistent workgroup per CU
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
     ncu = 256;
   constexpr int NB = NB3 ? 3 : 2;
-  if (p->Cout % 128 == 0 && p->CinP / CK >= 2) return launch_p<TH, TW, NI, 2, 4, 2, CK, 1, NB, RS, 0>(p, st, ncu);
-  if (p->Cout % 64 == 0) return launch_p<TH, TW, NI, 2, 4, 1, CK, 2, NB, RS, 0>(p, st, ncu);
+  // (eight producer waves = three waves per SIMD, 168 registers: the 128-wide tiles and the 64-channel resident filter do not fit)
+  if constexpr (PW == 4) {
+    if (p->Cout % 128 == 0 && p->CinP / CK >= 2) return launch_p<TH, TW, NI, 2, 4, 2, CK, 1, NB, RS, 0, PW>(p, st, ncu);
+  }
+  if (p->Cout % 64 == 0) return launch_p<TH, TW, NI, 2, 4, 1, CK, 2, NB, RS, 0, PW>(p, st, ncu);
   // 32-wide N tiles: the filter slice of a <= 64-channel layer stays in registers
-  if (p->CinP == 64 && 64 % CK == 0) return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 64>(p, st, ncu);
-  if (p->CinP == 32 && 32 % CK == 0) return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 32>(p, st, ncu);
-  if (p->CinP == 16 && CK == 16) return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 16>(p, st, ncu);
-  return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 0>(p, st, ncu);
+  if constexpr (PW == 4) {
+    if (p->CinP == 64 && 64 % CK == 0) return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 64, PW>(p, st, ncu);
+  }
+  if (p->CinP == 32 && 32 % CK == 0) return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 32, PW>(p, st, ncu);
+  if (p->CinP == 16 && CK == 16) return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 16, PW>(p, st, ncu);
+  return launch_p<TH, TW, NI, 4, 2, 1, CK, 2, NB, RS, 0, PW>(p, st, ncu);
 }
 
 }  // namespace
@@ -702,6 +758,9 @@ int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st) {
   if (p->in_mode != VV_IN_PLAIN && (!p->a || !p->b)) return VV_ERR_BAD_ARG;
   const bool ck32 = p->CinP % 32 == 0 && (p->in_mode != VV_IN_CAT || p->csplit % 32 == 0);
   switch (p->H) {      // (32x32: vv_conv_mfma keeps those launches on conv_mfma_kernel, see the header)
+#if (VV_EXPG & 4096)
+    case 32: return ck32 ? dispatch_p<8, 32, 1, 32, false, 2, 8>(p, st) : dispatch_p<8, 32, 1, 16, true, 2, 8>(p, st);
+#endif
     case 16: return ck32 ? dispatch_p<16, 16, 1, 32, false, 2>(p, st) : dispatch_p<16, 16, 1, 16, true, 2>(p, st);
     case 8: return ck32 ? dispatch_p<8, 8, 4, 32, false, 2>(p, st) : dispatch_p<8, 8, 4, 16, true, 2>(p, st);
     case 4: return dispatch_p<4, 4, 16, 16, false, 2>(p, st);
