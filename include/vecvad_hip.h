@@ -119,6 +119,14 @@ typedef struct vv_conv_params {
   const float* bn_z; int64_t bn_z_gstride;
   const float* bn_a; const float* bn_b; const float* bn_mean; const float* bn_invstd; int64_t bn_gstride;
   float* bn_partial;
+  /* vv_conv_mfma, bf16-output 3x3 launches (VV_CONV_BF16 | VV_CONV_OUT_BF16) only: optional second output view.  Output channels
+   * [osplit, Cout) go to out1 (as its channels [0, Cout - osplit)), channels [0, osplit) to out: the data gradient of a concat
+   * layer leaves as two dense tensors, one per consumer (skip half -> BatchNorm backward, upsampled half -> transposed-conv
+   * backward) -- with 32 bf16 channels per half an interleaved pixel row gives each consumer 64 useful bytes of every 128 fetched.
+   * osplit a multiple of 32; out1.cstride == out.cstride; out1.gstride == out.gstride.  out1.ptr == NULL: off. */
+  vv_view out1;
+  int32_t osplit;
+  int32_t pad1;
 } vv_conv_params;
 
 int vv_conv_mfma(const vv_conv_params* p, vv_stream stream);

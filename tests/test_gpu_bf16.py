@@ -548,3 +548,52 @@ def test_bf16_gemm_conv_all_bf16_tensors(H, Cin, Cout, B, mode):
         tot = res[0][1][gi].sum(0).double()                              # (c)
         torch.testing.assert_close(tot[0], new[gi].double().sum(0), rtol=1e-4, atol=1e-3 * scale * B)
         torch.testing.assert_close(tot[1], (new[gi].double() ** 2).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('H,Cin,Cout,B', [(32, 32, 64, 3), (16, 64, 128, 2), (16, 64, 64, 3), (8, 128, 256, 5), (8, 64, 128, 6),
+                                          (4, 256, 256, 19), (4, 64, 64, 33)])
+@pytest.mark.parametrize('legacy', [False, True])
+def test_bf16_conv_second_output_view(H, Cin, Cout, B, legacy):
+    """vv_conv_params.out1 / osplit (round 4): a concat layer's data gradient leaves as two dense tensors, channels [0, Cout/2) and
+    [Cout/2, Cout).  Both bf16-output kernels (the GEMM-shaped one: N tile inside a half or spanning both; the round-3 kernel, which
+    keeps the 32x32 level) must store exactly the values of the single-view launch, write nothing else, and leave the same per-tile
+    column sums (the transposed conv's bias gradient reads them over ALL channels)."""
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G, half = 2, Cout // 2
+    g = torch.Generator(device='cpu').manual_seed(H * 77 + Cin + Cout)
+    st = torch.cuda.current_stream().cuda_stream
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    x0s = _as_bf16_storage(_r(torch.randn(G, B * H * H, Cin, generator=g)).cuda())
+    pk = _pack(lib, L, w, G, 0, Cin, Cout, st)
+    flags = L.CONV_BF16 | L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16 | (L.CONV_NO_GEMM16 if legacy else 0)
+    nt = lib.vv_conv_ntiles2(B, H, H, L.CONV3, flags)
+    M = B * H * H
+
+    def run(split):
+        y = torch.full((G, M * Cout // 2 + 8,), 3.0, device='cuda')
+        s_ = torch.full((G, nt, 2, Cout), -7.0, device='cuda')
+        cp = L.ConvParams(L.CONV3, L.IN_PLAIN, G, B, H, H, Cin, Cin, Cout, L.View(x0s.data_ptr(), x0s.stride(0), Cin, 0), None, None, Cin,
+                          L.NULL_VIEW, Cin, flags, None, pk.data_ptr(), pk.stride(0), None, 0, L.View(y.data_ptr(), y.stride(0), Cout, 0),
+                          s_.data_ptr())
+        if split:
+            cp.out = L.View(y.data_ptr(), y.stride(0), half, 0)
+            cp.out1 = L.View(y.data_ptr() + M * half * 2, y.stride(0), half, 0)
+            cp.osplit = half
+        L.check(lib.vv_conv_mfma(C.byref(cp), st), 'conv')
+        torch.cuda.synchronize()
+        assert float(y[0, -1]) == 3.0 and float(y[1, -1]) == 3.0
+        return y.view(torch.bfloat16)[:, :M * Cout], s_
+
+    one, s_one = run(False)
+    two, s_two = run(True)
+    one = one.view(G, M, Cout)
+    assert torch.equal(two[:, :M * half].view(G, M, half), one[:, :, :half])
+    assert torch.equal(two[:, M * half:].view(G, M, half), one[:, :, half:])
+    assert torch.equal(s_one, s_two)
+    # the fp32 / non-bf16-output paths refuse the second view instead of ignoring it
+    y = torch.zeros(G, M * Cout + 8, device='cuda')
+    cp = L.ConvParams(L.CONV3, L.IN_PLAIN, G, B, H, H, Cin, Cin, Cout, L.View(x0s.data_ptr(), x0s.stride(0), Cin, 0), None, None, Cin,
+                      L.NULL_VIEW, Cin, L.CONV_BF16, None, pk.data_ptr(), pk.stride(0), None, 0, L.View(y.data_ptr(), y.stride(0), half, 0), None)
+    cp.out1, cp.osplit = L.View(y.data_ptr() + M * half * 4, y.stride(0), half, 0), half
+    assert lib.vv_conv_mfma(C.byref(cp), st) != 0

@@ -765,3 +765,30 @@ def test_fused_outconv_forward_backward_bitwise_equal_to_two_launches(monkeypatc
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
     assert float(res[0][1].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,nf,B', [('net4', 32, 5), ('full', 32, 3)])
+def test_bf16_concat_gradient_in_two_planes_bitwise_equal(monkeypatch, kind, nf, B):
+    """vv_conv_params.out1 in the train step (round 4): with all-bf16 tensors the data gradient of the three concat layers leaves as
+    two dense planes (skip half -> BatchNorm backward of the encoder layer, upsampled half -> transposed-conv backward).  A pure
+    layout change: every parameter gradient of the bank keeps its bits."""
+    monkeypatch.setenv('VV_PRECISION', 'bf16')
+    from oracle import unet_oracle as O
+    res = []
+    for split in ('1', '0'):
+        monkeypatch.setenv('VV_SPLIT_DCAT', split)
+        net, sd, tot_of = _build(kind, False, nf=nf)
+        net.train()
+        bank = net.bank()
+        assert bank.split_dcat == (split == '1')
+        raw, flow = O.seeded_cubes(B, tot_of, 5)
+        ws = bank.set_input_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), torch.arange(B, device='cuda'))
+        bank.forward(ws, True, outputs=False)
+        bank.backward(ws, fused=True)
+        torch.cuda.synchronize()
+        res.append((ws.score.clone(), bank.grads.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert float(res[0][1].abs().max()) > 0
+

@@ -45,7 +45,8 @@ class ConvParams(C.Structure):
                 ('w', c_vp), ('w_gstride', c_i64), ('bias', c_vp), ('bias_gstride', c_i64),
                 ('out', View), ('stats', c_vp),
                 ('bn_z', c_vp), ('bn_z_gstride', c_i64), ('bn_a', c_vp), ('bn_b', c_vp), ('bn_mean', c_vp), ('bn_invstd', c_vp),
-                ('bn_gstride', c_i64), ('bn_partial', c_vp)]
+                ('bn_gstride', c_i64), ('bn_partial', c_vp),
+                ('out1', View), ('osplit', c_i32), ('pad1', c_i32)]
 
 
 class WgradParams(C.Structure):

@@ -249,6 +249,8 @@ class UNetBank:
         # ... and so are the conv / transposed-conv OUTPUTS (pre-BatchNorm tensors; torch.autocast's output dtype, oracle 'y16') and
         # with them the pooled / frame-erased inputs: every tensor a bf16 kernel stages is then bf16 (VV_CONV_ALLSRC_BF16)
         self.y16 = self.dz16 and self.da16 and os.environ.get('VV_BF16_Y', '1') != '0'
+        # concat layers' data gradient as two dense planes (backward_plan.dcat_views): bf16-output launches of vv_conv_mfma only
+        self.split_dcat = self.da16 and os.environ.get('VV_SPLIT_DCAT', '1') != '0'        # (da16 => bf16 kernels => no Winograd path)
         self.fflag = self.cflag | ((L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16) if self.y16 else 0)      # forward launches
         # fused train / scoring steps (no reconstruction store): the 1x1 output conv's forward and backward in ONE pass over y
         # (vv_outconv_fwdbwd); the module API (forward -> outputs -> set_dout -> backward) keeps the two launches
@@ -649,6 +651,18 @@ class UNetBank:
         # buffers
         self._alloc_outconv_bwd(ws, B)
         ws.D = {l.idx: f(Ga, B * l.H * l.H, l.cin) for l in lay.convs if l.idx > 0}
+
+        def dcat_views(m):
+            """Data gradient of concat layer m as its two consumers read it: (skip half, upsampled half, split channel or 0).
+            All-bf16 tensors: two dense planes [pixels][half] inside ws.D[m] (vv_conv_params.out1) -- an interleaved pixel row of
+            2 x 32 bf16 channels hands each consumer 64 useful bytes of every 128-byte line (measured on the 32x32 level: BatchNorm
+            backward of the skip layer 264 / 190 us against 172 / 113 us for the same tensor sizes read densely)."""
+            dcat = ws.D[m.idx]
+            skipc = lay.convs[m.skip].cout
+            if self.split_dcat and 2 * skipc == m.cin and skipc & (skipc - 1) == 0:
+                plane = B * m.H * m.H * skipc * 2                      # bytes
+                return (L.view(dcat, skipc, 0, dcat.stride(0)), L.view(dcat.data_ptr() + plane, skipc, 0, dcat.stride(0)), skipc)
+            return (L.view(dcat, m.cin, 0, dcat.stride(0)), L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc), 0)
         ws.DT = [f(Ga, B * H * H, ci) for (_, H, ci, co) in lay.convT]
         ws.dz2 = [f(Ga, B * HWp * nf), f(Ga, B * HWp * nf)]   # dy of consecutive layers alternate (weight-grad runs on a side stream)
         ws.dz = ws.dz2[0]
@@ -742,9 +756,8 @@ class UNetBank:
                 return L.view(t, t.shape[2], 0, t.stride(0)), None, 0
             if skip_of:
                 m = skip_of[0]
-                dcat = ws.D[m.idx]
                 dp = ws.D[pool_of[0].idx] if pool_of else None
-                return (L.view(dcat, m.cin, 0, dcat.stride(0)), dp.data_ptr() if dp is not None else None,
+                return (dcat_views(m)[0], dp.data_ptr() if dp is not None else None,
                         dp.stride(0) if dp is not None else 0)
             m = nxt
             dn = ws.D[m.idx]
@@ -810,6 +823,10 @@ class UNetBank:
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
                                   ws.dstats.data_ptr() if l.mode == L.IN_CAT else None)
+                if l.mode == L.IN_CAT:
+                    v0, v1, osplit = dcat_views(l)
+                    if osplit:
+                        cp.out, cp.out1, cp.osplit = v0, v1, osplit
                 j = fused_producer(l)
                 if j is not None:                  # the first pass of layer j's BatchNorm backward rides on this launch's epilogue
                     yj = ws.y[j]
@@ -846,9 +863,8 @@ class UNetBank:
         def convT_bwd(u, m):
             """m: the CAT conv layer that consumed convT u; its data gradient holds d(convT out) in channels [skipC, cin)."""
             sidx, H, ci, co = lay.convT[u]
-            dcat = ws.D[m.idx]
             skipc = lay.convs[m.skip].cout
-            dy = L.View(dcat.data_ptr(), dcat.stride(0), m.cin, skipc)
+            dy = dcat_views(m)[1]
             DT = ws.DT[u]
             cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0,
                               self.cflag | (((L.CONV_ALLSRC_BF16 if self.y16 else L.CONV_SRC_BF16) | L.CONV_OUT_BF16) if self.da16 else 0), None,

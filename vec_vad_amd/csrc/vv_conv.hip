@@ -284,19 +284,23 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         }
       __syncthreads();
       constexpr int QN = TN / 8, NOUT = 128 * MR * QN / VV_WG;
-      static_assert((128 * MR * QN) % VV_WG == 0, "output items per thread");
+      static_assert((128 * MR * QN) % VV_WG == 0 && VV_WG % QN == 0, "output items per thread, one channel group per thread");
+      // second output view (vv_conv_params.out1): this thread's 8 channels belong to one of the two tensors
+      __bf16* obase = outh + co0 + (tid % QN) * 8;
+      if (p.out1.ptr && co0 + (tid % QN) * 8 >= p.osplit)
+        obase = reinterpret_cast<__bf16*>(p.out1.ptr + (int64_t)g * p.out1.gstride) + p.out1.coff + (co0 + (tid % QN) * 8 - p.osplit);
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) {
         const int it = tid + k * VV_WG;
-        const int q = it % QN, pp = it / QN;
+        const int pp = it / QN;
         const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
         const int img = img0 + im;
 #if (VV_EXPC & 8)
         if (acc[0][0][0] == 123.456f)
 #endif
         if (img < p.B) {
-          const uint4 v = *reinterpret_cast<const uint4*>(lo + pp * ORS + q * 8);
-          *reinterpret_cast<uint4*>(outh + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs + co0 + q * 8) = v;
+          const uint4 v = *reinterpret_cast<const uint4*>(lo + pp * ORS + (tid % QN) * 8);
+          *reinterpret_cast<uint4*>(obase + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs) = v;
         }
       }
     }
@@ -463,6 +467,12 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   if ((p->pad0 & VV_CONV_OUT_BF16) && !bf) return VV_ERR_BAD_ARG;
   if ((p->pad0 & VV_CONV_ALLSRC_BF16) && (!bf || p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
+  if (p->out1.ptr) {                                                    // second output view: bf16-output 3x3 launches only
+    if (!(bf && (p->pad0 & VV_CONV_OUT_BF16) && p->kind == VV_CONV3)) return VV_ERR_UNSUPPORTED;
+    if (p->osplit <= 0 || p->osplit >= p->Cout || p->osplit % 32 || p->out1.cstride != p->out.cstride ||
+        p->out1.gstride != p->out.gstride || p->out1.coff % 8)
+      return VV_ERR_BAD_ARG;
+  }
   const int sm = !bf ? 0 : ((p->pad0 & VV_CONV_ALLSRC_BF16) ? 2 : ((p->pad0 & VV_CONV_SRC_BF16) ? 1 : 0));
   // all-bf16 3x3 launches: the persistent GEMM-shaped kernel on the 16x16 / 8x8 / 4x4 levels; at 32x32 (HBM-bound, 1 - 2 chunks per
   // tile) it measured slower than this file's kernel, which has the same 256-pixel tiles there (vv_conv_ntiles2 is unaffected)

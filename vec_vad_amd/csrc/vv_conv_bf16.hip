@@ -76,13 +76,16 @@ struct OutStore {
   int lbase;               // byte offset of item 0 inside an output region
   float s1[8], s2[8];
 
-  __device__ __forceinline__ void init(const int tl, const int px0, const int H, const int W, const int ocs) {
+  // xoff(first channel of the thread's items inside the N tile) -> extra byte offset of the thread's items (second output view)
+  template <class XOff>
+  __device__ __forceinline__ void init(const int tl, const int px0, const int H, const int W, const int ocs, const XOff xoff) {
     const int qq = tl % QN;
+    const int xo = xoff(qq * 8);
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
       const int pp = px0 + (tl + k * NTHR) / QN;
       const int im = pp / (TH * TW), rr = (pp / TW) % TH, cc = pp % TW;
-      soff[k] = (((im * H + rr) * W + cc) * ocs + qq * 8) * 2;
+      soff[k] = (((im * H + rr) * W + cc) * ocs + qq * 8) * 2 + xo;
       sim[k] = im;
     }
     lbase = ((px0 + tl / QN) * ORS + qq * 8) * 2;
@@ -248,6 +251,13 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   const float* const pw_ = p.w; const int64_t wgs = p.w_gstride;
   const float* const pbias = p.bias; const int64_t biasg = p.bias_gstride;
   float* const optr = p.out.ptr; const int64_t og = p.out.gstride; const int ocs = p.out.cstride, oco = p.out.coff;
+  // second output view (channels >= osplit; same pixel and group strides, host-checked).  An N tile lies inside one half
+  // (osplit % TN == 0: the tile's base moves, o1d = byte distance of the views) or is the whole layer (TN == 2 osplit: the
+  // threads of the upper half carry the distance in their item offsets)
+  const int osplit = p.out1.ptr ? p.osplit : 0x40000000;
+  const int o1d = p.out1.ptr ? (int)((reinterpret_cast<const char*>(p.out1.ptr) - reinterpret_cast<const char*>(p.out.ptr)) + ((int64_t)p.out1.coff - oco) * 2) : 0;
+  auto xoff = [&](const int ch) -> int { return (TN > osplit && ch >= osplit) ? o1d - osplit * 2 : 0; };
+  auto tile_xoff = [&](const int nn) -> int { return (TN <= osplit && nn * TN >= osplit) ? o1d - osplit * 2 : 0; };
   float* const pstats = p.stats;
   float* const pdbg = p.bn_partial;
   constexpr int TPI = TW / TH;                                         // tiles per image: H == W == TW on every level (vv_conv_gemm16)
@@ -377,7 +387,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
     };
     // ---- finished tiles leave through the output regions (skipped when the consumers store their own rows: BRES > 0)
     OutStore<TH, TW, NI, TN, NTH, 256> outs;
-    outs.init(t, 0, H, W, ocs);
+    outs.init(t, 0, H, W, ocs, xoff);
     constexpr int NOUT = OutStore<TH, TW, NI, TN, NTH, 256>::NOUT;
     constexpr int NPARTS = NOUT >= 4 ? 4 : NOUT, KPP = NOUT / NPARTS;  // a tile's items leave in NPARTS parts, spread over the iterations
     int pend = NPARTS;                                                 // next part of the tile being stored (NPARTS: none)
@@ -392,7 +402,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       const int img0 = (pt / TPI) * NI, trem = pt % TPI;
       const int ty0 = trem * TH, tx0 = 0;
       rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(optr + (int64_t)g * og) + (int64_t)oco * 2, 0, 0x7FFFFFFF, 0x00020000);
-      st_sbase = (((img0 * H + ty0) * W + tx0) * ocs + nn * TN) * 2;
+      st_sbase = (((img0 * H + ty0) * W + tx0) * ocs + nn * TN) * 2 + tile_xoff(nn);
       st_nimg = PB - img0;
       st_row = ((g * NT + pt) * 2) * Cout + nn * TN;
       UnitCur un = su;                                                 // the run of tiles ends when the next unit is another UNet / N tile
@@ -609,7 +619,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   OutStore<TH, TW, NI, TN, 64, 64> couts;
   if constexpr (OWN) {
     static_assert(!OWN || (WM == 4 && MR == 2), "own-row stores: one wave = 64 pixels x the whole N tile");
-    couts.init(lane, wm * 64, H, W, ocs);
+    couts.init(lane, wm * 64, H, W, ocs, xoff);
     if (tid == 0) *reinterpret_cast<unsigned*>(ldsX + 2 * NWS * TN) = 0u;
   }
   auto store_own = [&](const UnitCur& c, const int reg) {
@@ -618,7 +628,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
     const int ty0 = trem * TH, tx0 = 0;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(optr + (int64_t)g * og) + (int64_t)oco * 2, 0,
                                                                           0x7FFFFFFF, 0x00020000);
-    const int sbase = (((img0 * H + ty0) * W + tx0) * ocs + nn * TN) * 2;
+    const int sbase = (((img0 * H + ty0) * W + tx0) * ocs + nn * TN) * 2 + tile_xoff(nn);
     couts.template store<0, OutStore<TH, TW, NI, TN, 64, 64>::NOUT>(reinterpret_cast<const char*>(ldsO + reg * OUT4), rsO, sbase, PB - img0,
                                                                     pstats != nullptr);
     if (pstats) {
@@ -756,6 +766,12 @@ int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st) {
   if (p->src0.cstride % 8 || p->src0.coff % 8 || p->out.cstride % 8 || p->out.coff % 8) return VV_ERR_BAD_ARG;
   if (p->in_mode == VV_IN_CAT && (p->csplit % 16 || p->src1.cstride % 8 || p->src1.coff % 8 || !p->src1.ptr)) return VV_ERR_BAD_ARG;
   if (p->in_mode != VV_IN_PLAIN && (!p->a || !p->b)) return VV_ERR_BAD_ARG;
+  if (p->out1.ptr) {      // second output view (validated by vv_conv_mfma): one buffer descriptor per UNet covers both tensors
+    const int64_t d = (reinterpret_cast<const char*>(p->out1.ptr) - reinterpret_cast<const char*>(p->out.ptr)) +
+                      ((int64_t)p->out1.coff - p->out.coff) * 2;
+    const int64_t span = (int64_t)p->B * p->H * p->W * p->out.cstride * 2;
+    if (d < 0 || d + span >= 0x7FFFFFFFll || p->Cout != 2 * p->osplit || (p->osplit & (p->osplit - 1))) return VV_ERR_UNSUPPORTED;
+  }
   const bool ck32 = p->CinP % 32 == 0 && (p->in_mode != VV_IN_CAT || p->csplit % 32 == 0);
   switch (p->H) {      // (32x32: vv_conv_mfma keeps those launches on conv_mfma_kernel, see the header)
 #if (VV_EXPG & 4096)

@@ -432,6 +432,7 @@ extern "C" int vv_conv_wino(const vv_conv_params* p, vv_stream stream) {
   if (!p || !p->src0.ptr || !p->w || !p->out.ptr) return VV_ERR_BAD_ARG;
   if (p->G <= 0 || p->B <= 0 || p->kind != VV_CONV3 || p->H != p->W) return VV_ERR_BAD_ARG;
   if (p->Cout % 32 || p->CinP % 8) return VV_ERR_UNSUPPORTED;
+  if (p->out1.ptr) return VV_ERR_UNSUPPORTED;                          // second output view: bf16-output launches of vv_conv_mfma
   if (p->bn_partial && (p->stats || !p->bn_z || !p->bn_a || !p->bn_b || !p->bn_mean || !p->bn_invstd)) return VV_ERR_BAD_ARG;
   {
     // the epilogue addresses one UNet's output (and z) with 32-bit byte offsets
