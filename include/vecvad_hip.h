@@ -115,7 +115,9 @@ typedef struct vv_conv_params {
    * (vv_bn_bwd_reduce) done in the epilogue.  out = dA of the producing layer's activation relu(a z + b); with z that layer's
    * conv output [G][B*H*W][Cout] (pixel stride Cout) the kernel also leaves  sum dz, sum dz * xhat  per pixel tile, dz = dA [a z + b > 0],
    * xhat = (z - mean) invstd, in bn_partial [G][ntiles][2][Cout] -- the layout vv_bn_bwd_apply reads with VV_BNBWD_PARTIALS_PER_TILE.
-   * a / b / mean / invstd: [G][Cout] each, group stride bn_gstride.  bn_partial == NULL: off. */
+   * a / b / mean / invstd: [G][Cout] each, group stride bn_gstride.  bn_partial == NULL: off.
+   * vv_conv_mfma takes the same fields for all-bf16 3x3 launches with Cout % 64 != 0 on the 32x32 level (z then holds bf16
+   * elements; rows per vv_conv_ntiles(B,H,W), read with VV_BNBWD_PARTIALS_PER_CTILE); other launches with bn_partial set are refused. */
   const float* bn_z; int64_t bn_z_gstride;
   const float* bn_a; const float* bn_b; const float* bn_mean; const float* bn_invstd; int64_t bn_gstride;
   float* bn_partial;
@@ -240,6 +242,7 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
 #define VV_BNBWD_DA_BF16 4             /* dA (and dpool) hold bf16 elements (VV_CONV_OUT_BF16 / vv_outconv_bwd dA_bf16) */
 #define VV_BNBWD_PARTIALS_PER_TILE 16  /* vv_bn_bwd_apply: `partial` holds [G][vv_wino_ntiles(B,H)][2][C] written by the data-gradient
                                           launch that produced dA (vv_conv_params.bn_partial): no vv_bn_bwd_reduce pass for that layer */
+#define VV_BNBWD_PARTIALS_PER_CTILE 32 /* the same for a data-gradient launch of vv_conv_mfma (all-bf16 tensors): [G][vv_conv_ntiles(B,H,W)][2][C] */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
   int32_t flags;

@@ -325,6 +325,51 @@ def test_bn_backward_sums_fused_into_data_gradient(monkeypatch):
     assert 0.0 < worst <= 1e-5, worst          # > 0: the two paths really are different code
 
 
+
+@pytest.mark.parametrize('kind', ['net4', 'full'])
+def test_bn_backward_sums_fused_into_bf16_data_gradient(monkeypatch, kind):
+    """Round 4: the same fusion for the all-bf16 bank on the 32x32 level (vv_conv_mfma's 32-wide data-gradient launches leave
+    sum dz, sum dz * xhat per 256-pixel tile: VV_BNBWD_PARTIALS_PER_CTILE) -- layers 0 and 12 lose their vv_bn_bwd_reduce pass.
+    The sums are over the stored (bf16) gradient in both paths, in another order: layer 12's own gradients (the first consumer of
+    fused sums in the backward order) move by fp32 round-off (measured 1.4e-6 of the tensor's norm, bar 1e-5).  From there on a
+    different c1 / c2 flips the bf16 rounding of a few stored dy elements, and every further layer of the backward chain rounds
+    its dy and data gradient to bf16 again: the difference grows to a few 1e-3 of a tensor's norm at layer 0 (measured 7.5e-3 at
+    worst) -- the step-to-step noise floor of bf16 gradients, the same effect as the 2e-3 script bar of test_gpu_scripts.py.
+    Bar 2e-2 for those; the training-level bf16 bars (losses over steps against the mixed oracle, test_gpu_bf16.py) are unaffected."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    monkeypatch.setenv('VV_PRECISION', 'bf16')
+    _, _, tot_of = _build(kind, False)
+    raw, flow = O.seeded_cubes(21, tot_of, 11)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    grads, nred = [], []
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('VV_FUSE_BN_SUMS', fuse)
+        net, _, _ = _build(kind, False)
+        net.train()
+        tr = FusedTrainer(net)
+        tr.step_cubes(rawd, flowd, torch.arange(21, device='cuda'))
+        torch.cuda.synchronize()
+        grads.append(tr.bank.grads_gu())
+        ws = tr.bank.workspace(21)
+        nred.append(sum(1 for c in tr.bank.backward_plan(ws, fused=tr.bank.fuse_outconv).calls if c[2].startswith('bn_bwd_reduce')))
+    assert nred[0] - nred[1] == 2, nred
+    lay = tr.bank.lay
+    worst = first = 0.0
+    for key, (off, shape) in lay.p.items():
+        n = int(torch.tensor(shape).prod())
+        a, b = grads[0][:, off:off + n].double(), grads[1][:, off:off + n].double()
+        d = ((a - b).norm() / a.norm().clamp_min(1e-30)).item()
+        if key.startswith('c13.') or key.startswith('o.'):
+            assert d == 0.0, (key, d)              # upstream of the first fused launch
+        elif key.startswith('c12.'):
+            first = max(first, d)
+        else:
+            worst = max(worst, d)
+    assert 0.0 < first <= 1e-5, first
+    assert worst <= 2e-2, worst
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_two_stream_schedules_have_every_dependency(monkeypatch, precision):
     """The two-stream schedules again, with one stream stalled before each of its launches (FusedTrainer.debug_delay): the other

@@ -29,6 +29,7 @@ CONV_RELU = 32          # VV_CONV_RELU: eval mode, BatchNorm folded into the fil
 CONV_NO_GEMM16 = 64     # VV_CONV_NO_GEMM16: keep an all-bf16 3x3 launch on the round-3 kernel (A/B switch)
 BNBWD_Y_BF16 = 8
 BNBWD_PARTIALS_PER_TILE = 16   # partial sums left by the data-gradient launch (ConvParams.bn_partial)
+BNBWD_PARTIALS_PER_CTILE = 32  # ... of vv_conv_mfma (all-bf16 tensors): rows per vv_conv_ntiles
 WGRAD_X_BF16 = 2
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 

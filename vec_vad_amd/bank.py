@@ -768,8 +768,17 @@ class UNetBank:
         def fused_producer(l):
             """Index of the layer whose BatchNorm-backward sums the data-gradient launch of conv layer l can leave behind
             (vv_conv_params.bn_partial): l reads relu(bn(y_j)) of the layer right before it and nobody else consumes that activation
-            (no pooling / skip / transposed-conv consumer), so dA_j is exactly this launch's output.  fp32 Winograd path only."""
-            if not (self.wino and not self.cflag and self.fuse_bn_sums) or l.mode != L.IN_ACT or l.idx == 0:
+            (no pooling / skip / transposed-conv consumer), so dA_j is exactly this launch's output.  fp32 Winograd path (every
+            level), and all-bf16 tensors on the 32x32 level (vv_conv_mfma's kernel with 32-wide N tiles: HBM-latency-bound launches
+            that absorb the extra read of z; on the deeper levels the stores belong to the single-issue producer waves of
+            vv_conv_bf16.hip, where the sums would cost more than the separate pass)."""
+            if not self.fuse_bn_sums or l.mode != L.IN_ACT or l.idx == 0:
+                return None
+            if self.wino and not self.cflag:
+                pass
+            elif self.y16 and self.da16 and self.dz16 and len(wplan['c%d' % l.idx]) > 2 and l.H == 32 and l.cin % 64 != 0:
+                pass                           # (that launch carries VV_CONV_ALLSRC_BF16 | VV_CONV_OUT_BF16: dgrad_flags)
+            else:
                 return None
             j = l.src
             if j != l.idx - 1 or j == last.idx:
@@ -803,7 +812,7 @@ class UNetBank:
             from_dgrad = i in fused                # ... by the data-gradient launch of layer i + 1
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
                                (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0) |
-                               (L.BNBWD_PARTIALS_PER_TILE if from_dgrad else 0) |
+                               ((L.BNBWD_PARTIALS_PER_TILE if self.wino else L.BNBWD_PARTIALS_PER_CTILE) if from_dgrad else 0) |
                                (L.BNBWD_DA_BF16 if self.da16 else 0) | (L.BNBWD_Y_BF16 if self.y16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())

@@ -43,6 +43,12 @@ inline bool vv_gemm16_flags(int kind, int flags) {
          !(flags & VV_CONV_NO_GEMM16);
 }
 
+// DPP row_ror:N -- the value of the lane N places further round this lane's row of 16
+template <int N>
+__device__ __forceinline__ float vv_dpp_ror(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+
 // XCD-aware work-item remap: the dispatcher places block b on XCD b%8 (observed, MI355X_MICROARCH.md);
 // give every XCD one contiguous chunk of the work list so that workgroups sharing a UNet's weight panel
 // share an L2.  nper = ceil(total/8); grid = 8*nper; caller drops w >= total.

@@ -114,6 +114,27 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
+  // vv_conv_params.bn_partial (all-bf16 data-gradient launches, 32-wide N tiles): the first pass of the BatchNorm backward that
+  // consumes this output rides on the epilogue's store loop.  The thread's z items (the pixels and 8 channels it will store) are
+  // requested HERE, ahead of the whole K loop: asked for in the epilogue they put an HBM round trip into every workgroup's
+  // critical path (measured: the 32 -> 32 launch at 32x32 204 -> 292 us).
+  constexpr bool BNF = BF && NR == 1 && KIND == VV_CONV3 && S16 == 2;
+  constexpr int BN_QN = NR * 4, BN_NOUT = 128 * MR * BN_QN / VV_WG;
+  const bool bnf = BNF && p.bn_partial != nullptr;
+  uint4 zq[BNF ? BN_NOUT : 1];
+  if constexpr (BNF) {
+    if (bnf) {
+      const unsigned short* zh = reinterpret_cast<const unsigned short*>(p.bn_z + (int64_t)g * p.bn_z_gstride) + co0 + (tid % BN_QN) * 8;
+#pragma unroll
+      for (int k = 0; k < BN_NOUT; ++k) {
+        const int pp = (tid + k * VV_WG) / BN_QN;
+        const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+        zq[k] = img0 + im < p.B ? *reinterpret_cast<const uint4*>(zh + ((int64_t)((img0 + im) * H + ty0 + r) * W + tx0 + c) * Cout)
+                                : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+
   // ---- software pipeline over the K chunks: activation tile (BatchNorm+ReLU deferred to commit) and weight panel of
   // chunk c+1 are in flight in registers while chunk c runs on the matrix cores; nothing but LDS is read in the MFMA loop.
   VVStagerB<NI, HH, HW, S, (S16 == 2 ? CK / 2 : CK)> stA;      // all-bf16 sources: 16-byte items of 8 channels
@@ -263,6 +284,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       // bf16 outputs: 2-byte stores straight from the accumulator layout (lane = channel) are 128 B per instruction and cost a
       // third of the kernel (elimination run, profiles/README.md).  The tile goes through LDS instead and leaves as 16-byte
       // items (8 channels) per lane: 8x fewer store instructions, whole 64-byte runs per pixel.
+      constexpr int QN = TN / 8, NOUT = 128 * MR * QN / VV_WG;
+      static_assert((128 * MR * QN) % VV_WG == 0 && VV_WG % QN == 0, "output items per thread, one channel group per thread");
+      static_assert(!BNF || (QN == BN_QN && NOUT == BN_NOUT), "z items = output items");
       __syncthreads();                    // every wave is done with the staging buffers
       unsigned short* lo = reinterpret_cast<unsigned short*>(lds4);
 #pragma unroll
@@ -283,12 +307,18 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
           }
         }
       __syncthreads();
-      constexpr int QN = TN / 8, NOUT = 128 * MR * QN / VV_WG;
-      static_assert((128 * MR * QN) % VV_WG == 0 && VV_WG % QN == 0, "output items per thread, one channel group per thread");
       // second output view (vv_conv_params.out1): this thread's 8 channels belong to one of the two tensors
       __bf16* obase = outh + co0 + (tid % QN) * 8;
       if (p.out1.ptr && co0 + (tid % QN) * 8 >= p.osplit)
         obase = reinterpret_cast<__bf16*>(p.out1.ptr + (int64_t)g * p.out1.gstride) + p.out1.coff + (co0 + (tid % QN) * 8 - p.osplit);
+      float bna[8], bnb[8], bnm[8], bni[8], bs1[8], bs2[8];
+      if constexpr (BNF) {
+        if (bnf) {
+          const int64_t o = (int64_t)g * p.bn_gstride + co0 + (tid % QN) * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { bna[j] = p.bn_a[o + j]; bnb[j] = p.bn_b[o + j]; bnm[j] = p.bn_mean[o + j]; bni[j] = p.bn_invstd[o + j]; bs1[j] = 0.f; bs2[j] = 0.f; }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) {
         const int it = tid + k * VV_WG;
@@ -301,6 +331,51 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         if (img < p.B) {
           const uint4 v = *reinterpret_cast<const uint4*>(lo + pp * ORS + (tid % QN) * 8);
           *reinterpret_cast<uint4*>(obase + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs) = v;
+          if constexpr (BNF) {
+            if (bnf) {
+              // bn_bwd16_kernel's pass 0 on the STORED (rounded) gradient: dz = dA [a z + b > 0]; sum dz, sum dz * z here (two
+              // packed-fp32 instructions per channel pair besides the compare / select), xhat's shift and scale once per thread:
+              // sum dz * xhat = invstd * (sum dz * z - mean * sum dz)
+              const unsigned dw[4] = {v.x, v.y, v.z, v.w}, zw[4] = {zq[k].x, zq[k].y, zq[k].z, zq[k].w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                typedef float v2f_ __attribute__((ext_vector_type(2)));
+                const v2f_ z2 = {__builtin_bit_cast(float, zw[j] << 16), __builtin_bit_cast(float, zw[j] & 0xFFFF0000u)};
+                const v2f_ d2 = {__builtin_bit_cast(float, dw[j] << 16), __builtin_bit_cast(float, dw[j] & 0xFFFF0000u)};
+                const v2f_ a2 = {bna[2 * j], bna[2 * j + 1]}, b2 = {bnb[2 * j], bnb[2 * j + 1]};
+                const v2f_ on = __builtin_elementwise_fma(a2, z2, b2);
+                const v2f_ dj = {on.x > 0.f ? d2.x : 0.f, on.y > 0.f ? d2.y : 0.f};
+                v2f_ t1 = {bs1[2 * j], bs1[2 * j + 1]}, t2 = {bs2[2 * j], bs2[2 * j + 1]};
+                t1 += dj;
+                t2 = __builtin_elementwise_fma(dj, z2, t2);
+                bs1[2 * j] = t1.x; bs1[2 * j + 1] = t1.y; bs2[2 * j] = t2.x; bs2[2 * j + 1] = t2.y;
+              }
+            }
+          }
+        }
+      }
+      if constexpr (BNF) {
+        if (bnf) {
+          // the 64 threads with this channel group: 16 lanes of each wave (lane % QN), then the four waves through LDS
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            static_assert(!BNF || QN == 4, "lanes with the same lane % 4");
+            bs2[j] = bni[j] * (bs2[j] - bnm[j] * bs1[j]);
+            bs1[j] += vv_dpp_ror<4>(bs1[j]); bs2[j] += vv_dpp_ror<4>(bs2[j]);      // rows of 16 lanes: rotate by 4, by 8
+            bs1[j] += vv_dpp_ror<8>(bs1[j]); bs2[j] += vv_dpp_ror<8>(bs2[j]);
+            bs1[j] += __shfl_xor(bs1[j], 16); bs2[j] += __shfl_xor(bs2[j], 16);
+            bs1[j] += __shfl_xor(bs1[j], 32); bs2[j] += __shfl_xor(bs2[j], 32);
+          }
+          __syncthreads();                // the output tile has left LDS
+          if (lane < QN) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lds[wave * 2 * TN + lane * 8 + j] = bs1[j]; lds[wave * 2 * TN + TN + lane * 8 + j] = bs2[j]; }
+          }
+          __syncthreads();
+          if (tid < 2 * TN) {
+            const float t = (lds[tid] + lds[2 * TN + tid]) + (lds[4 * TN + tid] + lds[6 * TN + tid]);
+            p.bn_partial[((int64_t)(g * NT + pt) * 2) * Cout + (tid / TN) * Cout + co0 + tid % TN] = t;
+          }
         }
       }
     }
@@ -467,6 +542,13 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   if ((p->pad0 & VV_CONV_OUT_BF16) && !bf) return VV_ERR_BAD_ARG;
   if ((p->pad0 & VV_CONV_ALLSRC_BF16) && (!bf || p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
+  if (p->bn_partial) {
+    // BatchNorm-backward partial sums in the epilogue: all-bf16 3x3 launches of the kernel in this file with 32-wide N tiles (the
+    // bank's 32 -> 32 channel data gradients on the 32x32 level; vv_conv_wino has its own form for the fp32 path)
+    if (!(bf && (p->pad0 & VV_CONV_OUT_BF16) && (p->pad0 & VV_CONV_ALLSRC_BF16) && p->kind == VV_CONV3)) return VV_ERR_UNSUPPORTED;
+    if ((vv_gemm16_flags(p->kind, p->pad0) && p->H <= 16) || p->Cout % 64 == 0 || p->stats || p->out1.ptr) return VV_ERR_UNSUPPORTED;
+    if (!p->bn_z || !p->bn_a || !p->bn_b || !p->bn_mean || !p->bn_invstd) return VV_ERR_BAD_ARG;
+  }
   if (p->out1.ptr) {                                                    // second output view: bf16-output 3x3 launches only
     if (!(bf && (p->pad0 & VV_CONV_OUT_BF16) && p->kind == VV_CONV3)) return VV_ERR_UNSUPPORTED;
     if (p->osplit <= 0 || p->osplit >= p->Cout || p->osplit % 32 || p->out1.cstride != p->out.cstride ||
