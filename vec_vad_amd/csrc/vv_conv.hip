@@ -43,7 +43,7 @@ struct Geo {
 // S16 (with BF, plain input): src0 holds bf16 elements -- a dy that BatchNorm backward stored as bf16; copied, not converted.
 // MR: 32-pixel row blocks per wave (2 = 256-pixel tiles; 1 = 128-pixel tiles, four workgroups per CU: the bf16 kernels on the 8x8 / 4x4
 // levels, where a launch has few, long workgroups and is bound by the chunk round trips)
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, int S16, int MR>      // S16: 0 fp32 sources, 1 plain bf16 src0, 2 ALL sources bf16
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, int S16, int MR>      // S16: 0 fp32 sources, 1 plain bf16 src0, 2 ALL sources bf16, 3 = 2 + bn_partial
 __global__ void __launch_bounds__(VV_WG, (MR == 1 && BF) ? 4 : ((BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2)))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
@@ -118,7 +118,9 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   // consumes this output rides on the epilogue's store loop.  The thread's z items (the pixels and 8 channels it will store) are
   // requested HERE, ahead of the whole K loop: asked for in the epilogue they put an HBM round trip into every workgroup's
   // critical path (measured: the 32 -> 32 launch at 32x32 204 -> 292 us).
-  constexpr bool BNF = BF && NR == 1 && KIND == VV_CONV3 && S16 == 2;
+  constexpr bool BNF = BF && NR == 1 && KIND == VV_CONV3 && S16 == 3;      // its own instantiation: as a run-time option it cost
+                                                                            // every 32-wide launch of the 32x32 level 20 % (registers, code in the epilogue)
+  static_assert(S16 != 3 || BNF, "S16 == 3: the 32-wide 3x3 launch with BatchNorm-backward sums");
   constexpr int BN_QN = NR * 4, BN_NOUT = 128 * MR * BN_QN / VV_WG;
   const bool bnf = BNF && p.bn_partial != nullptr;
   uint4 zq[BNF ? BN_NOUT : 1];
@@ -137,7 +139,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 
   // ---- software pipeline over the K chunks: activation tile (BatchNorm+ReLU deferred to commit) and weight panel of
   // chunk c+1 are in flight in registers while chunk c runs on the matrix cores; nothing but LDS is read in the MFMA loop.
-  VVStagerB<NI, HH, HW, S, (S16 == 2 ? CK / 2 : CK)> stA;      // all-bf16 sources: 16-byte items of 8 channels
+  VVStagerB<NI, HH, HW, S, (S16 >= 2 ? CK / 2 : CK)> stA;      // all-bf16 sources: 16-byte items of 8 channels
   stA.init(s, ox0, tid);            // every tile spans full rows (TW == W): the column origin is tile independent
   unsigned boff[NBT];
   float4 rb[NBT];
@@ -154,7 +156,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   auto issue = [&](const int c0) {
-    if constexpr (S16 == 2) stA.prefetch16w(s, img0, oy0, ox0, c0, tid);
+    if constexpr (S16 >= 2) stA.prefetch16w(s, img0, oy0, ox0, c0, tid);
     else if constexpr (S16 == 1) stA.prefetch16(s, img0, oy0, ox0, c0, tid);
     else stA.prefetch(s, img0, oy0, ox0, c0, tid);
     const int so = (BF ? (c0 >> 4) : (c0 >> 3)) * 2 * Cout * 16;
@@ -165,7 +167,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
   };
   auto commit = [&]() {
-    if constexpr (S16 == 2) stA.commit16w(lds, tid);
+    if constexpr (S16 >= 2) stA.commit16w(lds, tid);
     else if constexpr (S16 == 1) stA.commit_raw16(lds, tid);
     else if constexpr (BF) stA.commit_bf16(lds, tid);
     else stA.commit(lds, tid);
@@ -546,7 +548,7 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
     // BatchNorm-backward partial sums in the epilogue: all-bf16 3x3 launches of the kernel in this file with 32-wide N tiles (the
     // bank's 32 -> 32 channel data gradients on the 32x32 level; vv_conv_wino has its own form for the fp32 path)
     if (!(bf && (p->pad0 & VV_CONV_OUT_BF16) && (p->pad0 & VV_CONV_ALLSRC_BF16) && p->kind == VV_CONV3)) return VV_ERR_UNSUPPORTED;
-    if ((vv_gemm16_flags(p->kind, p->pad0) && p->H <= 16) || p->Cout % 64 == 0 || p->stats || p->out1.ptr) return VV_ERR_UNSUPPORTED;
+    if (p->H != 32 || p->W != 32 || p->Cout % 64 == 0 || p->stats || p->out1.ptr) return VV_ERR_UNSUPPORTED;
     if (!p->bn_z || !p->bn_a || !p->bn_b || !p->bn_mean || !p->bn_invstd) return VV_ERR_BAD_ARG;
   }
   if (p->out1.ptr) {                                                    // second output view: bf16-output 3x3 launches only
@@ -567,6 +569,7 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
       // (32-channel chunks for the bf16 kernels: measured -25 % with fp32 input on the 32x32 layers (spills), +-0 end to end with
       // bf16 input -- not kept)
+      if (sm == 2 && p->bn_partial) return launch<8, 32, 1, 1, VV_CONV3, 16, true, 3>(p, st);      // (validated above: 32x32 level, Cout % 64 != 0)
       if (sm == 2) return dispatch<VV_CONV3, 16, true, 2>(p, st);
       if (sm == 1) return dispatch<VV_CONV3, 16, true, 1>(p, st);
       return bf ? dispatch<VV_CONV3, 16, true>(p, st) : dispatch<VV_CONV3, 16, false>(p, st);
