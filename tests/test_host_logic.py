@@ -11,6 +11,18 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_struct_mirrors_match_the_compiled_structs():
+    """vv_abi_sizeof: every ctypes mirror in _lib.py has the size of the struct the library was compiled with (vv_conv_params grew
+    at its end in round 4), an unknown index answers -1, and lib() itself refuses a library whose structs differ."""
+    import ctypes as C
+    from vec_vad_amd import _lib
+    l = _lib.lib()
+    for which, cls in enumerate(_lib.ABI_STRUCTS):
+        assert l.vv_abi_sizeof(which) == C.sizeof(cls), cls.__name__
+    assert l.vv_abi_sizeof(len(_lib.ABI_STRUCTS)) == -1 and l.vv_abi_sizeof(-1) == -1
+    assert C.sizeof(_lib.ConvParams) % 8 == 0 and _lib.ConvParams.out1.offset > _lib.ConvParams.bn_partial.offset
+
+
 def test_library_exports_every_declared_symbol():
     from vec_vad_amd import _lib
     hdr = open(os.path.join(ROOT, 'include', 'vecvad_hip.h')).read()

@@ -156,11 +156,14 @@ _SIGS = {
                                 c_vp]),
     'vv_roc_auc_counts': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     'vv_version': (C.c_char_p, []),
+    'vv_abi_sizeof': (c_i32, [c_i32]),
     'vv_status_string': (C.c_char_p, [c_i32]),
     'vv_device_arch_ok': (c_i32, []),
 }
 
 EXPORTS = sorted(_SIGS)
+# order = the `which` argument of vv_abi_sizeof
+ABI_STRUCTS = (View, ConvParams, WgradParams, PackEntry, ReduceEntry, FoldEntry, BnBwdParams, OutconvParams, Conv2dParams)
 _lib = None
 
 
@@ -180,6 +183,12 @@ def lib():
             f = getattr(l, name)      # AttributeError if the symbol is not exported
             f.restype = res
             f.argtypes = args
+        # the ctypes mirrors against the structs the library was compiled with (include/vecvad_hip.h vv_abi_sizeof): a stale .so or a
+        # mirror that missed a field would otherwise read garbage behind the shorter struct
+        for which, cls in enumerate(ABI_STRUCTS):
+            if l.vv_abi_sizeof(which) != C.sizeof(cls):
+                raise VecVadHipError('%s: sizeof(%s) is %d in the library, %d in vec_vad_amd/_lib.py -- rebuild with '
+                                     '`python -m vec_vad_amd.build`' % (LIB_PATH, cls.__name__, l.vv_abi_sizeof(which), C.sizeof(cls)))
         _lib = l
     return _lib
 

@@ -1363,6 +1363,21 @@ extern "C" int vv_fold_bn(const vv_fold_entry* table_dev, int32_t nentries, int3
 
 extern "C" const char* vv_version(void) { return "vecvad_hip 0.1 (gfx950)"; }
 
+extern "C" int vv_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int)sizeof(vv_view);
+    case 1: return (int)sizeof(vv_conv_params);
+    case 2: return (int)sizeof(vv_wgrad_params);
+    case 3: return (int)sizeof(vv_pack_entry);
+    case 4: return (int)sizeof(vv_reduce_entry);
+    case 5: return (int)sizeof(vv_fold_entry);
+    case 6: return (int)sizeof(vv_bnbwd_params);
+    case 7: return (int)sizeof(vv_outconv_params);
+    case 8: return (int)sizeof(vv_conv2d_params);
+  }
+  return -1;
+}
+
 extern "C" const char* vv_status_string(int status) {
   switch (status & 0xff) {
     case VV_OK: return "VV_OK";
