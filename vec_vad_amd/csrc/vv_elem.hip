@@ -1054,6 +1054,257 @@ outconv_fwdbwd_kernel(const vv_outconv_params p, float* __restrict__ dA, const i
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ output conv, 8 channels per lane
+// The three launches of the 1x1 output conv (forward: MODE 0, backward from a stored d(out): MODE 1, both in one pass: MODE 2) as ONE
+// kernel body with CC / 8 lanes per pixel (4 at features_root 32) instead of CC / 4: the first form spent 900 wave-instructions per
+// 32 pixels, 72 of them the packed multiply-adds that do the work -- the rest an 8-lane butterfly per output channel (48 DPP moves +
+// 48 hazard nops + adds), the error terms recomputed on all eight lanes, address arithmetic and ~50 branches on run-time flags.
+// Here a lane holds 8 channels (one 16-byte load of a bf16 y), the butterfly is the two quad permutes, the element types of y / dA
+// are template parameters.  The three modes share every per-pixel expression and every reduction order, so the fused launch leaves
+// the bits of the two separate ones (tests/test_gpu_unet.py::test_fused_outconv_forward_backward_bitwise_equal_to_two_launches).
+//   per pixel:  v = relu(a y + b);  out[co] = sum_c v[c] W[co][c] + bias[co]  (8 sequential fmas per lane, then the butterfly);
+//               e = out - target, sse += e^2 (lane 0 of the pixel), d = gscale e;
+//               dA[c] = sum_co d[co] W[co][c];  dW[co][c] += d[co] v[c];  db[co] += d[co];
+//               BatchNorm-backward sums of the layer in front: g = dA [v > 0] (of the STORED dA), sum g, sum g * xhat.
+//   per cube:   lanes' sums over their pixels -> LDS -> one thread per output adds the NPG pixel lanes in order.
+template <int LPP>
+__device__ __forceinline__ float vv_group_sum48(float d) {
+  static_assert(LPP == 4 || LPP == 8, "4 or 8 lanes per pixel");
+  d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+  d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+  if constexpr (LPP == 8) d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, false));   // row_half_mirror
+  return d;
+}
+
+template <int CC, int MODE, bool Y16, bool DA16>
+__global__ void __launch_bounds__(VV_WG)
+outconv8_kernel(const vv_outconv_params p, const float* __restrict__ dout4_in, float* __restrict__ dA, const int64_t dA_gstride,
+                float* __restrict__ partial, const float* __restrict__ mean, const float* __restrict__ invstd,
+                float* __restrict__ bnpart, const int total, const int nper) {
+  constexpr int C = CC, LPP = CC / 8, NPG = VV_WG / LPP, NOUT = 4 * CC + 4, UN = 4;
+  constexpr bool FWD = MODE != 1, BWD = MODE != 0;
+  __shared__ float sh[BWD ? NPG : 1][BWD ? LPP * 32 + 4 : 1];
+  __shared__ float red[4];
+  int g, cube;
+  if constexpr (MODE == 1) { g = blockIdx.y; cube = blockIdx.x; }
+  else {
+    // work item = (cube, UNet), the G UNets of a cube adjacent in one XCD's chunk of the list: they read the same target pixels
+    const int wi = vv_xcd_remap(blockIdx.x, nper);
+    if (wi >= total) return;
+    g = wi % p.G; cube = wi / p.G;
+  }
+  const int tid = threadIdx.x, sub = tid % LPP, pg = tid / LPP;
+  const int c = sub * 8;
+  const int oc = FWD ? p.oc[g] : 4;
+  const int64_t abo = (int64_t)g * p.ab_gstride + c;
+  float a[8], b[8], wv[4][8], bias[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = p.a[abo + j]; b[j] = p.b[abo + j]; }
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    // (forward modes: rows >= oc are zero; the backward-only launch does not know oc and reads the rows as they are -- they belong
+    //  to the next parameter, and d is 0 there: the same sums)
+    const bool on = co < oc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[co][j] = on ? p.w[(int64_t)g * p.param_gstride + co * C + c + j] : 0.f;
+    bias[co] = (FWD && on) ? p.bias[(int64_t)g * p.param_gstride + co] : 0.f;
+  }
+  int tcs = 0;
+  const float* tgt = nullptr;
+  float gs = 0.f;
+  if constexpr (FWD) {
+    const int tsrc = p.tgt_src[g];
+    tgt = (tsrc == 0 ? p.tgt0 : p.tgt1) + p.tgt_coff[g];
+    tcs = tsrc == 0 ? p.tgt0_cstride : p.tgt1_cstride;
+    gs = p.gscale ? p.gscale[g] : 0.f;
+  }
+  const int64_t MB = (int64_t)p.B * p.HW;
+  const int64_t pix0 = (int64_t)cube * p.HW;
+  const float* __restrict__ yf = p.y + (int64_t)g * p.y_gstride;
+  const unsigned short* __restrict__ yh = reinterpret_cast<const unsigned short*>(yf);
+  float* __restrict__ dAf = BWD ? dA + (int64_t)g * dA_gstride : nullptr;
+  unsigned short* __restrict__ dAh = reinterpret_cast<unsigned short*>(dAf);
+  float sse = 0.f;
+  float dw[BWD ? 4 : 1][8], db[4] = {0.f, 0.f, 0.f, 0.f}, m[8], iv[8], s1[8], s2[8];
+  const bool bnp = BWD && bnpart != nullptr;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    m[j] = bnp ? mean[abo + j] : 0.f; iv[j] = bnp ? invstd[abo + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f;
+    if constexpr (BWD) { dw[0][j] = 0.f; dw[1][j] = 0.f; dw[2][j] = 0.f; dw[3][j] = 0.f; }
+  }
+  struct Y8 { uint4 lo, hi; };              // 8 channels of y: bf16 in lo | fp32 in lo, hi
+  auto ldy = [&](const int i) -> Y8 {
+    Y8 r;
+    if constexpr (Y16) { r.lo = *reinterpret_cast<const uint4*>(yh + (pix0 + i) * C + c); r.hi = r.lo; }
+    else {
+      r.lo = *reinterpret_cast<const uint4*>(yf + (pix0 + i) * C + c);
+      r.hi = *reinterpret_cast<const uint4*>(yf + (pix0 + i) * C + c + 4);
+    }
+    return r;
+  };
+  auto y8 = [&](const Y8& r) -> vv_f8 {
+    if constexpr (Y16) return vv_unpack_bf16x8(r.lo);
+    else {
+      vv_f8 f;
+      f.v[0] = __builtin_bit_cast(float, r.lo.x); f.v[1] = __builtin_bit_cast(float, r.lo.y); f.v[2] = __builtin_bit_cast(float, r.lo.z);
+      f.v[3] = __builtin_bit_cast(float, r.lo.w); f.v[4] = __builtin_bit_cast(float, r.hi.x); f.v[5] = __builtin_bit_cast(float, r.hi.y);
+      f.v[6] = __builtin_bit_cast(float, r.hi.z); f.v[7] = __builtin_bit_cast(float, r.hi.w);
+      return f;
+    }
+  };
+  // the target pixel (forward modes; every lane of the pixel reads it: the backward half needs d in all of them) or the stored d(out).
+  // Channels >= oc: the load is clamped to the last real channel and the value dropped -- no branch, nothing read past the pixel
+  const int k1 = oc > 1 ? 1 : oc - 1, k2 = oc > 2 ? 2 : oc - 1, k3 = oc > 3 ? 3 : oc - 1;
+  auto ldt = [&](const int i) -> float4 {
+    if constexpr (FWD) {
+      const float* q = tgt + (pix0 + i) * tcs;
+      return make_float4(q[0], q[k1], q[k2], q[k3]);
+    } else {
+      return *reinterpret_cast<const float4*>(dout4_in + ((int64_t)g * MB + pix0 + i) * 4);
+    }
+  };
+  auto body = [&](const int i, const Y8& yr, const float4 tq) {
+    const int64_t pix = pix0 + i;
+    const vv_f8 yv = y8(yr);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float z = fmaf(a[j], yv.v[j], b[j]); v[j] = z > 0.f ? z : 0.f; }
+    float dd[4];
+    if constexpr (FWD) {
+      float o[4];
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        float d = v[0] * wv[co][0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) d = fmaf(v[j], wv[co][j], d);
+        o[co] = d;
+      }
+      // the four butterflies step by step (independent chains back to back: no DPP hazard stalls)
+#pragma unroll
+      for (int co = 0; co < 4; ++co) o[co] = vv_group_sum48<LPP>(o[co]) + bias[co];
+      const float tv[4] = {tq.x, oc > 1 ? tq.y : 0.f, oc > 2 ? tq.z : 0.f, oc > 3 ? tq.w : 0.f};
+      float e[4];
+#pragma unroll
+      for (int co = 0; co < 4; ++co) { e[co] = o[co] - tv[co]; dd[co] = gs * e[co]; }      // rows >= oc: 0 - 0
+      if (sub == 0) {
+#pragma unroll
+        for (int co = 0; co < 4; ++co) sse = fmaf(e[co], e[co], sse);
+        if (p.out4) *reinterpret_cast<float4*>(p.out4 + ((int64_t)g * MB + pix) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (p.dout4) *reinterpret_cast<float4*>(p.dout4 + ((int64_t)g * MB + pix) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+      }
+    } else {
+      dd[0] = tq.x; dd[1] = tq.y; dd[2] = tq.z; dd[3] = tq.w;
+    }
+    if constexpr (BWD) {
+      float q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = 0.f;
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q[j] = fmaf(dd[co], wv[co][j], q[j]); dw[co][j] = fmaf(dd[co], v[j], dw[co][j]); }
+        db[co] += dd[co];
+      }
+      if constexpr (DA16) {                 // stored as bf16 (mixed precision): the sums below are those of the stored values
+        vv_f8 qf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf.v[j] = q[j];
+        const uint4 h = vv_pack_bf16x8(qf);
+        *reinterpret_cast<uint4*>(dAh + pix * C + c) = h;
+        qf = vv_unpack_bf16x8(h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = qf.v[j];
+      } else {
+        *reinterpret_cast<float4*>(dAf + pix * C + c) = make_float4(q[0], q[1], q[2], q[3]);
+        *reinterpret_cast<float4*>(dAf + pix * C + c + 4) = make_float4(q[4], q[5], q[6], q[7]);
+      }
+      if (bnp) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gq = v[j] > 0.f ? q[j] : 0.f;
+          s1[j] += gq;
+          s2[j] = fmaf(gq, (yv.v[j] - m[j]) * iv[j], s2[j]);
+        }
+      }
+    }
+  };
+  // UN pixel groups per trip, their loads issued before the first use (one load in flight per lane = a chain of HBM round trips)
+  for (int i0 = pg; i0 < p.HW; i0 += UN * NPG) {
+    Y8 yq[UN];
+    float4 tq[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (i0 + u * NPG < p.HW) { yq[u] = ldy(i0 + u * NPG); tq[u] = ldt(i0 + u * NPG); }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (i0 + u * NPG < p.HW) body(i0 + u * NPG, yq[u], tq[u]);
+  }
+  if constexpr (FWD) {
+    // per-cube squared error (only the sub == 0 lanes hold data): wave reduce, then the four waves
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sse += __shfl_xor(sse, off);
+    if ((tid & 63) == 0) red[tid >> 6] = sse;
+  }
+  if constexpr (BWD) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sh[pg][sub * 32 + co * 8 + j] = dw[co][j];
+    if (sub == 0) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co) sh[pg][LPP * 32 + co] = db[co];
+    }
+  }
+  __syncthreads();
+  if constexpr (FWD) {
+    if (tid == 0) p.score[(int64_t)g * p.B + cube] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+  if constexpr (BWD) {
+    // [co][cc] weight-gradient sums, then the 4 bias-gradient sums of this cube; fixed order over the pixel lanes
+    float* out = partial + ((int64_t)g * p.B + cube) * NOUT;
+    for (int e = tid; e < NOUT; e += VV_WG) {
+      float s = 0.f;
+      if (e < 4 * CC) {
+        const int co = e / CC, cc = e % CC;
+        for (int k = 0; k < NPG; ++k) s += sh[k][(cc >> 3) * 32 + co * 8 + (cc & 7)];
+      } else {
+        for (int k = 0; k < NPG; ++k) s += sh[k][LPP * 32 + (e - 4 * CC)];
+      }
+      out[e] = s;
+    }
+    if (!bnp) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[pg][sub * 16 + j] = s1[j]; sh[pg][sub * 16 + 8 + j] = s2[j]; }
+    __syncthreads();
+    if (tid < 2 * C) {                     // threads [0, C): sum g, [C, 2C): sum g * xhat
+      const int which = tid / CC, cc = tid % CC;
+      float s = 0.f;
+      for (int k = 0; k < NPG; ++k) s += sh[k][(cc >> 3) * 16 + which * 8 + (cc & 7)];
+      bnpart[((int64_t)(g * p.B + cube) * 2 + which) * C + cc] = s;
+    }
+  }
+}
+
+template <int MODE>
+static int launch_outconv8(const vv_outconv_params& p, const float* dout4_in, float* dA, int64_t dA_gstride, float* partial,
+                           const float* mean, const float* invstd, float* bnpart, bool y16, bool da16, hipStream_t st) {
+  const int total = p.B * p.G, nper = (total + 7) / 8;
+  const dim3 grid = MODE == 1 ? dim3(p.B, p.G) : dim3(nper * 8);
+#define VV_OC8(CC_, Y_, D_)                                                                                                        \
+  VV_LAUNCH((outconv8_kernel<CC_, MODE, Y_, D_>), grid, dim3(VV_WG), 0, st, p, dout4_in, dA, dA_gstride, partial, mean, invstd, bnpart, \
+            total, nper)
+  if (!y16) return VV_ERR_UNSUPPORTED;      // (fp32 y: the callers keep the 4-channels-per-lane kernels, see vv_outconv_fwd)
+  if (p.C == 32) {
+    if (da16) VV_OC8(32, true, true); else VV_OC8(32, true, false);
+  } else if (p.C == 64) {
+    if (da16) VV_OC8(64, true, true); else VV_OC8(64, true, false);
+  } else return VV_ERR_UNSUPPORTED;      /* features_root 32 (every shipped config) or 64 (SelfCompleteNet1raw1of's default) */
+#undef VV_OC8
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
 extern "C" int vv_pack_weights(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params,
                                int64_t params_gstride, float* packed, int64_t packed_gstride, int32_t max_elems,
                                vv_stream stream) {
@@ -1165,6 +1416,11 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
 extern "C" int vv_outconv_fwd(const vv_outconv_params* p, vv_stream stream) {
   if (!p || !p->y || !p->a || !p->b || !p->w || !p->bias || !p->oc || !p->tgt_src || !p->tgt_coff || !p->score || !p->tgt0)
     return VV_ERR_BAD_ARG;
+  // bf16 y: the 8-channels-per-lane kernel (the 4-per-lane form is instruction-bound there: 315 -> 192 us for the fused launch of
+  // BASELINE config 4).  fp32 y: the 4-per-lane kernels stay -- 100 registers less per lane, five waves per SIMD instead of two, and
+  // with 32 bytes of y per lane the launch is bound by loads in flight, not by instructions (77 us against 93 - 104 us).  All three
+  // launches of a precision use the same family, so fused and separate launches keep identical bits.
+  if (p->pad0 & 1) return launch_outconv8<0>(*p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, true, false, (hipStream_t)stream);
   const int total = p->B * p->G, nper = (total + 7) / 8;
   if (p->C == 32) VV_LAUNCH(outconv_fwd_kernel<32>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, total, nper);
   else if (p->C == 64) VV_LAUNCH(outconv_fwd_kernel<64>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, total, nper);
@@ -1180,6 +1436,7 @@ extern "C" int vv_outconv_fwdbwd(const vv_outconv_params* p, float* dA, int64_t 
     return VV_ERR_BAD_ARG;
   if (bnpart && (!mean || !invstd)) return VV_ERR_BAD_ARG;
   if (((flags & 2) != 0) != ((p->pad0 & 1) != 0)) return VV_ERR_BAD_ARG;      // one y tensor: both halves must agree on its element type
+  if (flags & 2) return launch_outconv8<2>(*p, nullptr, dA, dA_gstride, partial, mean, invstd, bnpart, true, (flags & 1) != 0, (hipStream_t)stream);
   const int total = p->B * p->G, nper = (total + 7) / 8;
   if (p->C == 32) VV_LAUNCH(outconv_fwdbwd_kernel<32>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, dA, dA_gstride, partial, mean, invstd, bnpart, flags, total, nper);
   else if (p->C == 64) VV_LAUNCH(outconv_fwdbwd_kernel<64>, dim3(nper * 8), dim3(VV_WG), 0, (hipStream_t)stream, *p, dA, dA_gstride, partial, mean, invstd, bnpart, flags, total, nper);
@@ -1196,6 +1453,13 @@ extern "C" int vv_outconv_bwd(int32_t G, int32_t B, int32_t HW, int32_t C, const
                               const float* mean, const float* invstd, float* bnpart, int32_t dA_bf16, vv_stream stream) {
   if (!dout4 || !y || !a || !b || !w || !dA || !partial) return VV_ERR_BAD_ARG;
   if (bnpart && (!mean || !invstd)) return VV_ERR_BAD_ARG;
+  if (dA_bf16 & 2) {
+    vv_outconv_params p = {};
+    p.G = G; p.B = B; p.HW = HW; p.C = C;
+    p.y = y; p.y_gstride = y_gstride; p.a = a; p.b = b; p.ab_gstride = ab_gstride;
+    p.w = w; p.param_gstride = param_gstride;
+    return launch_outconv8<1>(p, dout4, dA, dA_gstride, partial, mean, invstd, bnpart, true, (dA_bf16 & 1) != 0, (hipStream_t)stream);
+  }
   if (C == 32)
     VV_LAUNCH(outconv_bwd_kernel<32>, dim3(B, G), dim3(VV_WG), 0, (hipStream_t)stream, B, HW, C, dout4, y, y_gstride,
               a, b, ab_gstride, w, param_gstride, dA, dA_gstride, partial, mean, invstd, bnpart, dA_bf16);
