@@ -49,11 +49,14 @@ def main():
     # optional 4th argument: number of forward passes the profiled command ran (FlowNet2: every pass is the same work) -> whole-run
     # HBM bytes per pass.  A UNet bench process is NOT uniform (train steps + forward-only passes + one-off set-up), so for it the
     # per-step total is derived from the once-per-step kernels: train steps = launches of adam_bucketed_kernel, forward passes =
-    # launches of outconv_fwd_kernel / outconv_fwdbwd_kernel; only a process that ran train steps ALONE (bench.py --no-forward-timing) yields a per-step
+    # launches of outconv_fwd_kernel / outconv_fwdbwd_kernel / outconv8_kernel<., 0 | 2, ..>; only a process that ran train steps ALONE (bench.py --no-forward-timing) yields a per-step
     # total (round 3 divided a 6-train-step + 10-forward-pass process by `runs` = 5: VERDICT r3 weak #6).
     tot = sum((2 * fetch[k] + write.get(k, 0.0)) * 1024 for k in fetch)
     n_adam = sum(n for k, n in nf.items() if k.startswith('adam_bucketed_kernel'))
-    n_fwd = sum(n for k, n in nf.items() if k.startswith('outconv_fwd_kernel') or k.startswith('outconv_fwdbwd_kernel'))
+    import re as _re
+    # (outconv8_kernel<CC, MODE, ...>: MODE 0 = forward, 2 = forward + backward, 1 = backward only)
+    n_fwd = sum(n for k, n in nf.items() if k.startswith('outconv_fwd_kernel') or k.startswith('outconv_fwdbwd_kernel')
+                or _re.match(r'outconv8_kernel<\d+, [02],', k))
     if n_adam and n_fwd:
         out['train_steps_profiled'] = n_adam
         out['forward_passes_profiled'] = n_fwd
