@@ -44,19 +44,6 @@ def _pick_ksplit(groups, ntiles, ncu=256, epilogue=1.5, max_wg=1024):
     return best
 
 
-def _ring_ksplit(units, ntiles, ncu=256, kmax=8):
-    """Pixel-tile split of the bf16 weight-gradient kernels (one workgroup per CU).  units = UNets x (ci, co) block pairs.  The rule
-    "fill the CUs in one round" (ks = #CU // units) leaves the launch at ks = 1 when units is just above #CU / 2 -- 160 workgroups
-    on 256 CUs for the 256 -> 256 layer of the 4x4 level and for the first transposed conv (measured: the two slowest weight-gradient
-    launches of BASELINE config 4, 239 / 225 us for 0.1 PFLOP/s).  When one round fills less than 3/4 of the CUs a small ks
-    with several full rounds is taken instead: cost = rounds x tiles per workgroup, plus 5 % per extra slab for the reduction."""
-    k0 = max(1, min(ntiles, ncu // max(units, 1)))
-    if units * k0 * 4 >= ncu * 3 or os.environ.get('VV_WGRAD_ONE_ROUND') == '1':      # (A/B switch: the one-round rule everywhere)
-        return k0
-    cost = lambda k: (-(-units * k // ncu)) * (-(-ntiles // k)) * (1.0 + 0.05 * (k - 1))
-    return min(range(1, min(ntiles, kmax) + 1), key=lambda k: (cost(k), k))
-
-
 class UnitSpec:
     """One UNet of the bank: which frame it erases from the input and what it predicts."""
 
@@ -703,7 +690,7 @@ class UNetBank:
                 # (the flags of the launch go with the query: the all-bf16 weight gradient runs the LDS-ring kernel, whose tiling differs)
                 wfl = (L.WGRAD_DY_BF16 | L.WGRAD_X_BF16) if (self.dz16 and self.y16) else 0
                 if lib.vv_wgrad_bf16_plan(L.CONV3 | (wfl << 8), B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
-                    ks = _ring_ksplit(Ga * nblk.value, ntb.value)      # one workgroup per CU, one round (or a few full ones)
+                    ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))      # one workgroup per CU, one round
                     wplan['c%d' % l.idx] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['c%d' % l.idx][1])
         for u, (_, H, ci, co) in enumerate(lay.convT):
@@ -714,7 +701,7 @@ class UNetBank:
             if self.cflag and self.bf16_wgrad:
                 ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
                 if lib.vv_wgrad_bf16_plan(L.CONVT_FWD, B, H, H, ci, co, C.byref(ntb), C.byref(nblk), C.byref(kw)):
-                    ks = _ring_ksplit(Ga * nblk.value, ntb.value)
+                    ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))
                     wplan['t%d' % u] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['t%d' % u][1])
         # weight-gradient slabs: one region per layer (the reductions of a whole gradient bucket run as ONE grouped launch after the
