@@ -60,7 +60,11 @@ $C4 --steps 10 --warmup 3 --no-graph --breakdown > /dev/null 2> $O/breakdown_bf1
 python $R/tools/ubench_conv16.py 10 > $O/ubench_conv16.txt 2>/dev/null
 python $R/tools/ubench_conv16.py 10 legacy > $O/ubench_conv16_legacy.txt 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/ubench/gemm16_loop.hip -o /tmp/g16loop 2>/dev/null && /tmp/g16loop > $O/gemm16_loop_calibration.txt
+# config 4 as its own process (the bench line's cfg4_* record runs behind the fp32 workload of the same process and reads 1 - 3 % lower),
+# twice around the round-3-kernel run of the same box
+$C4 --steps 20 --warmup 5 > $O/bench_bf16_full_b512.json 2>/dev/null
 VV_CONV_GEMM16=0 $C4 --steps 10 --warmup 3 > $O/bench_bf16_full_b512_round3_conv_kernel.json 2>/dev/null
+$C4 --steps 20 --warmup 5 >> $O/bench_bf16_full_b512.json 2>/dev/null
 VV_FN2_WINO=0 python $R/tools/bench_flownet2.py > $O/bench_flownet2_no_winograd.json 2>/dev/null
 python - <<PY
 import json

@@ -20,7 +20,7 @@ for t in "" _bf16_full_b512 _flownet2; do
 done
 for n in net4_b256 net4_b32; do cp $O/step_gaps_$n.txt $P/r04_step_gaps_$n.txt; done
 for n in net4_b256 net4_b32 bf16_full_b512; do cp $O/breakdown_$n.txt $P/r04_breakdown_$n.txt; done
-for f in ubench_conv16.txt ubench_conv16_legacy.txt gemm16_loop_calibration.txt bench_bf16_full_b512_round3_conv_kernel.json bench_flownet2_no_winograd.json; do [ -f $O/$f ] && cp $O/$f $P/r04_$f; done
+for f in ubench_conv16.txt ubench_conv16_legacy.txt gemm16_loop_calibration.txt bench_bf16_full_b512.json bench_bf16_full_b512_round3_conv_kernel.json bench_flownet2_no_winograd.json; do [ -f $O/$f ] && cp $O/$f $P/r04_$f; done
 [ -f $O/flownet2_layers.txt ] && cp $O/flownet2_layers.txt $P/r04_flownet2_layers.txt
 python - <<PY
 import json
