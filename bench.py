@@ -623,7 +623,7 @@ def main():
         out['comm'] = rec['comm']
     if world == 1 and not args.no_secondary:
         sec = {}
-        for name, fn in (('full_b512_bf16', lambda: run_unet('full', 'bf16', 512, 10, 3, dev, 0, 1, None, 'none', False, 2048,
+        for name, fn in (('full_b512_bf16', lambda: run_unet('full', 'bf16', 512, 20, 5, dev, 0, 1, None, 'none', False, 2048,
                                                              graph=not args.no_graph)),
                          # the per-rank workloads of the reference's DataParallel split (train.py:375): BASELINE configs[2]
                          # = 256 / 8 GPUs, config.cfg's batch_size = 128 / 8 GPUs -- 1-GPU proxies, hipGraph vs eager loop
