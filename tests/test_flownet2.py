@@ -29,7 +29,7 @@ def _seeded_sd():
 
 def test_flownet2_oracle_matches_reference_graph():
     from oracle import flownet2_oracle as FO
-    torch.set_num_threads(8)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
     net, sd, g = _seeded_sd()
     out = FO.flownet2_forward(sd, _inputs())
     assert list(out.shape) == list(g['out_shape'])
@@ -132,7 +132,7 @@ def test_upsample4_vs_torch():
 @pytest.mark.gpu
 def test_flownet2_hip_vs_oracle_and_golden(monkeypatch):
     from oracle import flownet2_oracle as FO
-    torch.set_num_threads(8)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
     net, sd, g = _seeded_sd()
     net.load_state_dict(sd)
     net = net.cuda().eval()
@@ -166,7 +166,7 @@ def test_flownet2_align_corners_true_matches_oracle():
     FlowNet2(upsample_align_corners=True): same bar against the oracle run with the same switch, and the switch must matter."""
     from oracle import flownet2_oracle as FO
     from vec_vad_amd.flownet2 import FlowNet2
-    torch.set_num_threads(8)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
     _, sd, g = _seeded_sd()
     inp = _inputs()
     outs = {}
