@@ -61,8 +61,11 @@ def load_artifacts(base, fg, method, shanghai, build_net, device, h_block=1, w_b
     if shanghai:
         net_set = [[[build(weights[s][hh][ww]) for ww in range(len(weights[s][hh]))] for hh in range(len(weights[s]))]
                    for s in range(len(weights))]
-        st_r = [[[stat(raw_tr[s][hh][ww]) for ww in range(w_block)] for hh in range(h_block)] for s in range(len(weights))]
-        st_o = [[[stat(of_tr[s][hh][ww]) for ww in range(w_block)] for hh in range(h_block)] for s in range(len(weights))]
+        # (the statistics' nesting follows the FILE like the networks' does: h_block / w_block are accepted for compatibility only)
+        st_r = [[[stat(raw_tr[s][hh][ww]) for ww in range(len(weights[s][hh]))] for hh in range(len(weights[s]))]
+                for s in range(len(weights))]
+        st_o = [[[stat(of_tr[s][hh][ww]) for ww in range(len(weights[s][hh]))] for hh in range(len(weights[s]))]
+                for s in range(len(weights))]
     else:
         net_set = [[build(weights[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]
         st_r = [[stat(raw_tr[hh][ww]) for ww in range(len(weights[hh]))] for hh in range(len(weights))]

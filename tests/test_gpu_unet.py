@@ -837,3 +837,79 @@ def test_bf16_concat_gradient_in_two_planes_bitwise_equal(monkeypatch, kind, nf,
     assert torch.equal(res[0][1], res[1][1])
     assert float(res[0][1].abs().max()) > 0
 
+
+
+# ---- features_root other than 32 / 64: the model runs EMBEDDED in the next engine width (vec_vad_amd/unet.py engine_width) ----
+@pytest.mark.parametrize('kind,nf,n', [('net4', 4, 6), ('net4', 16, 6), ('full', 8, 4), ('1raw1of', 48, 3), ('net4', 20, 5)])
+def test_embedded_width_matches_oracle_eval_train_and_state(kind, nf, n):
+    """model/unet.py:74,271,563 take any features_root.  Zero-padded into the 32- / 64-wide engine, the extra channels must hold
+    exact zeros forward, receive exact-zero gradients and stay at zero through Adam, so that the module IS the reference's model:
+    eval scores and outputs vs the oracle at the model's own width (1e-3 / 2e-5 of max), three fused train steps (losses 1e-3,
+    parameters like test_three_train_steps_fused), the autograd drop-in's gradients, and the zero block checked bit for bit."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    from vec_vad_amd.unet import engine_width, _embed_pieces
+    net, sd, tot_of = _build(kind, False, nf=nf)
+    assert net._embedded and net._engine_nf == engine_width(nf) and net._engine_nf in (32, 64)
+    raw, flow = O.seeded_cubes(n, tot_of, 0)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    xs, xo = x.cuda(), x_of.cuda()
+    spec = O.bank_spec(kind)
+    net.eval()
+    with torch.no_grad():
+        of_o, raw_o, of_t, raw_t = net(xs, xo)
+        oo, ro, ot, rt = O.bank_forward(sd, spec, x, x_of, False, False)
+    np.testing.assert_allclose(((raw_t - raw_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), O.cube_scores(ro, rt).numpy(), rtol=1e-3)
+    np.testing.assert_allclose(((of_t - of_o) ** 2).sum(dim=(1, 2, 3)).cpu().numpy(), O.cube_scores(oo, ot).numpy(), rtol=1e-3)
+    assert torch.allclose(raw_o.cpu(), ro, rtol=0, atol=2e-5 * float(ro.abs().max()))
+    # autograd drop-in: gradients in the module's own shapes vs the oracle's
+    net.train()
+    sd_g = {k: v.clone() for k, v in sd.items()}
+    _, _, g_ref = O.train_step(sd_g, spec, x, x_of, O.AdamState(O.param_names(sd_g)))
+    of_o, raw_o, of_t, raw_t = net(xs, xo)
+    lf = torch.nn.MSELoss()
+    (lf(raw_t.detach(), raw_o) + lf(of_t.detach(), of_o)).backward()
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        if k.endswith('.0.bias') or k.endswith('.3.bias'):
+            continue
+        assert p.grad.shape == g_ref[k].shape
+        num += float(((p.grad.cpu().double() - g_ref[k].double()) ** 2).sum())
+        den += float((g_ref[k].double() ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    # fused trainer, three steps from the seeded state (the module was not stepped: reload it, which also exercises the push path)
+    net.load_state_dict(sd)
+    net.zero_grad()
+    tr = FusedTrainer(net)
+    sd_o = {k: v.clone() for k, v in sd.items()}
+    opt = O.AdamState(O.param_names(sd_o))
+    for step in range(3):
+        ws = tr.step_nchw(xs, xo)
+        l_hip = [float(v) for v in tr.losses(ws)]
+        l_ref = O.train_step(sd_o, spec, x, x_of, opt)[:2]
+        np.testing.assert_allclose(l_hip, l_ref, rtol=1e-3)
+    got = net.state_dict()                  # pulls the trained blocks out of the engine's tensors
+    assert _param_rel_l2(got, sd_o) < 2e-2
+    for k, v in got.items():
+        assert v.shape == sd_o[k].shape, k
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == int(sd_o[k]) == 3          # load_state_dict reset the counter; three fused steps since
+        elif k.endswith('running_mean') or k.endswith('running_var'):
+            assert torch.allclose(v.cpu(), sd_o[k], rtol=2e-3, atol=1e-5), k
+    # the padding of the engine's tensors is still exactly zero (parameters, Adam moments, running statistics)
+    bank = net.bank()
+    mask = torch.ones_like(bank.params, dtype=torch.bool)
+    for (g, key, p) in net._param_index:
+        off, shape = bank.lay.p[key]
+        m = mask[g, off:off + int(np.prod(shape))].view(shape)
+        for mi, bi in _embed_pieces(bank.lay, key, tuple(p.shape)):
+            m[bi] = False
+    assert int(mask.sum()) > 0
+    assert float(bank.params[mask].abs().max()) == 0.0
+    assert float(bank.adam_m[mask].abs().max()) == 0.0 and float(bank.adam_v[mask].abs().max()) == 0.0
+    # ... and the eval-mode scores after training agree with the oracle's on ITS trained weights
+    net.eval()
+    r, o = [t.cpu().numpy() for t in tr.score_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda())]
+    rs, os_ = O.score_pass(sd_o, spec, x, x_of, n)
+    np.testing.assert_allclose(r, rs, rtol=1e-3)
+    np.testing.assert_allclose(o, os_, rtol=1e-3)

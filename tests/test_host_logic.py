@@ -411,3 +411,57 @@ w_of =0.5
     c = T.read_config(str(p))
     assert (c['dataset_name'], c['h_block'], c['w_block'], c['tot_of_num'], c['rawRange']) == ('avenue', 2, 3, 1, 3)
     assert c['padding'] is True and c['lambda_of'] == 2.0 and c['w_of'] == 0.5 and c['shuffle_seed'] == 0 and c['score_batch'] == 512
+
+
+def test_graph_cache_keeps_two_cube_stores():
+    """a loop that alternates a training and a validation store must keep replaying both (the cache pins the two most
+    recently used stores); a third store evicts the least recently used one; release_graphs(keep_store=...) drops the others."""
+    from vec_vad_amd.trainer import FusedTrainer
+    tr = FusedTrainer.__new__(FusedTrainer)
+    tr._graphs = {}
+    A, Bs, Cs = (100, 101), (200, 201), (300, 301)
+    key = lambda kind, B, st: (kind, B) + st + (1e-3,)
+    for st in (A, Bs, A, Bs):
+        for kind in ('train', 'eval'):
+            k = key(kind, 32, st)
+            if tr._graph_lookup(k) is None:
+                tr._graphs[k] = 'cap'
+    assert len(tr._graphs) == 4 and all(tr._graph_lookup(key(kd, 32, st)) == 'cap' for st in (A, Bs) for kd in ('train', 'eval'))
+    assert tr._graph_lookup(key('train', 32, A)) == 'cap'          # A is now the most recently used
+    assert tr._graph_lookup(key('train', 32, Cs)) is None           # third store: evicts B (least recently used), keeps A
+    tr._graphs[key('train', 32, Cs)] = 'cap'
+    assert {k[2:4] for k in tr._graphs} == {A, Cs}
+    tr.release_graphs(keep_store=Cs)
+    assert {k[2:4] for k in tr._graphs} == {Cs} and tr._store_lru == [Cs]
+    tr.release_graphs()
+    assert tr._graphs == {} and tr._store_lru == []
+
+
+def test_embedded_width_layout_roundtrip():
+    """features_root outside {32, 64}: every module tensor maps to block(s) of the engine tensor and back (concat layers: the
+    upsampled half starts at the ENGINE's half width), engine_width picks 32 / 64 and refuses widths above 64."""
+    import torch
+    from vec_vad_amd import _lib as L
+    from vec_vad_amd.bank import BankLayout, conv_key_to_state_name
+    from vec_vad_amd.unet import SelfCompleteNet4, _embed_pieces, engine_width
+    assert [engine_width(n) for n in (1, 4, 31, 32, 33, 48, 64)] == [32, 32, 32, 32, 64, 64, 64]
+    with pytest.raises(L.VecVadHipError):
+        engine_width(96)
+    for nf in (4, 20, 48):
+        net = SelfCompleteNet4(features_root=nf, padding=False)
+        lay = BankLayout(engine_width(nf), 12)
+        stems = net._stems('_of')
+        for key, (off, shape) in lay.p.items():
+            p = net.get_parameter(conv_key_to_state_name(stems, key))
+            dst = torch.zeros(shape)
+            for mi, bi in _embed_pieces(lay, key, tuple(p.shape)):
+                dst[bi] = p.data[mi]
+            back = torch.empty(p.shape)
+            for mi, bi in _embed_pieces(lay, key, tuple(p.shape)):
+                back[mi] = dst[bi]
+            assert torch.equal(back, p.data), key
+            assert int((dst != 0).sum()) == int((p.data != 0).sum()), key
+        l12 = lay.convs[12]
+        w = net.get_parameter(conv_key_to_state_name(stems, 'c12.w'))
+        (m0, b0), (m1, b1) = _embed_pieces(lay, 'c12.w', tuple(w.shape))
+        assert b1[1].start == l12.cin // 2 and m1[1].start == nf and b0[1] == slice(0, nf)

@@ -85,3 +85,34 @@ def test_saved_by_build_loads_like_reference_file(tmp_path):
     back = torch.load(str(tmp_path / 'm.npy'), map_location='cpu', weights_only=False)[0][0][0]
     assert list(back.keys()) == list(ref.keys())
     assert all(back[k].dtype == ref[k].dtype and back[k].shape == ref[k].shape for k in ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ds,kind,shanghai', [('UCSDped2', 'net4', False), ('ShanghaiTech', 'full', True)])
+def test_reference_written_checkpoint_scored_by_the_hip_bank(ds, kind, shanghai):
+    """SURVEY 8(f-4) closed on the GPU: the model file the REFERENCE's classes wrote (features_root = 4) is loaded by test.py's
+    loader onto the MI355X and the cubes the reference scored after training (train.py:413-427) go through test.py's own device
+    scoring path (FusedTrainer.score_cubes: cube gather + folded eval forward + fused per-cube score sums, all HIP; the 4-wide
+    model runs embedded in the 32-wide engine, vec_vad_amd/unet.py engine_width) -- the scores must be the ones the reference
+    stored next to the weights, at the north-star bar (1e-3; observed ~1e-6)."""
+    import test as S
+    from vec_vad_amd.trainer import FusedTrainer
+    base = os.path.join(REF, ds + '_')
+    net_set, st_r, st_o = S.load_artifacts(base, FG, METHOD, shanghai, _build(kind), 'cuda')
+    raw_tr = torch.load(base + 'raw_training_scores_%s_%s.npy' % (FG, METHOD), weights_only=False)
+    of_tr = torch.load(base + 'of_training_scores_%s_%s.npy' % (FG, METHOD), weights_only=False)
+    last = len(raw_tr) - 1 if shanghai else None      # every scene's dict aliases the final weights (see the CPU test above)
+    tot_of = 5 if kind == 'full' else 1
+    raw, flow = O.seeded_cubes(8 if shanghai else 12, tot_of, (30 + last) if shanghai else 21)
+    net = (net_set[last][0][0] if shanghai else net_set[0][0])[0]
+    assert net._embedded and net._engine_nf == 32 and next(net.parameters()).is_cuda and not net.training
+    tr = FusedTrainer(net, reset_optimizer=False)
+    cubes = [raw[:5], raw[5:5], raw[5:]]              # three "frames", one of them empty (test.py:276)
+    flows = [flow[:5], flow[5:5], flow[5:]]
+    r, o = S.score_cubes_device(tr, cubes, flows, score_batch=4)
+    r_ref, o_ref = (raw_tr[last][0][0], of_tr[last][0][0]) if shanghai else (raw_tr[0][0], of_tr[0][0])
+    np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-3)
+    np.testing.assert_allclose(o.cpu().numpy(), o_ref, rtol=1e-3)
+    from _util import observe
+    observe('ref_written_%s_on_hip' % ds, raw_rel=float(np.abs(r.cpu().numpy() / r_ref - 1).max()),
+            of_rel=float(np.abs(o.cpu().numpy() / o_ref - 1).max()))

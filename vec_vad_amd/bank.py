@@ -935,22 +935,38 @@ class UNetBank:
         return ws
 
     def forward(self, ws, train, outputs=True):
-        """Runs the grouped forward.  train=True: batch statistics, running-stat update, dout4 = d(loss)/d(out).
-        outputs=False: only the per-cube scores (and dout4) are needed -- the reconstruction ws.out4 is not written."""
+        """Runs the grouped forward.  train=True: batch statistics, running-stat update, and the loss gradient of the 1x1 output
+        conv: as ws.dout4 = d(loss)/d(out) (outputs=True, or VV_FUSE_OUTCONV=0), or -- outputs=False with the fused output conv --
+        already carried through that conv by vv_outconv_fwdbwd (ws.gA_last / ocpart / bnpart; ws.dout4 is NOT written).  Which of
+        the two happened is recorded in ws.fused_fwd and backward() follows it.
+        outputs=False: only the per-cube scores are needed -- the reconstruction ws.out4 is not written."""
         if not train and self.eval_fold:
             self.prepare_eval()
-        (ws.fwd if outputs else ws.fwdq)[bool(train)].run(self._stream())
+        plan = (ws.fwd if outputs else ws.fwdq)[bool(train)]
+        plan.run(self._stream())
         ws.out4_valid = bool(outputs)
+        if train:
+            ws.fused_fwd = bool(getattr(plan, 'fused_outconv', False))
         if train:
             self.nbt[self.g0:self.g0 + self.Ga] += 1
             self.mark_dirty()
         return ws.score
 
-    def backward(self, ws, fused=False):
+    def backward(self, ws, fused=None):
         """Gradients of everything wrt ws.dout4 into self.grads (conv biases in front of BatchNorm get exact zeros).
-        fused: the forward was the scores-only train plan (outputs=False), whose vv_outconv_fwdbwd already did the output conv's
-        backward with the loss gradient -- ws.dout4 is then neither written nor read."""
-        self.backward_plan(ws, fused and self.fuse_outconv).run(self._stream())
+        The plan follows the LAST train-mode forward on this workspace (ws.fused_fwd): behind the scores-only train plan
+        (outputs=False), whose vv_outconv_fwdbwd already did the output conv's backward with the loss gradient, ws.dout4 is neither
+        written nor read and the plan has no vv_outconv_bwd launch; behind every other forward the plan starts from ws.dout4.
+        fused: optional assertion of which of the two the caller expects -- a mismatch raises instead of running a backward on
+        stale buffers (True is accepted behind an unfused forward only when the library runs with VV_FUSE_OUTCONV=0, where
+        "fused" has always meant "scores-only forward")."""
+        ran = getattr(ws, 'fused_fwd', None)
+        if ran is None:
+            raise RuntimeError('backward() needs a train-mode forward on this workspace first')
+        if fused is not None and bool(fused and self.fuse_outconv) != ran:
+            raise RuntimeError('backward(fused=%r) behind a forward that %s the fused output-conv pass: the buffers of the other plan '
+                               'are stale' % (fused, 'ran' if ran else 'did not run'))
+        self.backward_plan(ws, ran).run(self._stream())
 
     def losses(self, ws):
         """(loss_raw, loss_of) as device scalars from the per-cube squared errors (train.py:385-392)."""

@@ -176,8 +176,8 @@ class _Runner:
         return True
 
     def _wino(self, m, src, dst, dst_coff, slope, stream):
-        """Large stride-1 3x3 layers in Winograd F(2x2,3x3) form (vv_conv2d_wino): the layers that fill the chip -- at least 256
-        workgroups of 4 x 32 pixels x 32 channels -- where 2.25x fewer MFMAs is time (the H/32 and H/64 levels stay on the direct
+        """Large stride-1 3x3 layers in Winograd F(2x2,3x3) form (vv_conv2d_wino): the layers with at least
+        VV_FN2_WINO_MIN_WGS (default 100) workgroups of 4 x 32 pixels x 32 channels -- where 2.25x fewer MFMAs is time (the H/32 and H/64 levels stay on the direct
         kernel with its split-K).  VV_FN2_WINO=0 switches it off."""
         if not _WINO or m.kernel_size != (3, 3) or m.stride != (1, 1) or m.padding != (1, 1) or m.out_channels % 32:
             return False

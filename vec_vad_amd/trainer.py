@@ -210,9 +210,12 @@ class FusedTrainer:
         """train-mode forward + its bookkeeping (BatchNorm's num_batches_tracked, folded eval model invalidated, backward plan built):
         the part every kind of step shares"""
         bank = self.bank
-        self._run((ws.fwd if self.keep_outputs else ws.fwdq)[True], bank._stream())
+        fwd = (ws.fwd if self.keep_outputs else ws.fwdq)[True]
+        self._run(fwd, bank._stream())
         ws.out4_valid = bool(self.keep_outputs)
-        ws.bwd_cur = bank.backward_plan(ws, fused=not self.keep_outputs and bank.fuse_outconv)
+        ws.fused_fwd = bool(getattr(fwd, 'fused_outconv', False))      # which backward plan matches this forward (UNetBank.backward)
+        assert ws.fused_fwd == bool(not self.keep_outputs and bank.fuse_outconv)
+        ws.bwd_cur = bank.backward_plan(ws, fused=ws.fused_fwd)
         bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
         bank.mark_dirty()
 
@@ -379,20 +382,31 @@ class FusedTrainer:
         its store (train.py's per-segment stores of ShanghaiTech) calls this so that the old store's memory is freed with it."""
         if keep_store is None:
             self._graphs = {}
+            self._store_lru = []
         else:
             self._graphs = {k: v for k, v in self._graphs.items() if k[2:4] == keep_store}
+            self._store_lru = [s for s in getattr(self, '_store_lru', []) if s == keep_store]
+
+    MAX_STORES = 2          # cube stores whose graphs are kept at the same time (a training store + a validation / scoring store)
 
     def _graph_lookup(self, key):
-        """Cache entry of ``key`` = (kind, B, raw pointer, flow pointer, ...).  Entries are pinned per cube STORE, and at most one
-        store is kept: a key of a new store evicts every entry (captured or 'warm') of the others, so a trainer fed a fresh store
-        per data segment holds one store's graphs, not one set per segment it has ever seen.  Within a store the
-        distinct (kind, B, hyper-parameter) keys are bounded at 8."""
+        """Cache entry of ``key`` = (kind, B, raw pointer, flow pointer, ...).  Entries are pinned per cube STORE and the
+        MAX_STORES most recently used stores are kept: a key of a further store evicts every entry (captured or 'warm') of the
+        least recently used one, so a trainer fed a fresh store per data segment holds two stores' graphs, not one set per
+        segment it has ever seen, while a loop that alternates a training and a validation store keeps replaying both
+        (train.py frees a replaced store at once with release_graphs()).  Within the cache the distinct
+        (kind, B, store, hyper-parameter) keys are bounded at 8."""
+        store = key[2:4]
+        lru = self._store_lru = [s for s in getattr(self, '_store_lru', []) if s != store] + [store]
         cap = self._graphs.get(key)
         if cap is None:
-            if any(k[2:4] != key[2:4] for k in self._graphs):
-                self.release_graphs(keep_store=key[2:4])
+            while len(lru) > self.MAX_STORES:
+                old = lru.pop(0)
+                self._graphs = {k: v for k, v in self._graphs.items() if k[2:4] != old}
             if len(self._graphs) >= 8:
-                self._graphs = {}
+                self._graphs = {k: v for k, v in self._graphs.items() if k[2:4] == store}
+                if len(self._graphs) >= 8:
+                    self._graphs = {}
         return cap
 
     def _step_graphed(self, raw_u8, flow, idx):
@@ -418,6 +432,7 @@ class FusedTrainer:
         bank._adam_t += 1            # host mirror of the device step counter (vv_adam_tick advanced it inside the graph)
         bank.mark_dirty()
         cap.ws.out4_valid = bool(self.keep_outputs)      # part of the cache key: the captured plan stores them or not
+        cap.ws.fused_fwd = bool(not self.keep_outputs and bank.fuse_outconv)
         return cap.ws
 
     def step_cubes(self, raw_u8, flow, idx):

@@ -21,6 +21,43 @@ _NO_STANDALONE = ('this block only carries parameters for the fused HIP UNet ban
                   'SelfCompleteNet* model (vec_vad_amd has no per-block PyTorch fallback)')
 
 
+def engine_width(features_root):
+    """Width the HIP bank runs a model of ``features_root`` at.  The MFMA tiles are built for 32- and 64-wide first levels
+    (every shipped config.cfg has 32, SelfCompleteNet1raw1of defaults to 64, model/unet.py:74,271,563); any other width up to
+    64 runs EMBEDDED in the next engine width: the extra channels carry zero filters, zero BatchNorm gamma / beta and zero
+    biases, so they hold exact zeros in the forward pass (relu(0 * xhat + 0) = 0, and a zero adds exactly nothing to a
+    consumer's sum), receive exact-zero gradients in the backward pass (dz = gamma * ... = 0, activation 0, xhat 0) and are
+    left at zero by Adam (m = v = 0 -> update 0 / (0 + eps) = 0): the embedded model is the reference's model, not an
+    approximation of it."""
+    nf = int(features_root)
+    if nf in (32, 64):
+        return nf
+    if 0 < nf < 32:
+        return 32
+    if 32 < nf < 64:
+        return 64
+    raise L.VecVadHipError('features_root = %d: the HIP UNet bank is built for first-level widths up to 64 '
+                           '(32 = every shipped config.cfg, 64 = SelfCompleteNet1raw1of default)' % nf)
+
+
+def _embed_pieces(lay, key, mshape):
+    """How a module tensor of shape ``mshape`` sits inside the bank tensor ``key`` (engine layout ``lay``): a list of
+    (module index, bank index) pairs.  One top-left block for everything except the first conv of an ``up`` block, whose input is
+    cat([skip, upsampled]) (model/unet.py:59): the module's upsampled half starts at channel cin_m / 2, the engine's at cin_e / 2."""
+    kind, field = key.split('.')
+    if kind[0] == 'c' and field == 'w':
+        l = lay.convs[int(kind[1:])]
+        co, ci = mshape[0], mshape[1]
+        if l.mode == L.IN_CAT:
+            h, he = ci // 2, l.cin // 2
+            return [((slice(None), slice(0, h)), (slice(0, co), slice(0, h))),
+                    ((slice(None), slice(h, 2 * h)), (slice(0, co), slice(he, he + h)))]
+        return [((slice(None), slice(None)), (slice(0, co), slice(0, ci)))]
+    if len(mshape) >= 2:              # transposed conv [ci, co, 3, 3], 1x1 output conv [out_c, nf, 1, 1]
+        return [((slice(None), slice(None)), (slice(0, mshape[0]), slice(0, mshape[1])))]
+    return [((slice(None),), (slice(0, mshape[0]),))]
+
+
 class double_conv(nn.Module):
     """(conv3x3 => BN => ReLU) * 2 -- parameter holder (reference: model/unet.py:4-20)."""
 
@@ -115,10 +152,16 @@ class _BankFn(torch.autograd.Function):
         g = bank.grads.clone()          # fresh storage: autograd may keep / accumulate these views
         out = []
         for (gi, key, p) in model._param_index:
-            if bank.g0 <= gi < bank.g0 + bank.Ga:
-                out.append(bank.grad_view(gi, key, grads=g, shape=p.shape))      # (the 1x1 output conv is padded to 4 rows in the bank)
-            else:
+            if not (bank.g0 <= gi < bank.g0 + bank.Ga):
                 out.append(None)
+            elif model._embedded:          # narrower than the engine: gather the module's block(s) out of the engine-shaped gradient
+                ge = bank.grad_view(gi, key, grads=g)
+                gm = torch.empty(p.shape, device=ge.device, dtype=ge.dtype)
+                for mi, bi in _embed_pieces(bank.lay, key, tuple(p.shape)):
+                    gm[mi] = ge[bi]
+                out.append(gm)
+            else:
+                out.append(bank.grad_view(gi, key, grads=g, shape=p.shape))      # (the 1x1 output conv is padded to 4 rows in the bank)
         return (None, None, None, None) + tuple(out)
 
 
@@ -148,6 +191,9 @@ class _SelfCompleteBase(nn.Module):
         self._bank = None
         self._bank_dirty = True
         self._lambda = (1.0, 1.0)
+        self._engine_nf = engine_width(features_root)
+        self._embedded = self._engine_nf != features_root
+        self._sync_ver = None           # embedded models: (module tensor versions, bank state version) of the last push / pull
 
     def _make_unet(self, tag, out_ch):
         """Registers inc<tag>, down<tag>{1,2,3} and returns the matching `up` builder (decoder is registered later,
@@ -177,11 +223,13 @@ class _SelfCompleteBase(nn.Module):
         raise NotImplementedError
 
     def _apply(self, fn, *a, **k):
+        self._sync()                     # (embedded widths) what the bank trained must be in the tensors that are about to move
         r = super()._apply(fn, *a, **k)
         self._bank_dirty = True
         return r
 
     def set_loss_weights(self, lambda_raw=1.0, lambda_of=1.0):
+        self._sync()
         self._lambda = (lambda_raw, lambda_of)
         self._bank_dirty = True
 
@@ -197,25 +245,28 @@ class _SelfCompleteBase(nn.Module):
         table = self._unit_table()
         g0, ga = self._active_window(table)
         old = self._bank
-        bank = UNetBank([u for u, _ in table], nf=self.features_root, tot_raw_num=self.tot_raw_num,
+        bank = UNetBank([u for u, _ in table], nf=self._engine_nf, tot_raw_num=self.tot_raw_num,
                         tot_of_num=self.tot_of_num, padding=self.padding, active=(g0, ga), device=device,
                         lambda_raw=self._lambda[0], lambda_of=self._lambda[1])
-        index = []
+        index, bindex = [], []
         with torch.no_grad():
             for g, (u, stems) in enumerate(table):
                 for key, (off, shape) in bank.lay.p.items():
                     p = self.get_parameter(conv_key_to_state_name(stems, key))
-                    dst = bank.params[g, off:off + p.numel()].view(p.shape)
-                    dst.copy_(p.data)
-                    p.data = dst
+                    if not self._embedded:     # the module tensor IS the bank's block
+                        dst = bank.params[g, off:off + p.numel()].view(p.shape)
+                        dst.copy_(p.data)
+                        p.data = dst
                     index.append((g, key, p))
                 for key, (off, shape) in bank.lay.b.items():
                     name = conv_key_to_state_name(stems, key)
                     mod, _, leaf = name.rpartition('.')
                     m = self.get_submodule(mod)
-                    dst = bank.bufs[g, off:off + shape[0]]
-                    dst.copy_(getattr(m, leaf))
-                    m._buffers[leaf] = dst
+                    if not self._embedded:
+                        dst = bank.bufs[g, off:off + shape[0]]
+                        dst.copy_(getattr(m, leaf))
+                        m._buffers[leaf] = dst
+                    bindex.append((g, key, m, leaf))
                     if leaf == 'running_mean':
                         l = int(key.split('.')[0][1:])
                         bank.nbt[g, l] = m.num_batches_tracked.to(device)
@@ -223,15 +274,82 @@ class _SelfCompleteBase(nn.Module):
         if old is not None and old.adam_m is not None and old.params.shape == bank.params.shape:
             bank.adam_m, bank.adam_v, bank.adam_t = old.adam_m.to(device), old.adam_v.to(device), old.adam_t
         self._param_index = index
+        self._buf_index = bindex
         self._bank = bank
         self._bank_dirty = False
+        if self._embedded:
+            self._push()
         return bank
+
+    # ---- embedded widths (features_root not 32 / 64): module tensors are copies of blocks of the engine's tensors ------------
+    def _tensor_versions(self):
+        return (tuple(p._version for (_, _, p) in self._param_index),
+                tuple(getattr(m, leaf)._version for (_, _, m, leaf) in self._buf_index))
+
+    def _push(self):
+        """module -> bank (after construction, load_state_dict, or an optimizer that wrote the module's tensors)."""
+        bank = self._bank
+        with torch.no_grad():
+            for (g, key, p) in self._param_index:
+                off, shape = bank.lay.p[key]
+                n = 1
+                for d in shape:
+                    n *= d
+                dst = bank.params[g, off:off + n].view(shape)
+                for mi, bi in _embed_pieces(bank.lay, key, tuple(p.shape)):
+                    dst[bi] = p.data[mi].to(dst.device)
+            for (g, key, m, leaf) in self._buf_index:
+                off, shape = bank.lay.b[key]
+                src = getattr(m, leaf)
+                bank.bufs[g, off:off + src.shape[0]] = src.to(bank.bufs.device)
+        bank.mark_dirty()
+        self._sync_ver = (self._tensor_versions(), bank._state_ver)
+
+    def _pull(self):
+        """bank -> module (after the bank's own Adam / train-mode BatchNorm wrote parameters and running statistics)."""
+        bank = self._bank
+        with torch.no_grad():
+            for (g, key, p) in self._param_index:
+                off, shape = bank.lay.p[key]
+                n = 1
+                for d in shape:
+                    n *= d
+                src = bank.params[g, off:off + n].view(shape)
+                for mi, bi in _embed_pieces(bank.lay, key, tuple(p.shape)):
+                    p.data[mi] = src[bi].to(p.device)
+            for (g, key, m, leaf) in self._buf_index:
+                off, shape = bank.lay.b[key]
+                dst = getattr(m, leaf)
+                dst.copy_(bank.bufs[g, off:off + dst.shape[0]])
+        self._sync_ver = (self._tensor_versions(), bank._state_ver)
+
+    def _sync(self):
+        """Embedded models: bring module tensors and bank back together, whichever side was written since the last sync (the
+        module wins when both were: an explicit load / optimizer write is the caller's statement of what the model is)."""
+        if not self._embedded or self._bank is None or self._bank_dirty:
+            return
+        tv, sv = self._sync_ver
+        if self._tensor_versions() != tv:
+            self._push()
+        elif self._bank._state_ver != sv:
+            self._pull()
+
+    def state_dict(self, *args, **kwargs):
+        self._sync()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._sync()
+        return r
 
     def forward(self, x, x_of):
         if not x.is_cuda:
             raise L.VecVadHipError('SelfComplete forward needs CUDA/HIP tensors (the hot path is HIP-only)')
         bank = self.bank(x.device)
-        if self._param_index[0][2].data_ptr() != bank.params.data_ptr() + 4 * bank.lay.p['c0.w'][0]:
+        if self._embedded:
+            self._sync()
+        elif self._param_index[0][2].data_ptr() != bank.params.data_ptr() + 4 * bank.lay.p['c0.w'][0]:
             self._bank_dirty = True      # somebody re-assigned .data; re-adopt the parameters
             bank = self.bank(x.device)
         params = [p for (_, _, p) in self._param_index]
