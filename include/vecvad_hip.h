@@ -88,6 +88,9 @@ typedef struct vv_view {
  * GEMM-shaped kernel of round 4 (vv_conv_bf16.hip, 256-pixel tiles on every level); with this flag it stays on the round-3
  * kernel (128-pixel tiles on the 16x16 / 8x8 / 4x4 levels).  vv_conv_ntiles2 follows the same flags. */
 #define VV_CONV_NO_GEMM16 64
+/* A/B switch: vv_conv_wino runs the 32x32-level launches with at most 32 input channels on the persistent LDS-DMA ring kernel of
+ * round 5 (bit-identical results); with this flag they stay on the per-tile kernel. */
+#define VV_CONV_NO_RING 128
 typedef struct vv_conv_params {
   int32_t kind;      /* vv_conv_kind */
   int32_t in_mode;   /* vv_in_mode */

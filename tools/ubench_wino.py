@@ -12,6 +12,7 @@ from vec_vad_amd import _lib as L
 lib = L.lib()
 G, B = 6, int(os.environ.get('UB_B', '256'))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+IN_MODE = L.IN_PLAIN if os.environ.get('UB_PLAIN') == '1' else L.IN_ACT
 st = torch.cuda.current_stream().cuda_stream
 # (H, Cin, Cout, weight in the step: how many forward + dgrad launches of this shape a Net4 train step has)
 LAYERS = [(32, 16, 32, 1, 'conv0'), (32, 32, 32, 4, 'conv1/13 dgrad1/13'), (32, 64, 32, 1, 'conv12'), (32, 32, 64, 1, 'dgrad12'),
@@ -37,12 +38,16 @@ for H, Cin, Cout, mult, name in LAYERS:
     a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
     b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
     outs, times = [], []
-    for fn, pk, nt in ((lib.vv_conv_mfma, pack(lib.vv_pack_weights, w, Cin, Cout, 9), lib.vv_conv_ntiles(B, H, H)),
-                       (lib.vv_conv_wino, pack(lib.vv_pack_wino, w, Cin, Cout, 16), lib.vv_wino_ntiles(B, H))):
+    pkw = pack(lib.vv_pack_wino, w, Cin, Cout, 16)
+    for fn, pk, nt, fl in ((lib.vv_conv_mfma, pack(lib.vv_pack_weights, w, Cin, Cout, 9), lib.vv_conv_ntiles(B, H, H), 0),
+                           (lib.vv_conv_wino, pkw, lib.vv_wino_ntiles(B, H), 0),
+                           (lib.vv_conv_wino, pkw, lib.vv_wino_ntiles(B, H), L.CONV_NO_RING)):
+        if fl and not (H == 32 and Cin <= 32):
+            continue
         y = torch.zeros(G, B * H * H, Cout, device='cuda')
         s_ = torch.zeros(G, nt, 2, Cout, device='cuda')
-        cp = L.ConvParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, Cin, Cout, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(), Cin,
-                          L.NULL_VIEW, 0, 0, None, pk.data_ptr(), pk.stride(0), bias.data_ptr(), Cout, L.view(y, Cout, 0, y.stride(0)),
+        cp = L.ConvParams(L.CONV3, IN_MODE, G, B, H, H, Cin, Cin, Cout, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(), Cin,
+                          L.NULL_VIEW, 0, fl, None, pk.data_ptr(), pk.stride(0), bias.data_ptr(), Cout, L.view(y, Cout, 0, y.stride(0)),
                           s_.data_ptr())
         for _ in range(2):
             L.check(fn(C.byref(cp), st), 'conv')
@@ -58,9 +63,12 @@ for H, Cin, Cout, mult, name in LAYERS:
     err = (outs[0][0] - outs[1][0]).abs().max().item() / outs[0][0].abs().max().item()
     serr = (outs[0][1] - outs[1][1]).abs().max().item() / outs[0][1].abs().max().item()
     alg = 2.0 * B * H * H * 9 * Cin * Cout * G
+    ring = ''
+    if len(outs) > 2:
+        ring = ' | per-tile kernel %7.1f us, ring bit-equal: %s' % (times[2] * 1e6, bool(torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])))
     print('%-20s H=%2d %3d->%3d x%d : wino %7.1f us %6.1f TF/s exec (%.2f of peak)  alg %6.1f | direct %7.1f us %6.1f TF/s | err %.1e stats %.1e %s'
           % (name, H, Cin, Cout, mult, times[1] * 1e6, alg * 16 / 36 / times[1] / 1e12, alg * 16 / 36 / times[1] / 157.3e12, alg / times[1] / 1e12,
-             times[0] * 1e6, alg / times[0] / 1e12, err, serr, '' if err < 2e-5 and serr < 1e-3 else '  <-- MISMATCH'), flush=True)
+             times[0] * 1e6, alg / times[0] / 1e12, err, serr, ('' if err < 2e-5 and serr < 1e-3 else '  <-- MISMATCH') + ring), flush=True)
     tot_t += mult * times[1]
     tot_alg += mult * alg
 print('weighted (27 launches of a Net4 step): %.3f ms, avg %.1f us/launch, executed %.1f TF/s = %.3f of peak, algorithmic %.1f TF/s'

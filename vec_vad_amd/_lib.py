@@ -27,6 +27,7 @@ CONV_OUT_BF16 = 8       # VV_CONV_OUT_BF16
 CONV_ALLSRC_BF16 = 16   # VV_CONV_ALLSRC_BF16
 CONV_RELU = 32          # VV_CONV_RELU: eval mode, BatchNorm folded into the filter, ReLU in the epilogue
 CONV_NO_GEMM16 = 64     # VV_CONV_NO_GEMM16: keep an all-bf16 3x3 launch on the round-3 kernel (A/B switch)
+CONV_NO_RING = 128      # VV_CONV_NO_RING: keep the 32x32-level Winograd launches on the per-tile kernel (A/B switch)
 BNBWD_Y_BF16 = 8
 BNBWD_PARTIALS_PER_TILE = 16   # partial sums left by the data-gradient launch (ConvParams.bn_partial)
 BNBWD_PARTIALS_PER_CTILE = 32  # ... of vv_conv_mfma (all-bf16 tensors): rows per vv_conv_ntiles

@@ -258,6 +258,8 @@ class UNetBank:
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
+        # VV_WINO_RING=0: A/B switch, the 32x32-level Winograd launches stay on the per-tile kernel (bit-identical results)
+        self.wino_flag = L.CONV_NO_RING if (self.wino and os.environ.get('VV_WINO_RING', '1') == '0') else 0
         self.wgrad_flag = 256                  # vv_wgrad_params.pad0 bit 8: Winograd form of the 3x3 weight gradient
         # first reduction pass of the BatchNorm backward inside the data-gradient launch that produces dA (where it is the only producer)
         self.fuse_bn_sums = os.environ.get('VV_FUSE_BN_SUMS', '1') != '0'
@@ -499,7 +501,7 @@ class UNetBank:
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             y = ws.y[l.idx]
             panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
-            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, self.fflag, chmap,
+            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, self.fflag | self.wino_flag, chmap,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
@@ -624,7 +626,7 @@ class UNetBank:
             mode, s0, a, b, s1, csplit = src(l)
             y = ws.y[l.idx]
             panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
-            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, L.CONV_RELU, None,
+            cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, L.CONV_RELU | self.wino_flag, None,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U, L.view(y, l.cout, 0, y.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
@@ -827,7 +829,7 @@ class UNetBank:
                 Dl = ws.D[i]
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
-                                  dgrad_flags(i), None,
+                                  dgrad_flags(i) | self.wino_flag, None,
                                   kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libvecvad_hip.so')
 MANIFEST = os.path.join(CSRC, 'build', 'manifest.json')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + os.environ.get('VV_HIPCC_EXTRA', '').split()
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-inline-asm'] + os.environ.get('VV_HIPCC_EXTRA', '').split()
 
 
 def sources():

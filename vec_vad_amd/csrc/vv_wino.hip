@@ -38,6 +38,14 @@ constexpr int WN = 256;                // threads per workgroup: one wave per xi
 constexpr int WT = 32;                 // tiles per workgroup
 constexpr int SB_MASK = 0x386;         // may cross a scheduling barrier: VALU, SALU, LDS -- not MFMA, not VMEM
 
+// LDS hand-over between the waves of a workgroup WITHOUT the vector-memory drain a __syncthreads() can carry (wino_ring_kernel keeps
+// LDS-DMAs in flight across it); the empty asm keeps the compiler from lifting later LDS reads above the barrier
+__device__ __forceinline__ void vv_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int H_>
 struct WGeo {
   static constexpr int TPI = H_ / 2;                       // tiles per image side
@@ -349,6 +357,314 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// wino_ring_kernel<KQ, BNF>: the same convolution on the 32x32 level for layers with at most 32 (padded) input channels (KQ = CinP
+// / 8 chunks: conv0, conv1 / 13, their data gradients and the data gradient of the concat layer -- 6 of the 7 launches of the
+// level), built around the memory system instead of around the workgroup.
+//
+// Why: wino_conv_kernel<32> runs these layers at 0.40 of the matrix peak with the matrix pipe half idle.  A workgroup lives ~8 us
+// for 1.7 us of MFMA work: 2 us until its first halo chunk is back from HBM, up to 1 us more at every chunk boundary (a chunk's 16
+// MFMAs are shorter than the round trip of the next chunk's loads), an epilogue that loads nothing.  Three workgroups per CU (158
+// registers) then keep ~20 KB per CU in flight = 2.5 TB/s by Little's law -- exactly what the launch moves.  Deeper prefetch inside
+// a workgroup does not help (round 4: all chunks requested at once, same time): the average in flight over the workgroup's LIFE is
+// what counts, and the in-order load counter ties the halo prefetch to the filter-tap loads of the next chunk.
+//
+// Here a workgroup is PERSISTENT (two per CU, a contiguous run of pixel tiles each) and
+//   * the transformed filter taps of its (UNet, N tile) live in registers for the whole run (KQ x 16 per lane: possible because
+//     K <= 32) -- the chunk loop has NO register-destination loads, so the load counter counts halo traffic only;
+//   * halo chunks go global -> LDS by DMA (buffer_load_dwordx4 ... lds, no staging registers) into a ring of NBUF = D + 1 chunk
+//     buffers, D chunks = one or two whole tiles AHEAD of the chunk being multiplied, across tile boundaries and across the
+//     epilogue: the HBM round trip of a tile overlaps the MFMAs and the epilogue of the tile before it.  Counted s_waitcnt vmcnt +
+//     raw s_barrier (a __syncthreads() would drain the ring); the stores of an epilogue sit in the same in-order counter and are
+//     counted (STORES_MIN), so a chunk's wait never waits for them;
+//   * the producing layer's BatchNorm + ReLU is applied in place in LDS by the lane that transferred the 16 bytes (own vmcnt, no
+//     barrier in between); zero padding = DMA lanes whose offset is out of range (zeros) and that the activation pass skips;
+//   * ONE barrier per chunk (wino_conv_kernel: two): a ring slot is refilled right behind the barrier that proves its last
+//     reader has passed.
+// LDS image of a chunk: two planes (channels 0-3 / 4-7 of the 8-channel chunk = the two lane halves of an A operand) of
+// [6 halo rows][column parity][17] float4, no padding: the 16 lanes of a tile row read 16 consecutive float4 (conflict-free), and
+// the image is lane-linear as the DMA needs it (slot s = wave * 128 + k * 64 + lane; 408 of 512 slots used).
+// Same arithmetic in the same order as wino_conv_kernel<32> (chunk -> nu -> 4 MFMAs, same epilogue): bit-identical outputs and
+// BatchNorm partial sums (tests/test_gpu_unet.py::test_wino_ring_bitwise_equal).
+template <int KQ, bool BNF>
+__global__ void __launch_bounds__(WN, 2)
+wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int ipw) {
+  constexpr int H_ = 32, TPI = 16, PARTS = 8, HWH = 17;
+  constexpr int D = 4;                                     // prefetch distance in chunks (whole tiles: D % KQ == 0)
+  constexpr int E = D / KQ;                                // ... = tiles ahead
+  constexpr int NBUF = D + 1;
+  constexpr int CH4 = 512;                                 // float4 slots per ring buffer (408 used)
+  constexpr int PLANE = 6 * 2 * HWH;                       // 204 float4 per channel-quad plane
+  constexpr int NUSED = 2 * PLANE;                         // 408
+  constexpr int EX4 = 4 * 16 * 64 / 2;                     // epilogue exchange [wave][16][64] float2
+  constexpr int RING4 = NBUF * CH4;
+  constexpr int SP4 = RING4 + EX4;                         // [2][4][32] floats: BatchNorm partials of the four waves
+  constexpr int AB4 = SP4 + 64;                            // [2][KQ * 2] float4: a, b of the producing layer's BatchNorm
+  constexpr int STORES_MIN = 16;                           // VMEM instructions every wave issues in every epilogue, at least
+  constexpr int VMW = 2 * (D - 1) + STORES_MIN * E;        // allowed outstanding when chunk j must have landed (see above)
+  static_assert(D % KQ == 0 && VMW <= 63, "ring geometry");
+  __shared__ float4 lds4[AB4 + 4 * KQ];                    // the ONLY __shared__ object (73.6 KB: two workgroups per CU)
+  float* lds = reinterpret_cast<float*>(lds4);
+  const v4f* ldsA = reinterpret_cast<const v4f*>(lds4);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds4;
+
+  const int w_begin = blockIdx.x * ipw;
+  const int w_end = w_begin + ipw < total ? w_begin + ipw : total;
+  if (w_begin >= w_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cout = p.Cout;
+  const bool act_mode = p.in_mode == VV_IN_ACT;
+  const int cs = p.src0.cstride;
+
+  // ---- this lane's two DMA items per chunk (k = 0, 1): slot s -> (channel quad q, halo row hy, column parity, column index)
+  int rel[2];                  // byte offset inside the halo tile, or out of range
+  int yflag[2];                // 1: top halo row (outside the image for part 0), 2: bottom halo row (outside for the last part)
+  bool xok[2];
+  int qk[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int sl = xi * 128 + k * 64 + lane;
+    const int q = sl >= PLANE ? 1 : 0, r = sl - q * PLANE;
+    const int hy = r / (2 * HWH), r2 = r % (2 * HWH);
+    const int par = r2 >= HWH ? 1 : 0, cx = r2 - par * HWH;
+    const int x = 2 * cx + par - 1;
+    xok[k] = sl < NUSED && (unsigned)x < (unsigned)H_;
+    rel[k] = ((hy * H_ + x) * cs + 4 * q) * 4;
+    yflag[k] = (hy == 0 ? 1 : 0) | (hy == 5 ? 2 : 0);
+    qk[k] = sl < NUSED ? q : 0;
+  }
+
+  // ---- cursors.  Work item w -> (g, nn, pt), pt fastest: a workgroup's run stays inside one (UNet, N tile) as long as possible
+  auto decode = [&](const int w, int& g, int& nn, int& pt) {
+    pt = w % NT;
+    const int t = w / NT;
+    nn = t % NN;
+    g = t / NN;
+  };
+  int gc, nc, ptc;             // compute cursor
+  decode(w_begin, gc, nc, ptc);
+  int gd = gc, nd = nc, ptd = ptc, wd = w_begin;         // DMA cursor (E tiles ahead in steady state)
+  auto advance = [&](int& g, int& nn, int& pt) {
+    if (++pt == NT) {
+      pt = 0;
+      if (++nn == NN) { nn = 0; ++g; }
+    }
+  };
+  unsigned voff[2] = {0x80000000u, 0x80000000u};
+  __amdgpu_buffer_rsrc_t rsS;
+  auto dma_item = [&]() {      // per-item part of the DMA addresses for the tile under the DMA cursor (or "nothing": past the run)
+    const bool live = wd < w_end;
+    const int img = ptd >> 3, part = ptd & 7;
+    const int tileoff = ((img * H_ + part * 4 - 1) * H_) * cs * 4;
+    const int ym = (part == 0 ? 1 : 0) | (part == PARTS - 1 ? 2 : 0);
+    rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src0.ptr + (int64_t)(live ? gd : gc) * p.src0.gstride + p.src0.coff), 0,
+                                            0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      voff[k] = (live && xok[k] && !(yflag[k] & ym)) ? (unsigned)(tileoff + rel[k]) : 0x80000000u;
+  };
+  int slotd = 0;               // ring slot the next DMA pair fills
+  auto dma_chunk = [&](const int c) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned dst = lds_base + (unsigned)((slotd * CH4 + xi * 128 + k * 64) * 16);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   ::"s"(dst), "v"(voff[k]), "s"(rsS), "s"(c * 32) : "memory", "m0");
+    }
+    slotd = slotd + 1 == NBUF ? 0 : slotd + 1;
+  };
+
+  // ---- prologue: the first E tiles' chunks in flight
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    dma_item();
+#pragma unroll
+    for (int c = 0; c < KQ; ++c) dma_chunk(c);
+    advance(gd, nd, ptd);
+    ++wd;
+  }
+
+  // ---- this lane's tile and patch origin inside a ring buffer
+  const int tyl = l31 >> 4, tx = l31 & 15;
+  const int pbase = half * PLANE + (2 * tyl) * 2 * HWH + tx;
+  const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+  const float sg = xi == 1 ? 1.f : -1.f;
+  const int po1 = pbase + a1 * 2 * HWH, po2 = pbase + a2 * 2 * HWH;
+
+  v4f u[KQ][4];
+  float bias = 0.f;
+  float bna = 0.f, bnb = 0.f, bni = 0.f, bnm = 0.f;
+  int g_have = -1, n_have = -1;
+  const float lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();
+  const int ocs = p.out.cstride;
+  constexpr int LP = 8;                                    // pixels between the two lane halves (tile + 4)
+  const int bnu = KQ * 2 * Cout * 16;                      // bytes between nu slabs of the packed panel
+  int slotc = 0;
+  v2f* ex2 = reinterpret_cast<v2f*>(lds4 + RING4) + lane;
+  float* sp = lds + SP4 * 4;
+
+  for (int w = w_begin; w < w_end; ++w) {
+    const int co0 = nc * 32;
+    if (gc != g_have || nc != n_have) {
+      // ---- a new (UNet, N tile): filter taps -> registers, bias / BatchNorm scalars, activation table -> LDS.  Rare (a run of
+      //      tiles shares them); these register loads drain the DMA ring once (in-order counter), the counted waits below stay valid
+      const float* __restrict__ wg = p.w + (int64_t)gc * p.w_gstride;
+      const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
+      const unsigned bvo = (unsigned)(half * Cout + co0 + l31) * 16u;
+#pragma unroll
+      for (int c = 0; c < KQ; ++c)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) u[c][n] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bvo, (xi * 4 + n) * bnu + c * 2 * Cout * 16, 0);
+      bias = p.bias ? p.bias[(int64_t)gc * p.bias_gstride + co0 + l31] : 0.f;
+      if constexpr (BNF) {
+        const int64_t bo = (int64_t)gc * p.bn_gstride + co0 + l31;
+        bna = p.bn_a[bo]; bnb = p.bn_b[bo]; bni = p.bn_invstd[bo];
+        bnm = -p.bn_mean[bo] * bni;
+      }
+      if (act_mode && gc != g_have) {
+        if (tid < 4 * KQ) {
+          const float* src = (tid < 2 * KQ ? p.a : p.b) + (int64_t)gc * p.ab_gstride + (tid % (2 * KQ)) * 4;
+          lds4[AB4 + tid] = *reinterpret_cast<const float4*>(src);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);             // (the builtin, not asm: the compiler's own load scoreboard must see it, or it waits
+      vv_lds_barrier();                          //  vmcnt(0) in front of the first MFMA of EVERY tile and drains the ring there)
+      g_have = gc; n_have = nc;
+    }
+    const int img = ptc >> 3, part = ptc & 7;
+    const int ymc = (part == 0 ? 1 : 0) | (part == PARTS - 1 ? 2 : 0);
+
+    v16f acc[4];
+#pragma unroll
+    for (int c = 0; c < KQ; ++c) {
+      // ---- chunk c of this tile has landed (this wave's pieces); activate them in place; meet the other waves
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+      if (act_mode) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (xok[k] && !(yflag[k] & ymc)) {
+            const int sl = slotc * CH4 + xi * 128 + k * 64 + lane;
+            const float4 a4 = lds4[AB4 + c * 2 + qk[k]], b4 = lds4[AB4 + 2 * KQ + c * 2 + qk[k]];
+            lds4[sl] = vv_act4(lds4[sl], a4, b4);
+          }
+      }
+      vv_lds_barrier();
+      // ---- every wave is past chunk j - 1: its slot takes chunk j + D (same chunk index, E tiles ahead)
+      if (c == 0) dma_item();
+      dma_chunk(c);
+      if (c == KQ - 1) { advance(gd, nd, ptd); ++wd; }
+      // ---- V = B^T d B for this wave's xi, 16 MFMAs
+      const int rb = slotc * CH4;
+      v4f R[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int o = (b & 1) * HWH + (b >> 1);
+        const v4f d1 = ldsA[rb + po1 + o], d2 = ldsA[rb + po2 + o];
+        R[b] = d1 + sg * d2;
+      }
+      v4f V[4];
+      V[0] = R[0] - R[2];
+      V[1] = R[1] + R[2];
+      V[2] = R[2] - R[1];
+      V[3] = R[1] - R[3];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (c == 0) {
+          const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[c][n].x, z, 0, 0, 0);
+        } else {
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[c][n].x, acc[n], 0, 0, 0);
+        }
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[c][n].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[c][n].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[c][n].w, acc[n], 0, 0, 0);
+      }
+      slotc = slotc + 1 == NBUF ? 0 : slotc + 1;
+    }
+
+    // ---- epilogue (wino_conv_kernel's, on its own LDS region: the ring keeps filling underneath)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const v2f t = {acc[0][i] + acc[1][i] + acc[2][i], acc[1][i] - acc[2][i] - acc[3][i]};
+      ex2[(xi * 16 + i) * 64] = t;
+    }
+    float zq[4][4];
+    if constexpr (BNF) {
+      const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.bn_z + (int64_t)gc * p.bn_z_gstride), 0, 0x7FFFFFFF, 0x00020000);
+      const int vz = (half * LP * Cout + co0 + l31) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t2 = xi * 8 + j;
+        const int oy = 2 * (part * 2 + t2 / TPI), ox = 2 * (t2 % TPI);
+        const int so = ((img * H_ + oy) * H_ + ox) * Cout * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          zq[j][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, vz, so + ((q >> 1) * H_ + (q & 1)) * Cout * 4, 0));
+      }
+    }
+    vv_lds_barrier();
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+        p.out.ptr + (int64_t)gc * p.out.gstride + p.out.coff, 0, 0x7FFFFFFF, 0x00020000);
+    const int vo = (half * LP * ocs + co0 + l31) * 4;
+    const v2f* exw = ex2 + xi * 4 * 64;
+    v2f s12 = {0.f, 0.f}, q12 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t2 = xi * 8 + j;
+      const int oy = 2 * (part * 2 + t2 / TPI), ox = 2 * (t2 % TPI);
+      const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
+      v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
+      ya[0] = ya[0] < lo ? lo : ya[0]; ya[1] = ya[1] < lo ? lo : ya[1];
+      yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
+      const int so = ((img * H_ + oy) * H_ + ox) * ocs * 4;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[0]), rsO, vo, so, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[1]), rsO, vo, so + ocs * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yb[0]), rsO, vo, so + H_ * ocs * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yb[1]), rsO, vo, so + (H_ + 1) * ocs * 4, 0);
+      if constexpr (BNF) {
+        const v2f za = {zq[j][0], zq[j][1]}, zb = {zq[j][2], zq[j][3]};
+        const v2f pa = bna * za + bnb, pb = bna * zb + bnb;
+        const v2f da = {pa.x > 0.f ? ya.x : 0.f, pa.y > 0.f ? ya.y : 0.f}, db = {pb.x > 0.f ? yb.x : 0.f, pb.y > 0.f ? yb.y : 0.f};
+        s12 += da + db;
+        q12 = __builtin_elementwise_fma(da, bni * za + bnm, q12);
+        q12 = __builtin_elementwise_fma(db, bni * zb + bnm, q12);
+      } else {
+        s12 += ya + yb;
+        q12 = __builtin_elementwise_fma(ya, ya, q12);
+        q12 = __builtin_elementwise_fma(yb, yb, q12);
+      }
+    }
+    float* const sout = BNF ? p.bn_partial : p.stats;
+    if (sout) {
+      float s1 = s12.x + s12.y, s2 = q12.x + q12.y;
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (half == 0) {
+        sp[xi * 32 + l31] = s1;
+        sp[(4 + xi) * 32 + l31] = s2;
+      }
+      vv_lds_barrier();
+      if (tid < 32) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          t1 += sp[k * 32 + tid];
+          t2 += sp[(4 + k) * 32 + tid];
+        }
+        float* st = sout + ((int64_t)(gc * NT + ptc) * 2) * Cout + co0 + tid;
+        st[0] = t1;
+        st[Cout] = t2;
+      }
+    }
+    advance(gc, nc, ptc);
+  }
+  // the tail's dummy DMAs write zeros into ring slots: they must have landed before this workgroup's LDS is handed on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // U = G g G^T of every (ci, co) filter, in the B-operand panel layout [xi*4+nu][Kp/8][2][N][4].
 //   G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
 // mode 0: forward       g[a][b] = W[co = n][ci = k][a][b]
@@ -404,6 +720,30 @@ wino_pack_kernel(const vv_pack_entry* __restrict__ table, const float* __restric
   }
 }
 
+// wino_ring_kernel: two persistent workgroups per CU, a contiguous run of work items each
+template <int KQ>
+int launch_wino_ring(const vv_conv_params* p, hipStream_t st) {
+  const int NT = p->B * 8;
+  const int NN = p->Cout / 32;
+  const int total = p->G * NN * NT;
+  const int slots = 2 * 256;
+  const int ipw = (total + slots - 1) / slots;
+  const int nwg = (total + ipw - 1) / ipw;
+  if (p->bn_partial)
+    VV_LAUNCH((wino_ring_kernel<KQ, true>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
+  else
+    VV_LAUNCH((wino_ring_kernel<KQ, false>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
+// the launches wino_ring_kernel takes: 32x32 level, K <= 32, one plain or activated source, enough tiles for runs of >= 4 per workgroup
+inline bool vv_wino_ring_ok(const vv_conv_params* p) {
+  if (p->H != 32 || (p->CinP != 16 && p->CinP != 32) || (p->pad0 & VV_CONV_NO_RING)) return false;
+  if (p->in_mode != VV_IN_PLAIN && p->in_mode != VV_IN_ACT) return false;
+  return (int64_t)p->G * (p->Cout / 32) * p->B * 8 >= 4 * 512;
+}
+
 template <int H_>
 int launch_wino(const vv_conv_params* p, hipStream_t st) {
   using G_ = WGeo<H_>;
@@ -443,6 +783,7 @@ extern "C" int vv_conv_wino(const vv_conv_params* p, vv_stream stream) {
   if (p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)
     return VV_ERR_UNSUPPORTED;    // feed the materialised tensor (vv_pool_act / vv_cube_erase) as VV_IN_PLAIN
   hipStream_t st = (hipStream_t)stream;
+  if (vv_wino_ring_ok(p)) return p->CinP == 16 ? launch_wino_ring<2>(p, st) : launch_wino_ring<4>(p, st);
   switch (p->H) {
     case 32: return launch_wino<32>(p, st);
     case 16: return launch_wino<16>(p, st);
