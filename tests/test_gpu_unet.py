@@ -895,7 +895,8 @@ def test_embedded_width_matches_oracle_eval_train_and_state(kind, nf, n):
         if k.endswith('num_batches_tracked'):
             assert int(v) == int(sd_o[k]) == 3          # load_state_dict reset the counter; three fused steps since
         elif k.endswith('running_mean') or k.endswith('running_var'):
-            assert torch.allclose(v.cpu(), sd_o[k], rtol=2e-3, atol=1e-5), k
+            # (three Adam steps of lr * sign(g) apart in a few round-off-decided weights: the bar of the golden test's final state)
+            assert torch.allclose(v.cpu(), sd_o[k], rtol=2e-2, atol=2e-3), k
     # the padding of the engine's tensors is still exactly zero (parameters, Adam moments, running statistics)
     bank = net.bank()
     mask = torch.ones_like(bank.params, dtype=torch.bool)
@@ -913,3 +914,51 @@ def test_embedded_width_matches_oracle_eval_train_and_state(kind, nf, n):
     rs, os_ = O.score_pass(sd_o, spec, x, x_of, n)
     np.testing.assert_allclose(r, rs, rtol=1e-3)
     np.testing.assert_allclose(o, os_, rtol=1e-3)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,mode,bnf,relu', [(64, 32, 32, 'act', False, False), (43, 32, 32, 'plain', True, False),
+                                                      (43, 16, 32, 'plain', False, False), (64, 16, 32, 'act', False, True),
+                                                      (37, 32, 64, 'plain', False, False), (64, 32, 64, 'act', True, False)])
+def test_wino_ring_bitwise_equal(B, Cin, Cout, mode, bnf, relu):
+    """vv_conv_wino's persistent LDS-DMA ring kernel (32x32 level, K <= 32: csrc/vv_wino.hip wino_ring_kernel) against the per-tile
+    kernel (VV_CONV_NO_RING) on the same tensors: output, BatchNorm partial sums and the fused BatchNorm-backward sums must agree
+    BIT FOR BIT (same chunk -> MFMA order, same epilogue arithmetic), including runs of tiles that cross a UNet / N-tile boundary
+    in the middle of a workgroup's run (B = 43 / 37: 5 tiles per workgroup) and the folded eval path's ReLU epilogue."""
+    import ctypes as C
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G, H = 6, 32
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device='cpu').manual_seed(B * 100 + Cin + Cout)
+    x = torch.randn(G, B * H * H, Cin, generator=g).cuda()
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    bias = torch.randn(G, Cout, generator=g).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    z = torch.randn(G, B * H * H, Cout, generator=g).cuda()
+    bn = [(torch.rand(G, Cout, generator=g) + 0.5).cuda() for _ in range(4)]
+    ent = (L.PackEntry * 1)(L.PackEntry(0, 0, 0, Cin, Cin, Cout))
+    tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()
+    pk = torch.zeros(G, 16 * Cin * Cout, device='cuda')
+    L.check(lib.vv_pack_wino(tab.data_ptr(), 1, G, w.data_ptr(), w[0].numel(), pk.data_ptr(), pk.stride(0), Cin * Cout, st), 'pack')
+    nt = lib.vv_wino_ntiles(B, H)
+    assert G * (Cout // 32) * nt >= 4 * 512                # enough tiles for the ring kernel to take the launch
+    outs = []
+    for flag in (0, L.CONV_NO_RING):
+        y = torch.full((G, B * H * H, Cout), float('nan'), device='cuda')
+        s_ = torch.full((G, nt, 2, Cout), float('nan'), device='cuda')
+        cp = L.ConvParams(L.CONV3, L.IN_ACT if mode == 'act' else L.IN_PLAIN, G, B, H, H, Cin, Cin, Cout, L.view(x, Cin, 0, x.stride(0)),
+                          a.data_ptr(), b.data_ptr(), Cin, L.NULL_VIEW, 0, flag | (L.CONV_RELU if relu else 0), None, pk.data_ptr(),
+                          pk.stride(0), bias.data_ptr(), Cout, L.view(y, Cout, 0, y.stride(0)), None if bnf else s_.data_ptr())
+        if bnf:
+            cp.bn_z, cp.bn_z_gstride = z.data_ptr(), z.stride(0)
+            cp.bn_a, cp.bn_b, cp.bn_mean, cp.bn_invstd = (t.data_ptr() for t in bn)
+            cp.bn_gstride, cp.bn_partial = Cout, s_.data_ptr()
+        L.check(lib.vv_conv_wino(C.byref(cp), st), 'conv')
+        torch.cuda.synchronize()
+        outs.append((y, s_))
+    assert not torch.isnan(outs[0][0]).any() and not torch.isnan(outs[0][1]).any()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    if relu:
+        assert float(outs[0][0].min()) == 0.0

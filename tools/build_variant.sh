@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$1; DEF=$2; OUT=$3
 mkdir -p $R/exp_libs /tmp/vvvar
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEF -I$R/include -c $R/vec_vad_amd/csrc/$SRC.hip -o /tmp/vvvar/$SRC.$$.o 2> /dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm $DEF -I$R/include -c $R/vec_vad_amd/csrc/$SRC.hip -o /tmp/vvvar/$SRC.$$.o 2> /dev/null
 OBJS=$(ls $R/vec_vad_amd/csrc/build/*.hip.o | grep -v "/$SRC.hip.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/$OUT $OBJS /tmp/vvvar/$SRC.$$.o
 rm -f /tmp/vvvar/$SRC.$$.o

@@ -21,6 +21,10 @@ LAYERS = [(32, 16, 32, 1, 'conv0'), (32, 32, 32, 4, 'conv1/13 dgrad1/13'), (32, 
           (4, 128, 256, 1, 'conv6'), (4, 256, 128, 1, 'dgrad6'), (4, 256, 256, 2, 'conv7 dgrad7')]
 
 
+if os.environ.get('UB_ONLY32') == '1':
+    LAYERS = [l for l in LAYERS if l[0] == 32 and l[1] <= 32]
+
+
 def pack(fn, w, K, N, taps):
     ent = (L.PackEntry * 1)(L.PackEntry(0, 0, 0, K, K, N))
     tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()

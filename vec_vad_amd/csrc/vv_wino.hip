@@ -32,6 +32,14 @@
 #ifndef VV_EXPM
 #define VV_EXPM 0
 #endif
+// VV_EXPR (bit mask, default 0): the same for wino_ring_kernel -- 1 no MFMAs, 2 no HBM reads (every DMA lane out of range), 4 no output
+// stores, 8 no epilogue, 16 no activation pass, 32 no chunk barriers, 64 no patch reads / input transform.  VV_RING_D: prefetch distance.
+#ifndef VV_EXPR
+#define VV_EXPR 0
+#endif
+#ifndef VV_RING_D
+#define VV_RING_D 4
+#endif
 namespace {
 
 constexpr int WN = 256;                // threads per workgroup: one wave per xi
@@ -390,7 +398,7 @@ template <int KQ, bool BNF>
 __global__ void __launch_bounds__(WN, 2)
 wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int ipw) {
   constexpr int H_ = 32, TPI = 16, PARTS = 8, HWH = 17;
-  constexpr int D = 4;                                     // prefetch distance in chunks (whole tiles: D % KQ == 0)
+  constexpr int D = VV_RING_D;                             // prefetch distance in chunks (whole tiles: D % KQ == 0)
   constexpr int E = D / KQ;                                // ... = tiles ahead
   constexpr int NBUF = D + 1;
   constexpr int CH4 = 512;                                 // float4 slots per ring buffer (408 used)
@@ -463,7 +471,7 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
                                             0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      voff[k] = (live && xok[k] && !(yflag[k] & ym)) ? (unsigned)(tileoff + rel[k]) : 0x80000000u;
+      voff[k] = (live && xok[k] && !(yflag[k] & ym) && !(VV_EXPR & 2)) ? (unsigned)(tileoff + rel[k]) : 0x80000000u;
   };
   int slotd = 0;               // ring slot the next DMA pair fills
   auto dma_chunk = [&](const int c) {
@@ -541,7 +549,7 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     for (int c = 0; c < KQ; ++c) {
       // ---- chunk c of this tile has landed (this wave's pieces); activate them in place; meet the other waves
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
-      if (act_mode) {
+      if (act_mode && !(VV_EXPR & 16)) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
           if (xok[k] && !(yflag[k] & ymc)) {
@@ -550,7 +558,9 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
             lds4[sl] = vv_act4(lds4[sl], a4, b4);
           }
       }
+#if !(VV_EXPR & 32)
       vv_lds_barrier();
+#endif
       // ---- every wave is past chunk j - 1: its slot takes chunk j + D (same chunk index, E tiles ahead)
       if (c == 0) dma_item();
       dma_chunk(c);
@@ -561,14 +571,31 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int o = (b & 1) * HWH + (b >> 1);
+#if (VV_EXPR & 64)
+        R[b] = v4f{sg, sg + b, sg, sg} + (float)rb;
+#else
         const v4f d1 = ldsA[rb + po1 + o], d2 = ldsA[rb + po2 + o];
         R[b] = d1 + sg * d2;
+#endif
       }
       v4f V[4];
       V[0] = R[0] - R[2];
       V[1] = R[1] + R[2];
       V[2] = R[2] - R[1];
       V[3] = R[1] - R[3];
+      // the four GEMMs' MFMAs interleaved (k step outermost): consecutive matrix instructions write DIFFERENT accumulators, each
+      // accumulator still sees its k steps in the order x, y, z, w (bit-identical to nu-major issue); nothing but MFMAs between
+      // the fences (a VALU between two MFMAs on one accumulator costs ~40 cycles, MI355X_MICROARCH.md)
+      __builtin_amdgcn_sched_barrier(0);
+#if (VV_EXPR & 1)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (c == 0)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+        acc[n][0] += V[n].x * u[c][n].x + V[n].y * u[c][n].y + V[n].z * u[c][n].z + V[n].w * u[c][n].w;
+      }
+#else
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         if (c == 0) {
@@ -577,13 +604,23 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         } else {
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[c][n].x, acc[n], 0, 0, 0);
         }
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[c][n].y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[c][n].z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[c][n].w, acc[n], 0, 0, 0);
       }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[c][n].y, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[c][n].z, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[c][n].w, acc[n], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
       slotc = slotc + 1 == NBUF ? 0 : slotc + 1;
     }
 
+#if (VV_EXPR & 8)
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.456f) sp[tid] = 1.f;
+    advance(gc, nc, ptc);
+    continue;
+#endif
     // ---- epilogue (wino_conv_kernel's, on its own LDS region: the ring keeps filling underneath)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -620,10 +657,15 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       ya[0] = ya[0] < lo ? lo : ya[0]; ya[1] = ya[1] < lo ? lo : ya[1];
       yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
       const int so = ((img * H_ + oy) * H_ + ox) * ocs * 4;
+#if (VV_EXPR & 4)
+      if (ya[0] + ya[1] + yb[0] + yb[1] == 123.456f)
+#endif
+      {
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[0]), rsO, vo, so, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[1]), rsO, vo, so + ocs * 4, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yb[0]), rsO, vo, so + H_ * ocs * 4, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yb[1]), rsO, vo, so + (H_ + 1) * ocs * 4, 0);
+      }
       if constexpr (BNF) {
         const v2f za = {zq[j][0], zq[j][1]}, zb = {zq[j][2], zq[j][3]};
         const v2f pa = bna * za + bnb, pb = bna * zb + bnb;
