@@ -33,12 +33,15 @@
 #define VV_EXPM 0
 #endif
 // VV_EXPR (bit mask, default 0): the same for wino_ring_kernel -- 1 no MFMAs, 2 no HBM reads (every DMA lane out of range), 4 no output
-// stores, 8 no epilogue, 16 no activation pass, 32 no chunk barriers, 64 no patch reads / input transform.  VV_RING_D: prefetch distance.
+// stores, 8 no epilogue, 16 no activation pass, 32 no chunk barriers.  VV_RING_D: prefetch distance.
 #ifndef VV_EXPR
 #define VV_EXPR 0
 #endif
 #ifndef VV_RING_D
 #define VV_RING_D 4
+#endif
+#ifndef VV_RING_MIN
+#define VV_RING_MIN (4 * 512)      // work items (tiles x N tiles x UNets) from which the ring kernel takes a launch: runs of >= 4 per workgroup
 #endif
 namespace {
 
@@ -394,7 +397,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 // the image is lane-linear as the DMA needs it (slot s = wave * 128 + k * 64 + lane; 408 of 512 slots used).
 // Same arithmetic in the same order as wino_conv_kernel<32> (chunk -> nu -> 4 MFMAs, same epilogue): bit-identical outputs and
 // BatchNorm partial sums (tests/test_gpu_unet.py::test_wino_ring_bitwise_equal).
-template <int KQ, bool BNF>
+template <int KQ, bool BNF, bool RELU>
 __global__ void __launch_bounds__(WN, 2)
 wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int ipw) {
   constexpr int H_ = 32, TPI = 16, PARTS = 8, HWH = 17;
@@ -406,8 +409,8 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr int NUSED = 2 * PLANE;                         // 408
   constexpr int EX4 = 4 * 16 * 64 / 2;                     // epilogue exchange [wave][16][64] float2
   constexpr int RING4 = NBUF * CH4;
-  constexpr int SP4 = RING4 + EX4;                         // [2][4][32] floats: BatchNorm partials of the four waves
-  constexpr int AB4 = SP4 + 64;                            // [2][KQ * 2] float4: a, b of the producing layer's BatchNorm
+  constexpr int SP4 = RING4 + EX4;                         // [2][4][64] floats: BatchNorm partials of the four waves' lanes
+  constexpr int AB4 = SP4 + 128;                           // [2][KQ * 2] float4: a, b of the producing layer's BatchNorm
   constexpr int STORES_MIN = 16;                           // VMEM instructions every wave issues in every epilogue, at least
   constexpr int VMW = 2 * (D - 1) + STORES_MIN * E;        // allowed outstanding when chunk j must have landed (see above)
   static_assert(D % KQ == 0 && VMW <= 63, "ring geometry");
@@ -505,16 +508,81 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   float bias = 0.f;
   float bna = 0.f, bnb = 0.f, bni = 0.f, bnm = 0.f;
   int g_have = -1, n_have = -1;
-  const float lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();
   const int ocs = p.out.cstride;
   constexpr int LP = 8;                                    // pixels between the two lane halves (tile + 4)
   const int bnu = KQ * 2 * Cout * 16;                      // bytes between nu slabs of the packed panel
   int slotc = 0;
   v2f* ex2 = reinterpret_cast<v2f*>(lds4 + RING4) + lane;
-  float* sp = lds + SP4 * 4;
+  float* sp = lds + SP4 * 4;                              // [sum | sum of squares][wave][64 lanes]
+  float* const sout = BNF ? p.bn_partial : p.stats;
+  bool pend = false;                                      // a tile's column sums wait in sp for their reduction
+  int64_t pend_off = 0;
+  auto flush_stats = [&]() {                              // wave w reduces and stores channels 8w .. 8w+7
+    if (lane < 8) {
+      const int ch = xi * 8 + lane;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t1 += sp[k * 64 + ch] + sp[k * 64 + 32 + ch];
+        t2 += sp[(4 + k) * 64 + ch] + sp[(4 + k) * 64 + 32 + ch];
+      }
+      float* st = sout + pend_off + ch;
+      st[0] = t1;
+      st[Cout] = t2;
+    }
+    pend = false;
+  };
+
+  // ---- the chunk pipeline.  A wave's own latencies (DMA issue, the wait for the next chunk, its activation, the barrier, the
+  //      patch reads) sit INSIDE the 16 MFMAs of the chunk before: k steps x, y | DMA issue for chunk j + D, wait for chunk j + 1,
+  //      activate this wave's pieces of it | k step z | barrier, patch reads of chunk j + 1 | k step w | input transform of chunk
+  //      j + 1 (VALU: it cannot run under fp32 MFMAs of the same SIMD, so it is not interleaved).  Profiled before this order
+  //      (s_memtime per phase, 32 -> 32): 14.6 k cycles per tile and wave, 3.9 k of them issuing MFMAs, the rest a serial chain
+  //      of those latencies.
+  auto land = [&](const int cn, const int ym, const int slot, const bool same_tile) {   // this wave's pieces of a chunk: landed, activated
+    // in-order counter: everything issued after the chunk's DMA pair may stay outstanding -- the D - 1 younger pairs and the
+    // stores of the epilogues in between (E of them; E - 1 when the chunk is the first of the NEXT tile, whose pair went out D
+    // chunks ago = after the last epilogue but E - 1)
+    if (same_tile)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW - STORES_MIN) : "memory");
+    if (act_mode && !(VV_EXPR & 16)) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (xok[k] && !(yflag[k] & ym)) {
+          const int sl = slot * CH4 + xi * 128 + k * 64 + lane;
+          const float4 a4 = lds4[AB4 + cn * 2 + qk[k]], b4 = lds4[AB4 + 2 * KQ + cn * 2 + qk[k]];
+          lds4[sl] = vv_act4(lds4[sl], a4, b4);
+        }
+    }
+  };
+  v4f P[8];
+  auto fetch = [&](const int slot) {
+    const int rb = slot * CH4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int o = (b & 1) * HWH + (b >> 1);
+      P[2 * b] = ldsA[rb + po1 + o];
+      P[2 * b + 1] = ldsA[rb + po2 + o];
+    }
+  };
+  v4f V[4];
+  auto transform = [&]() {
+    v4f R[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) R[b] = P[2 * b] + sg * P[2 * b + 1];
+    V[0] = R[0] - R[2];
+    V[1] = R[1] + R[2];
+    V[2] = R[2] - R[1];
+    V[3] = R[1] - R[3];
+  };
+  bool restart = true;         // the pipeline has no chunk in its registers: the first tile, and the first tile of another UNet
 
   for (int w = w_begin; w < w_end; ++w) {
     const int co0 = nc * 32;
+    const int img = ptc >> 3, part = ptc & 7;
+    const int ymc = (part == 0 ? 1 : 0) | (part == PARTS - 1 ? 2 : 0);
     if (gc != g_have || nc != n_have) {
       // ---- a new (UNet, N tile): filter taps -> registers, bias / BatchNorm scalars, activation table -> LDS.  Rare (a run of
       //      tiles shares them); these register loads drain the DMA ring once (in-order counter), the counted waits below stay valid
@@ -541,80 +609,71 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       vv_lds_barrier();                          //  vmcnt(0) in front of the first MFMA of EVERY tile and drains the ring there)
       g_have = gc; n_have = nc;
     }
-    const int img = ptc >> 3, part = ptc & 7;
-    const int ymc = (part == 0 ? 1 : 0) | (part == PARTS - 1 ? 2 : 0);
+    if (restart) {             // chunk 0 of this tile: landed (everything is: the tap loads above drained the counter), activated, read
+      land(0, ymc, slotc, false);
+      vv_lds_barrier();
+      fetch(slotc);
+      transform();
+      restart = false;
+    }
+    // the tile after this one (its first chunk is prepared under this tile's last MFMAs, with THIS UNet's activation table)
+    int gn = gc, nn_ = nc, ptn = ptc;
+    advance(gn, nn_, ptn);
+    const bool cross = gn != gc;                 // ... unless it belongs to another UNet: then the pipeline restarts there
+    const int ymn = ((ptn & 7) == 0 ? 1 : 0) | ((ptn & 7) == PARTS - 1 ? 2 : 0);
 
     v16f acc[4];
 #pragma unroll
     for (int c = 0; c < KQ; ++c) {
-      // ---- chunk c of this tile has landed (this wave's pieces); activate them in place; meet the other waves
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
-      if (act_mode && !(VV_EXPR & 16)) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if (xok[k] && !(yflag[k] & ymc)) {
-            const int sl = slotc * CH4 + xi * 128 + k * 64 + lane;
-            const float4 a4 = lds4[AB4 + c * 2 + qk[k]], b4 = lds4[AB4 + 2 * KQ + c * 2 + qk[k]];
-            lds4[sl] = vv_act4(lds4[sl], a4, b4);
-          }
-      }
-#if !(VV_EXPR & 32)
-      vv_lds_barrier();
-#endif
-      // ---- every wave is past chunk j - 1: its slot takes chunk j + D (same chunk index, E tiles ahead)
-      if (c == 0) dma_item();
-      dma_chunk(c);
-      if (c == KQ - 1) { advance(gd, nd, ptd); ++wd; }
-      // ---- V = B^T d B for this wave's xi, 16 MFMAs
-      const int rb = slotc * CH4;
-      v4f R[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int o = (b & 1) * HWH + (b >> 1);
-#if (VV_EXPR & 64)
-        R[b] = v4f{sg, sg + b, sg, sg} + (float)rb;
-#else
-        const v4f d1 = ldsA[rb + po1 + o], d2 = ldsA[rb + po2 + o];
-        R[b] = d1 + sg * d2;
-#endif
-      }
-      v4f V[4];
-      V[0] = R[0] - R[2];
-      V[1] = R[1] + R[2];
-      V[2] = R[2] - R[1];
-      V[3] = R[1] - R[3];
-      // the four GEMMs' MFMAs interleaved (k step outermost): consecutive matrix instructions write DIFFERENT accumulators, each
-      // accumulator still sees its k steps in the order x, y, z, w (bit-identical to nu-major issue); nothing but MFMAs between
-      // the fences (a VALU between two MFMAs on one accumulator costs ~40 cycles, MI355X_MICROARCH.md)
-      __builtin_amdgcn_sched_barrier(0);
+      const bool last = c == KQ - 1;
+      const int slotn = slotc + 1 == NBUF ? 0 : slotc + 1;
+      auto mfma_k = [&](const int k) {
 #if (VV_EXPR & 1)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        if (c == 0)
+        for (int n = 0; n < 4; ++n) {
+          if (c == 0 && k == 0)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-        acc[n][0] += V[n].x * u[c][n].x + V[n].y * u[c][n].y + V[n].z * u[c][n].z + V[n].w * u[c][n].w;
-      }
+            for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+          acc[n][0] += V[n][k] * u[c][n][k];
+        }
 #else
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        if (c == 0) {
-          const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[c][n].x, z, 0, 0, 0);
-        } else {
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[c][n].x, acc[n], 0, 0, 0);
+        for (int n = 0; n < 4; ++n) {
+          if (c == 0 && k == 0) {
+            const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n][k], u[c][n][k], z, 0, 0, 0);
+          } else {
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n][k], u[c][n][k], acc[n], 0, 0, 0);
+          }
         }
-      }
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[c][n].y, acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[c][n].z, acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[c][n].w, acc[n], 0, 0, 0);
 #endif
+      };
+      // (the four GEMMs' MFMAs interleaved, k step outermost: consecutive matrix instructions write DIFFERENT accumulators, each
+      //  accumulator sees its k steps in the order x, y, z, w -- bit-identical to the per-tile kernel's nu-major issue)
       __builtin_amdgcn_sched_barrier(0);
-      slotc = slotc + 1 == NBUF ? 0 : slotc + 1;
+      mfma_k(0);
+      mfma_k(1);
+      __builtin_amdgcn_sched_barrier(0);
+      // every wave is past the barrier of chunk j: the slot of chunk j - 1 takes chunk j + D (same chunk index, E tiles ahead)
+      if (c == 0) dma_item();
+      dma_chunk(c);
+      if (last) { advance(gd, nd, ptd); ++wd; }
+      if (!(last && cross)) land(last ? 0 : c + 1, last ? ymn : ymc, slotn, !last);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_k(2);
+      __builtin_amdgcn_sched_barrier(0);
+#if !(VV_EXPR & 32)
+      vv_lds_barrier();                          // chunk j + 1 is complete in LDS; the column sums of the tile before are too
+#endif
+      if (c == 0 && pend) flush_stats();
+      if (!(last && cross)) fetch(slotn);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_k(3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(last && cross)) transform();
+      slotc = slotn;
     }
+    if (cross) restart = true;
 
 #if (VV_EXPR & 8)
     if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.456f) sp[tid] = 1.f;
@@ -654,8 +713,10 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const int oy = 2 * (part * 2 + t2 / TPI), ox = 2 * (t2 % TPI);
       const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
       v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
-      ya[0] = ya[0] < lo ? lo : ya[0]; ya[1] = ya[1] < lo ? lo : ya[1];
-      yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
+      if constexpr (RELU) {        // VV_CONV_RELU (folded eval model); compare + select so that a NaN stays a NaN, like torch's ReLU
+        ya[0] = ya[0] < 0.f ? 0.f : ya[0]; ya[1] = ya[1] < 0.f ? 0.f : ya[1];
+        yb[0] = yb[0] < 0.f ? 0.f : yb[0]; yb[1] = yb[1] < 0.f ? 0.f : yb[1];
+      }
       const int so = ((img * H_ + oy) * H_ + ox) * ocs * 4;
 #if (VV_EXPR & 4)
       if (ya[0] + ya[1] + yb[0] + yb[1] == 123.456f)
@@ -679,29 +740,20 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         q12 = __builtin_elementwise_fma(yb, yb, q12);
       }
     }
-    float* const sout = BNF ? p.bn_partial : p.stats;
     if (sout) {
-      float s1 = s12.x + s12.y, s2 = q12.x + q12.y;
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (half == 0) {
-        sp[xi * 32 + l31] = s1;
-        sp[(4 + xi) * 32 + l31] = s2;
-      }
-      vv_lds_barrier();
-      if (tid < 32) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          t1 += sp[k * 32 + tid];
-          t2 += sp[(4 + k) * 32 + tid];
-        }
-        float* st = sout + ((int64_t)(gc * NT + ptc) * 2) * Cout + co0 + tid;
-        st[0] = t1;
-        st[Cout] = t2;
-      }
+      // this lane's column sums go to LDS as they are; the sum over the two lane halves and the four waves (in the per-tile
+      // kernel's order: (half 0 + half 1) per wave, then waves 0..3) and the store happen behind the NEXT tile's first chunk
+      // barrier, which proves that every wave has written them -- no barrier of its own, no cross-half shuffles
+      sp[xi * 64 + lane] = s12.x + s12.y;
+      sp[(4 + xi) * 64 + lane] = q12.x + q12.y;
+      pend_off = ((int64_t)(gc * NT + ptc) * 2) * Cout + co0;
+      pend = true;
     }
     advance(gc, nc, ptc);
+  }
+  if (pend) {
+    vv_lds_barrier();
+    flush_stats();
   }
   // the tail's dummy DMAs write zeros into ring slots: they must have landed before this workgroup's LDS is handed on
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -771,10 +823,12 @@ int launch_wino_ring(const vv_conv_params* p, hipStream_t st) {
   const int slots = 2 * 256;
   const int ipw = (total + slots - 1) / slots;
   const int nwg = (total + ipw - 1) / ipw;
-  if (p->bn_partial)
-    VV_LAUNCH((wino_ring_kernel<KQ, true>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
+  if (p->bn_partial)          // (data-gradient launches: never with the eval path's ReLU)
+    VV_LAUNCH((wino_ring_kernel<KQ, true, false>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
+  else if (p->pad0 & VV_CONV_RELU)
+    VV_LAUNCH((wino_ring_kernel<KQ, false, true>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
   else
-    VV_LAUNCH((wino_ring_kernel<KQ, false>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
+    VV_LAUNCH((wino_ring_kernel<KQ, false, false>), dim3(nwg), dim3(WN), 0, st, *p, NT, NN, total, ipw);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
@@ -783,7 +837,8 @@ int launch_wino_ring(const vv_conv_params* p, hipStream_t st) {
 inline bool vv_wino_ring_ok(const vv_conv_params* p) {
   if (p->H != 32 || (p->CinP != 16 && p->CinP != 32) || (p->pad0 & VV_CONV_NO_RING)) return false;
   if (p->in_mode != VV_IN_PLAIN && p->in_mode != VV_IN_ACT) return false;
-  return (int64_t)p->G * (p->Cout / 32) * p->B * 8 >= 4 * 512;
+  if (p->bn_partial && (p->pad0 & VV_CONV_RELU)) return false;
+  return (int64_t)p->G * (p->Cout / 32) * p->B * 8 >= VV_RING_MIN;
 }
 
 template <int H_>
