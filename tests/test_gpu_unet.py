@@ -962,3 +962,29 @@ def test_wino_ring_bitwise_equal(B, Cin, Cout, mode, bnf, relu):
     assert torch.equal(outs[0][1], outs[1][1])
     if relu:
         assert float(outs[0][0].min()) == 0.0
+
+
+@pytest.mark.parametrize('precision,kind,nf,B', [('fp32', 'net4', 32, 5), ('fp32', '1raw1of', 64, 3), ('bf16', 'full', 32, 3)])
+def test_grouped_slab_reduction_bitwise_equal_to_per_layer_kernel(monkeypatch, precision, kind, nf, B):
+    """vv_wgrad_reduce_grouped (round 5: one workgroup per 32 x 32 filter tile, nine taps transposed through LDS, full-line stores)
+    against the per-layer, one-element-per-thread vv_wgrad_reduce (VV_GROUP_REDUCE=0): the same slabs summed in the same order --
+    every weight gradient of the bank (3x3 convs incl. the 12-channel first layer, transposed convs) keeps its bits."""
+    monkeypatch.setenv('VV_PRECISION', precision)
+    from oracle import unet_oracle as O
+    res = []
+    for grouped in ('1', '0'):
+        monkeypatch.setenv('VV_GROUP_REDUCE', grouped)
+        net, sd, tot_of = _build(kind, False, nf=nf)
+        net.train()
+        bank = net.bank()
+        raw, flow = O.seeded_cubes(B, tot_of, 7)
+        ws = bank.set_input_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), torch.arange(B, device='cuda'))
+        bank.forward(ws, True, outputs=False)
+        bank.backward(ws)
+        labels = [c[2] for c in bank.backward_plan(ws, fused=bank.fuse_outconv).calls]
+        assert any(l.startswith('wgradT_reduce0') for l in labels)
+        assert (sum(1 for l in labels if 'reduce' in l and l.startswith('wgrad')) <= 3) == (grouped == '1')
+        torch.cuda.synchronize()
+        res.append(bank.grads.clone())
+    assert torch.equal(res[0], res[1])
+    assert float(res[0].abs().max()) > 0

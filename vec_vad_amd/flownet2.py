@@ -123,7 +123,8 @@ class _Runner:
     def __init__(self):
         self.lib = L.lib()
         self.cache = {}
-        self.hook = None        # hook(label, e0, e1): HIP events around every conv launch (bench diagnostics, eager mode only)
+        self.hook = None        # hook(label, flop, e0, e1): HIP events around every conv launch (bench diagnostics, eager mode only)
+        self.last_wino = False
 
     def _packed(self, m):
         key = id(m)
@@ -202,6 +203,7 @@ class _Runner:
         bias = m.bias.data_ptr() if m.bias is not None else None
         L.check(self.lib.vv_conv2d_wino(src.t.data_ptr(), src.cs, 0, src.t.numel(), ent[1].data_ptr(), bias, slope, dst.t.data_ptr(),
                                         dst.cs, dst_coff, src.B, src.H, src.W, ent[2], m.out_channels, stream), 'conv2d_wino')
+        self.last_wino = True           # (bench diagnostics: this launch executed 16/36 of the direct form's multiply-adds)
         return True
 
     def _rowk(self, m, src, dst, dst_coff, slope, stream):
@@ -247,10 +249,11 @@ class _Runner:
         oh, ow = dst.H, dst.W
         flop = 2.0 * src.B * (src.H * src.W if de else oh * ow) * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.last_wino = False
         e0.record()
         r = self._launch(layer, src, dst, dst_coff)
         e1.record()
-        self.hook(label, flop, e0, e1)
+        self.hook(label + ('_wino' if self.last_wino else ''), flop, e0, e1)
         return r
 
     def _launch(self, layer, src, dst, dst_coff=0):
