@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 FLOP = {'net4': (1855520768, 5524094976), 'full': (3092316160, 9206169600)}      # (forward, train step) per cube, SURVEY 8(d)
 FP32_MFMA_PEAK = 157.3e12       # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 BF16_MFMA_PEAK = 2.5e15         # v_mfma_f32_32x32x16_bf16, dense
+BF16_MFMA_CALIBRATED = 1.57e15  # the same instruction in a loop with the conv kernel's operand traffic, measured (profiles/r04_gemm16_loop_calibration.txt)
 HBM_PEAK = 8.0e12               # HBM3E, MI355X_MICROARCH.md
 WINO_EXEC = 16.0 / 36.0         # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
 FLOWNET2_GFLOP = 464.2          # per 1024x448 pair, SURVEY appendix A.2
@@ -255,7 +256,10 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
                        'conv_mfma_kernel<..., BF=true> (32x32 level): 3x3 conv forward + data-gradient, bf16 operands on '
                        'v_mfma_f32_32x32x16_bf16, fp32 accumulation; achieved = algorithmic bytes (input once + output once, bf16 tensors) / time',
              'achieved': b_alg / t / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b_alg / t / HBM_PEAK,
-             'mfma_tflops': f_alg / t / 1e12, 'frac_of_bf16_mfma_peak': f_alg / t / BF16_MFMA_PEAK}
+             'mfma_tflops': f_alg / t / 1e12, 'frac_of_bf16_mfma_peak': f_alg / t / BF16_MFMA_PEAK,
+             # what a loop of nothing but v_mfma_f32_32x32x16_bf16 with this kernel's operand traffic sustains on this chip
+             # (profiles/r04_gemm16_loop_calibration.txt: 1.55 - 1.57 PFLOP/s; the chip clocks down under dense bf16 MFMA)
+             'frac_of_calibrated_bf16': f_alg / t / BF16_MFMA_CALIBRATED, 'calibrated_bf16_tflops': BF16_MFMA_CALIBRATED / 1e12}
     r.update(common)
     return r
 
@@ -272,8 +276,11 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     --breakdown / a side-stream schedule: every timed step is eager with events (the round-2 behaviour)."""
     from vec_vad_amd.trainer import FusedTrainer
     net, tot_of = build_net(model, precision, dev)
+    # VV_FORCE_DIST=1 (a one-rank group under torch.distributed.run --nproc-per-node 1): the bucketed exchange runs anyway -- the
+    # command line, backend init, hipGraph segments and in-place collectives of the N > 1 run, on one GPU
     trainer = FusedTrainer(net, lr=1e-3, eps=1e-7, process_group=dist.group.WORLD if dist is not None else None,
-                           overlap={'none': False, 'free': True, 'paired': 'paired'}[overlap])
+                           overlap={'none': False, 'free': True, 'paired': 'paired'}[overlap],
+                           always_bucket=dist is not None and world == 1)
     bank = trainer.bank
     graph = bool(graph and trainer.use_graph and overlap == 'none' and not breakdown)
     trainer.use_graph = graph
@@ -617,10 +624,14 @@ def main():
     torch.cuda.set_device(local_rank_dev)
     dev = torch.device('cuda', local_rank_dev)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('VV_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('VV_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' only for single-GPU bring-up tests
+        if world == 1:                     # VV_FORCE_DIST without a launcher: a one-rank rendezvous of its own
+            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:

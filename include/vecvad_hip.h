@@ -323,6 +323,9 @@ int vv_adam(int64_t n, float* param, const float* grad, float* m, float* v, floa
  *                     that each data-parallel all-reduce (train.py:375) runs in place on one contiguous range.  bounds: HOST array
  *                     of nb+1 multiples of 4, bounds[0] = 0, bounds[nb] = U, nb <= 8. */
 int vv_adam_tick(int64_t* t_dev, float lr, double beta1, double beta2, float* sc_dev, vv_stream stream);
+/* counters[0..n) += inc on the device: BatchNorm2d's num_batches_tracked of a train-mode forward (model/unet.py:11,14 through
+ * torch.nn.BatchNorm2d) -- a first-party launch, so that a captured train step holds no framework kernel */
+int vv_counter_add(int64_t* counters, int32_t n, int64_t inc, vv_stream stream);
 int vv_adam_bucketed(int32_t G, int64_t U, int32_t nb, const int64_t* bounds, float* param, const float* grad, float* m,
                      float* v, const float* sc_dev, float beta1, float beta2, float eps, float grad_scale, vv_stream stream);
 

@@ -369,3 +369,32 @@ def test_bench_eight_ranks_on_one_gpu_dataparallel_split():
     assert abs(d['value'] - 32 * 4 / (d['ms_per_step'] * 4e-3)) <= 1e-6 * d['value']
     assert '4 segment' in d['execution']['mode'], d['execution']
     assert np.isfinite(d['config']['loss_raw'])
+
+
+def test_bench_under_the_drivers_launcher_on_rccl_world1():
+    """First-SCALE-run hardening: the EXACT command line the driver uses at N = 8 -- python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ... -- at N = 1 with
+    VV_FORCE_DIST=1, so that it runs on the real `nccl` (= RCCL) backend on this one-GPU box: init_process_group('nccl', device_id=),
+    the step captured in four hipGraph segments with the three in-place bucket all-reduces between them (a sum over one rank is the
+    identity), max-over-ranks timing through dist.all_reduce / all_gather on device tensors, the `comm` record, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VV_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('VV_DIST_BACKEND', None)
+    env.pop('VV_SINGLE_DEVICE', None)
+    port = 33900 + (os.getpid() % 1000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '3', '--batch', '32',
+           '--pool', '128', '--no-cpu-baseline', '--no-secondary']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['config']['global_batch'] == 32
+    assert d['comm']['ranks'] == 1 and d['comm']['backend'] == 'nccl' and len(d['comm']['buckets']) == 3
+    assert '4 segment' in d['execution']['mode'], d['execution']
+    assert np.isfinite(d['config']['loss_raw']) and d['value'] > 0
+    assert abs(d['value'] - 32 * 6 / (d['ms_per_step'] * 6e-3)) <= 1e-6 * d['value']

@@ -133,6 +133,7 @@ _SIGS = {
     'vv_bias_from_partials': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'vv_adam': (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     'vv_adam_tick': (c_i32, [c_vp, c_f32, c_f64, c_f64, c_vp, c_vp]),
+    'vv_counter_add': (c_i32, [c_vp, c_i32, c_i64, c_vp]),
     'vv_adam_bucketed': (c_i32, [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
     'vv_cube_gather': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vv_pool_act': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),

@@ -950,9 +950,19 @@ class UNetBank:
         if train:
             ws.fused_fwd = bool(getattr(plan, 'fused_outconv', False))
         if train:
-            self.nbt[self.g0:self.g0 + self.Ga] += 1
+            self.bump_nbt()
             self.mark_dirty()
         return ws.score
+
+    def nbt_call(self):
+        """(fn, args, label) of the launch that advances BatchNorm's num_batches_tracked of the active UNets (first party: a captured
+        train step then holds no framework kernel)."""
+        n = len(self.lay.convs)
+        return (self.lib.vv_counter_add, (self.nbt.data_ptr() + 8 * self.g0 * n, self.Ga * n, 1), 'nbt')
+
+    def bump_nbt(self):
+        fn, args, label = self.nbt_call()
+        L.check(fn(*args, self._stream()), label)
 
     def backward(self, ws, fused=None):
         """Gradients of everything wrt ws.dout4 into self.grads (conv biases in front of BatchNorm get exact zeros).

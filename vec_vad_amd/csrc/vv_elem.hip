@@ -1515,6 +1515,20 @@ extern "C" int vv_adam(int64_t n, float* param, const float* grad, float* m, flo
   return VV_OK;
 }
 
+namespace {
+__global__ void counter_add_kernel(int64_t* __restrict__ p, const int n, const int64_t inc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += inc;
+}
+}  // namespace
+
+extern "C" int vv_counter_add(int64_t* counters, int32_t n, int64_t inc, vv_stream stream) {
+  if (!counters || n <= 0) return VV_ERR_BAD_ARG;
+  VV_LAUNCH(counter_add_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, counters, n, inc);
+  VV_CHECK_LAUNCH();
+  return VV_OK;
+}
+
 extern "C" int vv_adam_tick(int64_t* t_dev, float lr, double beta1, double beta2, float* sc_dev, vv_stream stream) {
   if (!t_dev || !sc_dev) return VV_ERR_BAD_ARG;
   VV_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_dev, lr, beta1, beta2, sc_dev);

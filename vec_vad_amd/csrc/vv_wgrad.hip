@@ -514,68 +514,36 @@ wgrad_reduce_kernel(const int kind, const int Cin, const int Cout, const int NCO
 }
 
 // The same reduction for SEVERAL layers in one launch (all weight gradients of a gradient bucket: up to 13 launches of 8-20 us
-// become one): blockIdx.x runs over the concatenated tile lists of the table's entries (entry e owns tiles [block_start / 36,
-// block_start / 36 + tiles), four workgroups per tile).
-// Round 5: one workgroup per (8 ci x 32 co) quarter of a filter tile with all nine taps, transposed through LDS.  The round-3 form
-// gave every thread ONE output element: a wave's 64 stores went to 64 different cache lines of the OIHW gradient (neighbouring co
-// are Cin * 36 bytes apart), 4 useful bytes per line -- the launches ran at ~2 TB/s of slab reads and were as long at 32 cubes as
-// at 256.  Here a thread sums nine elements (one per tap, all their slab loads in flight at once; same per-element order as before
-// -- four interleaved partial sums over the slabs, (s0 + s1) + (s2 + s3): bit-identical), the sums meet in LDS and leave in the
-// gradient's own order: runs of 72 consecutive floats per output channel (3x3 conv, OIHW) or one run of 2304 (transposed conv,
-// IOHW).  LDS image: 3x3 conv [tap][ci][co] with strides 353 / 41 / 1 floats (353 = 1, 41 = 9 mod 32: element f = (ci, tap) of a
-// fixed co is read from bank (f + co) mod 32, conflict-free; written with co along the lanes); transposed conv: the output order
-// itself (co along the lanes = stride 9, conflict-free).
+// become one): blockIdx.x runs over the concatenated block lists of the table's entries.
 __global__ void __launch_bounds__(VV_WG)
 wgrad_reduce_grouped_kernel(const vv_reduce_entry* __restrict__ table, const int n, const float* __restrict__ partial,
                             const int64_t partial_gstride, float* __restrict__ grads) {
-  constexpr int TS = 353, RS = 41;
-  __shared__ float red[9 * TS];
-  const int tb = blockIdx.x >> 2, quarter = blockIdx.x & 3;
   int e = 0;
-  for (int i = 1; i < n; ++i) e = tb >= table[i].block_start / 36 ? i : e;      // entries are sorted by block_start
+  for (int i = 1; i < n; ++i) e = (int)blockIdx.x >= table[i].block_start ? i : e;      // entries are sorted by block_start
   const vv_reduce_entry t = table[e];
-  const int tile = tb - t.block_start / 36;
+  const int bx = blockIdx.x - t.block_start;
+  const int quarter = bx & 3;
+  const int tap = (bx >> 2) % 9;
+  const int tile = (bx >> 2) / 9;
   const int g = blockIdx.y;
   const int cit = tile / t.NCO, cot = tile % t.NCO;
-  const int tid = threadIdx.x;
-  const int ci_l = tid >> 5, co_l = tid & 31;              // this thread's element of every tap (ci inside the quarter)
-  const bool conv3 = t.kind == VV_CONV3;
-  const int nslab = t.nslab;
-  const float* src = partial + (int64_t)g * partial_gstride + t.part_off + (int64_t)tile * nslab * (9 * 1024) + quarter * 256 + tid;
-  float s[9][4];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[tap][j] = 0.f;
+  const int el = quarter * VV_WG + threadIdx.x;
+  const float* src = partial + (int64_t)g * partial_gstride + t.part_off + (int64_t)tile * t.nslab * (9 * 1024) + tap * 1024 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = 0;
-  for (; k + 4 <= nslab; k += 4)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[tap][j] += src[(int64_t)(k + j) * (9 * 1024) + tap * 1024];
-  for (; k < nslab; ++k)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) s[tap][0] += src[(int64_t)k * (9 * 1024) + tap * 1024];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-    red[conv3 ? tap * TS + ci_l * RS + co_l : ci_l * 288 + co_l * 9 + tap] = (s[tap][0] + s[tap][1]) + (s[tap][2] + s[tap][3]);
-  __syncthreads();
+  for (; k + 4 <= t.nslab; k += 4) {
+    s0 += src[(int64_t)(k + 0) * (9 * 1024)];
+    s1 += src[(int64_t)(k + 1) * (9 * 1024)];
+    s2 += src[(int64_t)(k + 2) * (9 * 1024)];
+    s3 += src[(int64_t)(k + 3) * (9 * 1024)];
+  }
+  for (; k < t.nslab; ++k) s0 += src[(int64_t)k * (9 * 1024)];
+  const float s = (s0 + s1) + (s2 + s3);
   float* dst = grads + t.grad_off + (int64_t)g * t.grad_gstride;
-  const int ci0 = cit * 32 + quarter * 8, co0 = cot * 32;
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int f = r * VV_WG + tid;                         // 0 .. 2303
-    if (conv3) {                                           // f = (co, ci, tap): 72 consecutive floats per output channel
-      const int o_l = f / 72, rem = f - o_l * 72;
-      const int i_l = rem / 9, tap = rem - i_l * 9;
-      const int co = co0 + o_l, ci = ci0 + i_l;
-      if (ci < t.Cin && co < t.Cout) dst[((int64_t)co * t.Cin + ci) * 9 + tap] = red[tap * TS + i_l * RS + o_l];
-    } else {                                               // f = (ci, co, tap): 288 consecutive floats per input channel
-      const int i_l = f / 288, rem = f - i_l * 288;
-      const int o_l = rem / 9, tap = rem - o_l * 9;
-      const int ci = ci0 + i_l, co = co0 + o_l;
-      if (ci < t.Cin && co < t.Cout) dst[((int64_t)ci * t.Cout + co) * 9 + tap] = red[f];
-    }
+  const int ci = cit * 32 + (el >> 5), co = cot * 32 + (el & 31);
+  if (ci < t.Cin && co < t.Cout) {
+    if (t.kind == VV_CONV3) dst[((int64_t)co * t.Cin + ci) * 9 + tap] = s;
+    else dst[((int64_t)ci * t.Cout + co) * 9 + tap] = s;
   }
 }
 
@@ -673,8 +641,7 @@ extern "C" int vv_wgrad_reduce(int32_t kind, int32_t G, int32_t Cin, int32_t Cin
 extern "C" int vv_wgrad_reduce_grouped(const vv_reduce_entry* table_dev, int32_t nentries, int32_t total_blocks, int32_t G,
                                        const float* partial, int64_t partial_gstride, float* grads, vv_stream stream) {
   if (!table_dev || !partial || !grads || nentries <= 0 || total_blocks <= 0) return VV_ERR_BAD_ARG;
-  if (total_blocks % 36) return VV_ERR_BAD_ARG;                      // 36 block units per (32 ci x 32 co) tile (the table's block_start)
-  VV_LAUNCH(wgrad_reduce_grouped_kernel, dim3(total_blocks / 9, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, nentries, partial,
+  VV_LAUNCH(wgrad_reduce_grouped_kernel, dim3(total_blocks, G), dim3(VV_WG), 0, (hipStream_t)stream, table_dev, nentries, partial,
             partial_gstride, grads);
   VV_CHECK_LAUNCH();
   return VV_OK;

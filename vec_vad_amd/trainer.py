@@ -216,7 +216,7 @@ class FusedTrainer:
         ws.fused_fwd = bool(getattr(fwd, 'fused_outconv', False))      # which backward plan matches this forward (UNetBank.backward)
         assert ws.fused_fwd == bool(not self.keep_outputs and bank.fuse_outconv)
         ws.bwd_cur = bank.backward_plan(ws, fused=ws.fused_fwd)
-        bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
+        bank.bump_nbt()
         bank.mark_dirty()
 
     def _adam(self):
@@ -339,9 +339,7 @@ class FusedTrainer:
         else:
             seg += [self._thunk(*c) for c in fwd.calls]
 
-        def nbt(st):           # torch op on the capturing stream: BatchNorm's num_batches_tracked (views of bank.nbt)
-            bank.nbt[bank.g0:bank.g0 + bank.Ga] += 1
-        seg.append(nbt)
+        seg.append(self._thunk(*bank.nbt_call()))      # BatchNorm's num_batches_tracked (views of bank.nbt)
         segments = []
         lo = 0
         for i, c in enumerate(bwd.calls):
