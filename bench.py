@@ -90,7 +90,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed.  This is a
     number read from profiles/, not something this run measured (PMC collection needs rocprofv3 around the process)."""
-    for n in (name, name.replace('r04_', 'r03_'), name.replace('r04_', 'r02_'), name.replace('r04_', 'r01_')):
+    for n in (name, name.replace('r05_', 'r04_'), name.replace('r05_', 'r03_'), name.replace('r05_', 'r02_'), name.replace('r05_', 'r01_')):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             _STEP_BYTES[name] = d.get('hbm_bytes_per_train_step')
@@ -240,7 +240,8 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
               'timed_on': 'one stream (eager event steps)' if overlap == 'none' else 'eager two-stream executor (%s)' % overlap}
     if precision == 'fp32':
         r = {'bound': 'mfma',
-             'kernel': ('wino_conv_kernel<H>: 3x3 conv forward + data-gradient as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32'
+             'kernel': ('wino_conv_kernel<H> + wino_ring_kernel<KQ> (32x32 level, K <= 32: persistent, LDS-DMA ring): 3x3 conv forward + '
+                        'data-gradient as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32'
                         if bank.wino else 'conv_mfma_kernel: 3x3 implicit GEMM on v_mfma_f32_32x32x2_f32, forward + data-gradient'),
              'achieved': f_exe / t / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': f_exe / t / FP32_MFMA_PEAK,
              'accounting': 'achieved / frac = multiply-adds the matrix cores execute (x16/36 of the direct convolution for the '
@@ -390,9 +391,9 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     # the committed PMC passes: default workload (net4, B=256) and BASELINE config 4 (full, B=512, bf16)
     pname = None
     if model == 'net4' and B == 256:
-        pname = 'r04_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')
+        pname = 'r05_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')
     elif model == 'full' and B == 512 and precision == 'bf16':
-        pname = 'r04_pmc_hbm_traffic_bf16_full_b512.json'
+        pname = 'r05_pmc_hbm_traffic_bf16_full_b512.json'
     traffic = pmc_traffic(pname) if pname else (None, None)
     rec = {'value': value, 'unit': 'cubes/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
            'dtype': 'f32' if precision == 'fp32' else 'bf16 operands, f32 accumulate',
@@ -499,7 +500,7 @@ def run_scoring(dev, B=512, n=8192, reps=3):
 
 
 def _fn2_traffic():
-    for n in ('r04_pmc_hbm_traffic_flownet2.json', 'r03_pmc_hbm_traffic_flownet2.json'):
+    for n in ('r05_pmc_hbm_traffic_flownet2.json', 'r04_pmc_hbm_traffic_flownet2.json', 'r03_pmc_hbm_traffic_flownet2.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             return d['total_hbm_bytes_per_run_corrected'], _profile_tag(n, d)
