@@ -455,7 +455,10 @@ class UNetBank:
         HWp = HW0 * HW0
         ws.gA_last = f(Ga, B * HWp, self.nf)
         nblk = [lib.vv_bn_bwd_nblk(B, l.H, l.H, l.cout) for l in lay.convs]
-        ws.bnpart = f(Ga, max(max(n, lib.vv_wino_ntiles(B, l.H)) * 2 * l.cout for n, l in zip(nblk, lay.convs)))
+        # rows: BatchNorm-backward blocks, or the pixel tiles of whichever conv kernel leaves the fused sums (Winograd tiles in fp32,
+        # vv_conv_mfma's tiles for the bf16 32x32 launches: VV_BNBWD_PARTIALS_PER_TILE / _PER_CTILE) -- sized for all of them explicitly
+        ws.bnpart = f(Ga, max(max(n, lib.vv_wino_ntiles(B, l.H), lib.vv_conv_ntiles(B, l.H, l.H),
+                                  lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag)) * 2 * l.cout for n, l in zip(nblk, lay.convs)))
         ws.ocpart = f(Ga, B, 4 * self.nf + 4)
 
     def backward_plan(self, ws, fused):

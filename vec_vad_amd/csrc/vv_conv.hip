@@ -560,9 +560,6 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   const int sm = !bf ? 0 : ((p->pad0 & VV_CONV_ALLSRC_BF16) ? 2 : ((p->pad0 & VV_CONV_SRC_BF16) ? 1 : 0));
   // all-bf16 3x3 launches: the persistent GEMM-shaped kernel on the 16x16 / 8x8 / 4x4 levels; at 32x32 (HBM-bound, 1 - 2 chunks per
   // tile) it measured slower than this file's kernel, which has the same 256-pixel tiles there (vv_conv_ntiles2 is unaffected)
-  #ifdef VV_G16_32
-  if (vv_gemm16_flags(p->kind, p->pad0)) return vv_conv_gemm16(p, st);
-#endif
   if (vv_gemm16_flags(p->kind, p->pad0) && p->H <= 16) return vv_conv_gemm16(p, st);
   switch (p->kind) {
     case VV_CONV3:

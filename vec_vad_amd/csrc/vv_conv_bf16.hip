@@ -259,7 +259,9 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   auto xoff = [&](const int ch) -> int { return (TN > osplit && ch >= osplit) ? o1d - osplit * 2 : 0; };
   auto tile_xoff = [&](const int nn) -> int { return (TN <= osplit && nn * TN >= osplit) ? o1d - osplit * 2 : 0; };
   float* const pstats = p.stats;
-  float* const pdbg = p.bn_partial;
+#if (VV_EXPG & 512)
+  float* const pdbg = p.bn_partial;                                    // per-role cycle counters of a PROFILING build only (bench scripts pass a scratch tensor)
+#endif
   constexpr int TPI = TW / TH;                                         // tiles per image: H == W == TW on every level (vv_conv_gemm16)
   static_assert(TW % TH == 0 && (TPI & (TPI - 1)) == 0, "a tile is TH full rows of a TW x TW image");
   UnitStep ustep;
@@ -761,6 +763,9 @@ int dispatch_p(const vv_conv_params* p, hipStream_t st) {
 
 int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st) {
   if (p->H != p->W || p->CinP % 16 || p->Cout % 32) return VV_ERR_UNSUPPORTED;
+#if !(VV_EXPG & 512)
+  if (p->bn_partial) return VV_ERR_UNSUPPORTED;      // the BatchNorm-backward sums are an epilogue of conv_mfma_kernel's 32-wide launches only
+#endif
   if (p->in_mode != VV_IN_PLAIN && p->in_mode != VV_IN_ACT && p->in_mode != VV_IN_CAT) return VV_ERR_UNSUPPORTED;
   // 16-byte items of 8 channels: every channel offset / stride a multiple of 8 elements
   if (p->src0.cstride % 8 || p->src0.coff % 8 || p->out.cstride % 8 || p->out.coff % 8) return VV_ERR_BAD_ARG;

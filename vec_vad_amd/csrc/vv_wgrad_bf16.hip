@@ -860,6 +860,16 @@ inline void ring_block_shape(int H, int NCI, int NCO, int* cbk, int* obk) {
   *obk = NCO % 2 == 0 ? 2 : 1;
 }
 
+// ONE predicate for "vv_wgrad_bf16_plan sizes this launch for the LDS-ring kernel" (geometry and flags alone), used by the plan
+// query and by the launch's refusal below
+inline bool ring_planned(int kind, int flags, int H, int W, int CinP, int Cout, RGeo* r, int* cbk, int* obk) {
+  const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
+  if (kind != VV_CONV3 || (flags & both) != both || Cout % 32 || CinP <= 0 || CinP % 8) return false;
+  const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
+  ring_block_shape(H, NCI, NCO, cbk, obk);
+  return rgeo(H, W, *cbk == 1 && *obk == 1, r);
+}
+
 inline bool ring_ok(const vv_wgrad_params* p) {
   const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
   if (p->kind != VV_CONV3 || (p->pad0 & both) != both || p->H != p->W || p->H < 8) return false;
@@ -896,13 +906,11 @@ extern "C" int vv_wgrad_bf16_plan(int32_t kind, int32_t B, int32_t H, int32_t W,
   // 3x3 weight gradient runs the LDS-ring kernel, whose tiles and block shapes differ)
   const int flags = kind >> 8;
   kind &= 0xff;
-  const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
-  if (kind == VV_CONV3 && (flags & both) == both && Cout % 32 == 0 && CinP > 0 && CinP % 8 == 0) {
-    const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
-    int cbk, obk;
-    ring_block_shape(H, NCI, NCO, &cbk, &obk);
+  {
     RGeo r;
-    if (rgeo(H, W, cbk == 1 && obk == 1, &r)) {
+    int cbk, obk;
+    if (ring_planned(kind, flags, H, W, CinP, Cout, &r, &cbk, &obk)) {
+      const int NCI = (CinP + 31) / 32, NCO = Cout / 32;
       if (ntiles) *ntiles = ((B + r.NI - 1) / r.NI) * (H / r.TH);
       if (nblocks) *nblocks = (NCI / cbk) * (NCO / obk);
       if (kw) *kw = 1;
@@ -931,14 +939,10 @@ extern "C" int vv_wgrad_bf16(const vv_wgrad_params* p, vv_stream stream) {
   {
     // vv_wgrad_bf16_plan sizes ksplit / the slabs from (kind, flags, geometry) alone: a launch it planned for the LDS-ring kernel
     // must not fall through to the register-staged one (other tiles and block shapes: slabs would be missing) -- refuse instead
-    const int both = VV_WGRAD_X_BF16 | VV_WGRAD_DY_BF16;
-    if (p->kind == VV_CONV3 && (p->pad0 & both) == both && p->CinP > 0 && p->CinP % 8 == 0) {
-      const int NCI = (p->CinP + 31) / 32, NCO = p->Cout / 32;
-      int cbk, obk;
-      ring_block_shape(p->H, NCI, NCO, &cbk, &obk);
-      RGeo r;
-      if (rgeo(p->H, p->W, cbk == 1 && obk == 1, &r)) return VV_ERR_BAD_ARG;      // planned as ring, not ring-launchable (alignment / input mode)
-    }
+    RGeo r;
+    int cbk, obk;
+    if (ring_planned(p->kind, p->pad0, p->H, p->W, p->CinP, p->Cout, &r, &cbk, &obk))
+      return VV_ERR_BAD_ARG;                      // planned as ring, not ring-launchable (alignment / input mode)
   }
   if (p->kind != VV_CONV3) {                   // weight gradient of the transposed conv (H x W = its input resolution)
     switch (p->H == p->W ? p->H : 0) {
