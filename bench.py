@@ -488,8 +488,9 @@ def run_scoring(dev, B=512, n=8192, reps=3):
     # one accounting with the headline's roofline: the multiply-adds the matrix cores EXECUTE (Winograd 3x3 layers x16/36, K padding
     # counted; transposed convs and the 1x1 output conv as they are)
     bank = tr.bank
-    exe = sum(conv_exec_flops(l, B, bank.Ga, bank.wino) for l in bank.lay.convs)
+    exe = sum(v for k, v in conv_exec_flops(bank.lay, B, bank.Ga, bank.wino).items() if k.startswith('conv'))
     exe += sum(2.0 * B * H * H * 9 * ci * co * bank.Ga for (_, H, ci, co) in bank.lay.convT)
+    exe += 2.0 * B * 32 * 32 * bank.nf * sum(u.out_c for u in bank.units[bank.g0:bank.g0 + bank.Ga])      # 1x1 output convs (VALU)
     rec['executed_tflops'] = exe / (ms * 1e-3) / 1e12
     rec['frac_executed'] = exe / (ms * 1e-3) / FP32_MFMA_PEAK
     rec['roofline'] = {'bound': 'mfma', 'achieved': rec['executed_tflops'], 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',

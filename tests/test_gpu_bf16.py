@@ -597,3 +597,55 @@ def test_bf16_conv_second_output_view(H, Cin, Cout, B, legacy):
                       L.NULL_VIEW, Cin, L.CONV_BF16, None, pk.data_ptr(), pk.stride(0), None, 0, L.View(y.data_ptr(), y.stride(0), half, 0), None)
     cp.out1, cp.osplit = L.View(y.data_ptr() + M * half * 4, y.stride(0), half, 0), half
     assert lib.vv_conv_mfma(C.byref(cp), st) != 0
+
+
+@pytest.mark.parametrize('B,Cin,Cout,mode,variant', [(90, 32, 32, 'act', 'stats'), (90, 32, 32, 'plain', 'bnf'), (90, 16, 32, 'plain', 'stats'),
+                                                     (47, 32, 64, 'plain', 'split'), (90, 16, 32, 'act', 'relu'), (128, 32, 32, 'plain', 'none')])
+def test_bf16_ring_conv_bitwise_equal(B, Cin, Cout, mode, variant):
+    """conv_ring16_kernel (round 5, csrc/vv_conv_ring16.hip: persistent workgroups, halo of the next tile by LDS-DMA, filter in
+    registers) against conv_mfma_kernel<.., BF> (VV_CONV_NO_RING) on the same all-bf16 tensors of the 32x32 level: output, BatchNorm
+    column sums, the fused BatchNorm-backward sums and the two-plane output of a concat layer's data gradient agree BIT FOR BIT, for
+    runs of tiles that cross UNet / N-tile boundaries inside a workgroup."""
+    from vec_vad_amd import _lib as L
+    lib = L.lib()
+    G, H = 6, 32
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device='cpu').manual_seed(B * 100 + Cin + Cout)
+    M = B * H * H
+    xs = _as_bf16_storage(_r(torch.randn(G, M, Cin, generator=g)).cuda())
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    bias = torch.randn(G, Cout, generator=g).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    zs = _as_bf16_storage(_r(torch.randn(G, M, Cout, generator=g)).cuda())
+    bn = [(torch.rand(G, Cout, generator=g) + 0.5).cuda() for _ in range(4)]
+    pk = _pack(lib, L, w, G, 0, Cin, Cout, st)
+    base = L.CONV_BF16 | L.CONV_OUT_BF16 | L.CONV_ALLSRC_BF16 | (L.CONV_RELU if variant == 'relu' else 0)
+    nt = lib.vv_conv_ntiles2(B, H, H, L.CONV3, base)
+    assert G * (Cout // 32) * nt >= 4 * 512
+    outs = []
+    for flag in (0, L.CONV_NO_RING):
+        y = torch.full((G, M * Cout // 2 + 8), float('nan'), device='cuda')
+        s_ = torch.full((G, nt, 2, Cout), float('nan'), device='cuda')
+        use_stats = variant in ('stats', 'split', 'relu')
+        cp = L.ConvParams(L.CONV3, L.IN_ACT if mode == 'act' else L.IN_PLAIN, G, B, H, H, Cin, Cin, Cout,
+                          L.View(xs.data_ptr(), xs.stride(0), Cin, 0), a.data_ptr(), b.data_ptr(), Cin, L.NULL_VIEW, 0, base | flag, None,
+                          pk.data_ptr(), pk.stride(0), bias.data_ptr(), Cout, L.View(y.data_ptr(), y.stride(0), Cout, 0),
+                          s_.data_ptr() if use_stats else None)
+        if variant == 'split':
+            half = Cout // 2
+            cp.out = L.View(y.data_ptr(), y.stride(0), half, 0)
+            cp.out1 = L.View(y.data_ptr() + M * half * 2, y.stride(0), half, 0)
+            cp.osplit = half
+        if variant == 'bnf':
+            cp.bn_z, cp.bn_z_gstride = zs.data_ptr(), zs.stride(0)
+            cp.bn_a, cp.bn_b, cp.bn_mean, cp.bn_invstd = (t.data_ptr() for t in bn)
+            cp.bn_gstride, cp.bn_partial = Cout, s_.data_ptr()
+        L.check(lib.vv_conv_mfma(C.byref(cp), st), 'conv')
+        torch.cuda.synchronize()
+        assert float(y[0, -1]) != float(y[0, -1])            # nothing written behind the tensor (still NaN)
+        outs.append((y.view(torch.int16)[:, :M * Cout].clone(), s_.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if variant != 'none':
+        assert not torch.isnan(outs[0][1]).any()
+        assert torch.equal(outs[0][1], outs[1][1])

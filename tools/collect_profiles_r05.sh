@@ -51,6 +51,7 @@ for name, trace, marker in (('net4_b256_train_step', '$O/kernel_trace_net4_b256_
         out[name] = json.loads(subprocess.check_output([sys.executable, '$R/tools/launch_census.py', trace, marker]).decode())
     except Exception as e:
         out[name] = {'error': repr(e)}
+sys.path.insert(0, '$R')
 from vec_vad_amd import build as B
 out['library_build'] = B.wanted()[1][:16]
 print(json.dumps(out, indent=1))

@@ -14,6 +14,8 @@ lib = L.lib()
 G, B = int(os.environ.get('UB_G', '10')), int(os.environ.get('UB_B', '512'))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 legacy = L.CONV_NO_GEMM16 if len(sys.argv) > 2 and sys.argv[2] == 'legacy' else 0
+if os.environ.get('UB_NO_RING') == '1':      # the 32x32 launches on the round-3 kernel instead of conv_ring16_kernel (round 5)
+    legacy |= L.CONV_NO_RING
 only = os.environ.get('UB_ONLY')
 st = torch.cuda.current_stream().cuda_stream
 LAYERS = [(32, 16, 32, 'plain', 1, 'conv0'), (32, 32, 32, 'act', 2, 'conv1/13'), (32, 64, 32, 'cat', 1, 'conv12'),
@@ -40,6 +42,8 @@ nl = 0
 gen = torch.Generator(device='cuda').manual_seed(1)
 for H, Cin, Cout, mode, mult, name in LAYERS:
     if only and only not in name:
+        continue
+    if os.environ.get('UB_H') and int(os.environ['UB_H']) != H:
         continue
     csplit = Cin // 2 if mode == 'cat' else Cin
     x0 = bf16_buf((G, B * H * H, csplit), gen)

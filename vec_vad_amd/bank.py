@@ -258,8 +258,9 @@ class UNetBank:
         wino_env = os.environ.get('VV_WINOGRAD', '1') != '0'
         self.wino = wino_env and not self.cflag
         self.wino_wgrad = wino_env and os.environ.get('VV_WINOGRAD_WGRAD', '1') != '0'
-        # VV_WINO_RING=0: A/B switch, the 32x32-level Winograd launches stay on the per-tile kernel (bit-identical results)
-        self.wino_flag = L.CONV_NO_RING if (self.wino and os.environ.get('VV_WINO_RING', '1') == '0') else 0
+        # VV_WINO_RING=0 / VV_CONV_RING=0: A/B switch, the 32x32-level launches stay on the per-tile kernels instead of the persistent
+        # LDS-DMA ring kernels of round 5 (fp32: wino_ring_kernel, all-bf16: conv_ring16_kernel; bit-identical results either way)
+        self.wino_flag = L.CONV_NO_RING if '0' in (os.environ.get('VV_WINO_RING', '1'), os.environ.get('VV_CONV_RING', '1')) else 0
         self.wgrad_flag = 256                  # vv_wgrad_params.pad0 bit 8: Winograd form of the 3x3 weight gradient
         # first reduction pass of the BatchNorm backward inside the data-gradient launch that produces dA (where it is the only producer)
         self.fuse_bn_sums = os.environ.get('VV_FUSE_BN_SUMS', '1') != '0'

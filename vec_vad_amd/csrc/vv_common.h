@@ -43,6 +43,11 @@ inline bool vv_gemm16_flags(int kind, int flags) {
          !(flags & VV_CONV_NO_GEMM16);
 }
 
+// vv_conv_ring16.hip (round 5): the all-bf16 3x3 launches of the 32x32 level with at most 32 input channels on persistent workgroups
+// with an LDS-DMA halo prefetch; vv_conv_mfma routes to it (bit-identical results), VV_CONV_NO_RING keeps the launch where it was.
+int vv_conv_ring16(const vv_conv_params* p, hipStream_t st);
+bool vv_conv_ring16_ok(const vv_conv_params* p);
+
 // DPP row_ror:N -- the value of the lane N places further round this lane's row of 16
 template <int N>
 __device__ __forceinline__ float vv_dpp_ror(const float v) {

@@ -561,6 +561,7 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   // all-bf16 3x3 launches: the persistent GEMM-shaped kernel on the 16x16 / 8x8 / 4x4 levels; at 32x32 (HBM-bound, 1 - 2 chunks per
   // tile) it measured slower than this file's kernel, which has the same 256-pixel tiles there (vv_conv_ntiles2 is unaffected)
   if (vv_gemm16_flags(p->kind, p->pad0) && p->H <= 16) return vv_conv_gemm16(p, st);
+  if (sm == 2 && vv_conv_ring16_ok(p)) return vv_conv_ring16(p, st);
   switch (p->kind) {
     case VV_CONV3:
       if (p->CinP % 16) return VV_ERR_BAD_ARG;
