@@ -46,7 +46,7 @@ python - <<PY > $O/launch_census.json
 import json, subprocess, sys
 out = {}
 for name, trace, marker in (('net4_b256_train_step', '$O/kernel_trace_net4_b256_overlap.csv', 'adam_bucketed_kernel'),
-                            ('flownet2_forward', '$O/kernel_trace_flownet2_overlap.csv', 'flownet_prep')):
+                            ('flownet2_forward', '$O/kernel_trace_flownet2_overlap.csv', 'prep_sum_kernel')):
     try:
         out[name] = json.loads(subprocess.check_output([sys.executable, '$R/tools/launch_census.py', trace, marker]).decode())
     except Exception as e:
