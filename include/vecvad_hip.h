@@ -225,6 +225,20 @@ int vv_wino_ntiles(int32_t B, int32_t H);
 int vv_pack_wino(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params, int64_t params_gstride,
                  float* packed, int64_t packed_gstride, int32_t max_kn, vv_stream stream);
 
+/* ---- Winograd F(4x4,3x3) form of the same convolution (round 5; forward and data-gradient) ----
+ * 2.25 matrix-core multiply-adds per output pixel and channel pair (F(2x2,3x3): 4, direct: 9), fp32 throughout; the larger transform
+ * constants leave the result a few 1e-6 of the tensor's maximum from the direct form (F(2x2): a few 1e-7).
+ * vv_conv_wino44 takes the vv_conv_params of a VV_CONV3 launch (same fields and contract as vv_conv_wino, incl. `stats`, the fused
+ * BatchNorm-backward sums `bn_partial` and VV_CONV_RELU) with `w` = panels from vv_pack_wino44:
+ * [36 = xi*6+nu][CinP/8][2][2][Cout][2], element (t, k, n) at ((((t*CinP/8 + k/8)*2 + (k%4)/2)*2 + (k%8)/4)*Cout + n)*2 + k%2,
+ * U = G g G^T (6x6); mode 0 forward, mode 1 data-gradient (flipped + transposed filter).  36*KP*N floats per entry.
+ * in_mode PLAIN / ACT / CAT; CinP % 8 == 0; H = W in {32, 16, 8, 4}; `stats` / `bn_partial` have vv_wino44_ntiles(B, H) rows per UNet
+ * (a row = 32 tiles of 4x4 pixels). */
+int vv_conv_wino44(const vv_conv_params* p, vv_stream stream);
+int vv_wino44_ntiles(int32_t B, int32_t H);
+int vv_pack_wino44(const vv_pack_entry* table_dev, int32_t nentries, int32_t G, const float* params, int64_t params_gstride,
+                   float* packed, int64_t packed_gstride, int32_t max_kn, vv_stream stream);
+
 /* ---- BatchNorm (nn.BatchNorm2d(eps=1e-5, momentum=0.1), model/unet.py:11,14) ----
  * train != 0: batch statistics from the conv's partial sums; writes scale/shift a,b for the consumer's load,
  *             mean / invstd for the backward pass, and updates running_mean / running_var (unbiased) in place.

@@ -33,7 +33,7 @@ def pack(fn, w, K, N, taps):
     return out
 
 
-tot_t = tot_exec = tot_alg = 0.0
+tot_t = tot_exec = tot_alg = tot44 = 0.0
 for H, Cin, Cout, mult, name in LAYERS:
     g = torch.Generator(device='cpu').manual_seed(H * 1000 + Cin)
     x = torch.randn(G, B * H * H, Cin, generator=g).cuda()
@@ -45,8 +45,10 @@ for H, Cin, Cout, mult, name in LAYERS:
     pkw = pack(lib.vv_pack_wino, w, Cin, Cout, 16)
     for fn, pk, nt, fl in ((lib.vv_conv_mfma, pack(lib.vv_pack_weights, w, Cin, Cout, 9), lib.vv_conv_ntiles(B, H, H), 0),
                            (lib.vv_conv_wino, pkw, lib.vv_wino_ntiles(B, H), 0),
-                           (lib.vv_conv_wino, pkw, lib.vv_wino_ntiles(B, H), L.CONV_NO_RING)):
+                           (lib.vv_conv_wino, pkw, lib.vv_wino_ntiles(B, H), L.CONV_NO_RING),
+                           (lib.vv_conv_wino44, pack(lib.vv_pack_wino44, w, Cin, Cout, 36), lib.vv_wino44_ntiles(B, H), 0)):
         if fl and not (H == 32 and Cin <= 32):
+            outs.append(None); times.append(None)
             continue
         y = torch.zeros(G, B * H * H, Cout, device='cuda')
         s_ = torch.zeros(G, nt, 2, Cout, device='cuda')
@@ -68,12 +70,18 @@ for H, Cin, Cout, mult, name in LAYERS:
     serr = (outs[0][1] - outs[1][1]).abs().max().item() / outs[0][1].abs().max().item()
     alg = 2.0 * B * H * H * 9 * Cin * Cout * G
     ring = ''
-    if len(outs) > 2:
+    e44 = (outs[0][0] - outs[3][0]).abs().max().item() / outs[0][0].abs().max().item()
+    s44 = (outs[0][1] - outs[3][1]).abs().max().item() / outs[0][1].abs().max().item()
+    w44 = ' | F(4x4) %7.1f us %6.1f TF/s exec (%.2f) alg %6.1f err %.1e stats %.1e' % (
+        times[3] * 1e6, alg / 4 / times[3] / 1e12, alg / 4 / times[3] / 157.3e12, alg / times[3] / 1e12, e44, s44)
+    tot44 += mult * times[3]
+    if outs[2] is not None:
         ring = ' | per-tile kernel %7.1f us, ring bit-equal: %s' % (times[2] * 1e6, bool(torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])))
     print('%-20s H=%2d %3d->%3d x%d : wino %7.1f us %6.1f TF/s exec (%.2f of peak)  alg %6.1f | direct %7.1f us %6.1f TF/s | err %.1e stats %.1e %s'
           % (name, H, Cin, Cout, mult, times[1] * 1e6, alg * 16 / 36 / times[1] / 1e12, alg * 16 / 36 / times[1] / 157.3e12, alg / times[1] / 1e12,
-             times[0] * 1e6, alg / times[0] / 1e12, err, serr, ('' if err < 2e-5 and serr < 1e-3 else '  <-- MISMATCH') + ring), flush=True)
+             times[0] * 1e6, alg / times[0] / 1e12, err, serr, ('' if err < 2e-5 and serr < 1e-3 else '  <-- MISMATCH') + ring + w44), flush=True)
     tot_t += mult * times[1]
     tot_alg += mult * alg
 print('weighted (27 launches of a Net4 step): %.3f ms, avg %.1f us/launch, executed %.1f TF/s = %.3f of peak, algorithmic %.1f TF/s'
       % (tot_t * 1e3, tot_t / 27 * 1e6, tot_alg * 16 / 36 / tot_t / 1e12, tot_alg * 16 / 36 / tot_t / 157.3e12, tot_alg / tot_t / 1e12))
+print('F(4x4,3x3) on every launch: %.3f ms, avg %.1f us/launch' % (tot44 * 1e3, tot44 / 27 * 1e6))

@@ -109,6 +109,9 @@ _SIGS = {
     'vv_conv_wino': (c_i32, [C.POINTER(ConvParams), c_vp]),
     'vv_wino_ntiles': (c_i32, [c_i32, c_i32]),
     'vv_pack_wino': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
+    'vv_conv_wino44': (c_i32, [C.POINTER(ConvParams), c_vp]),
+    'vv_wino44_ntiles': (c_i32, [c_i32, c_i32]),
+    'vv_pack_wino44': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
     'vv_conv_ntiles2': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
