@@ -57,15 +57,15 @@ def conv_flops(lay, B, G):
     return fl
 
 
-def conv_exec_flops(lay, B, G, wino):
+def conv_exec_flops(lay, B, G, wino, w44=None):
     """FLOPs the matrix cores execute for the same launches: channels padded to the MFMA K granule (layer 0: 12 -> 16),
-    x 16/36 for the Winograd form."""
+    x 16/36 for the Winograd F(2x2,3x3) form, x 36/(16*9) = 1/4 for the launches w44(l, dgrad) routes to F(4x4,3x3)."""
     fl = {}
     k = WINO_EXEC if wino else 1.0
     for l in lay.convs:
-        fl['conv%d' % l.idx] = 2.0 * B * l.H * l.H * 9 * l.cinp * l.cout * G * k
+        fl['conv%d' % l.idx] = 2.0 * B * l.H * l.H * 9 * l.cinp * l.cout * G * (0.25 if (w44 and w44(l, False)) else k)
         if l.idx > 0:
-            fl['dgrad%d' % l.idx] = 2.0 * B * l.H * l.H * 9 * l.cin * l.cout * G * k
+            fl['dgrad%d' % l.idx] = 2.0 * B * l.H * l.H * 9 * l.cin * l.cout * G * (0.25 if (w44 and w44(l, True)) else k)
     return fl
 
 
@@ -224,7 +224,7 @@ def build_net(model, precision, dev):
 def conv_roofline(bank, B, per, precision, overlap, traffic):
     """roofline object of the 3x3-conv family from HIP-event timings {label: [seconds]}."""
     fl = conv_flops(bank.lay, B, bank.Ga)
-    fx = conv_exec_flops(bank.lay, B, bank.Ga, bank.wino)
+    fx = conv_exec_flops(bank.lay, B, bank.Ga, bank.wino, lambda l, d: bank._w44(B, l, d))      # (train-mode plan: VV_WINO44, default none)
     by = conv_bytes(bank.lay, B, bank.Ga, 2 if bank.y16 else 4, 2 if bank.dz16 else 4, 2 if bank.da16 else 4)
     t = sum(sum(v) for k, v in per.items() if k in fl)
     n = sum(len(v) for k, v in per.items() if k in fl)
@@ -423,7 +423,7 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
         if precision == 'fp32' and bank.wino:
             # executed share of the forward: the 14 Winograd conv launches execute 16/36, everything else (transposed convs) 1:1
             fa = conv_flops(bank.lay, B, bank.Ga)
-            fx = conv_exec_flops(bank.lay, B, bank.Ga, True)
+            fx = conv_exec_flops(bank.lay, B, bank.Ga, True, lambda l, d: bank._w44(B, l, d))
             conv_a = sum(v for k, v in fa.items() if k.startswith('conv'))
             conv_x = sum(v for k, v in fx.items() if k.startswith('conv'))
             exe = B * fwd_flop - conv_a + conv_x
@@ -488,7 +488,9 @@ def run_scoring(dev, B=512, n=8192, reps=3):
     # one accounting with the headline's roofline: the multiply-adds the matrix cores EXECUTE (Winograd 3x3 layers x16/36, K padding
     # counted; transposed convs and the 1x1 output conv as they are)
     bank = tr.bank
-    exe = sum(v for k, v in conv_exec_flops(bank.lay, B, bank.Ga, bank.wino).items() if k.startswith('conv'))
+    w44 = lambda l, d: bank._w44(B, l, d, evalm=True)
+    exe = sum(v for k, v in conv_exec_flops(bank.lay, B, bank.Ga, bank.wino, w44).items() if k.startswith('conv'))
+    rec['winograd_f4x4_layers'] = [l.idx for l in bank.lay.convs if w44(l, False)]
     exe += sum(2.0 * B * H * H * 9 * ci * co * bank.Ga for (_, H, ci, co) in bank.lay.convT)
     exe += 2.0 * B * 32 * 32 * bank.nf * sum(u.out_c for u in bank.units[bank.g0:bank.g0 + bank.Ga])      # 1x1 output convs (VALU)
     rec['executed_tflops'] = exe / (ms * 1e-3) / 1e12

@@ -260,6 +260,7 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
 #define VV_BNBWD_PARTIALS_PER_TILE 16  /* vv_bn_bwd_apply: `partial` holds [G][vv_wino_ntiles(B,H)][2][C] written by the data-gradient
                                           launch that produced dA (vv_conv_params.bn_partial): no vv_bn_bwd_reduce pass for that layer */
 #define VV_BNBWD_PARTIALS_PER_CTILE 32 /* the same for a data-gradient launch of vv_conv_mfma (all-bf16 tensors): [G][vv_conv_ntiles(B,H,W)][2][C] */
+#define VV_BNBWD_PARTIALS_PER_TILE44 64 /* the same for a data-gradient launch of vv_conv_wino44: [G][vv_wino44_ntiles(B,H)][2][C] */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;
   int32_t flags;

@@ -149,3 +149,67 @@ def test_wino44_output_into_channel_slice_and_determinism():
     assert (y[:, :, :CO] == 3.0).all() and (y[:, :, CO + Cout:] == 3.0).all()
     yr = torch.nn.functional.conv2d(x[1].view(B, H, H, Cin).permute(0, 3, 1, 2).double(), w[1].double(), padding=1).permute(0, 2, 3, 1).reshape(B * H * H, Cout)
     assert (yr - y[1, :, CO:CO + Cout].double()).abs().max().item() <= BAR * yr.abs().max().item()
+
+
+def test_bank_routes_to_wino44_on_request(monkeypatch):
+    """VV_WINO44=all: every 3x3 forward / data-gradient launch of a train step through vv_conv_wino44 (panels, BatchNorm partial rows,
+    the fused BatchNorm-backward sums and the concat layers' bias partials all follow the kernel's tile count) -- three Adam steps
+    against the oracle at the default path's bars, and the default path itself stays on F(2x2)."""
+    import numpy as np
+    from oracle import unet_oracle as O
+    from test_gpu_unet import _build
+    from vec_vad_amd.trainer import FusedTrainer
+    monkeypatch.setenv('VV_WINO44', 'all')
+    net, sd, tot_of = _build('net4', False)
+    raw, flow = O.seeded_cubes(6, tot_of, 3)
+    x, x_of = O.cubes_to_inputs(raw, flow)
+    net.train()
+    tr = FusedTrainer(net)
+    labels = None
+    opt = O.AdamState(O.param_names(sd))
+    for step in range(3):
+        ws = tr.step_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda(), torch.arange(6, device='cuda'))
+        l_raw, l_of = [float(v) for v in tr.losses(ws)]
+        lr_, lo_, _ = O.train_step(sd, O.bank_spec('net4'), x, x_of, opt)
+        assert abs(l_raw - lr_) <= 1e-3 * lr_ and abs(l_of - lo_) <= 1e-3 * lo_, (step, l_raw, lr_, l_of, lo_)
+    bank = tr.bank if hasattr(tr, 'bank') else None
+    if bank is not None:
+        ws = bank.workspace(6)
+        labels = [c[2] for c in ws.fwd[True].calls]
+        assert 'pack_wino44' in labels
+        assert all(c[0] is bank.lib.vv_conv_wino44 for c in ws.fwd[True].calls if c[2].startswith('conv') and c[2][4:].isdigit())
+    net.eval()
+    r, o = tr.score_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda())
+    rs, os_ = O.score_pass(sd, O.bank_spec('net4'), x, x_of, 6)
+    np.testing.assert_allclose(r.cpu().numpy(), rs, rtol=5e-3)
+    np.testing.assert_allclose(o.cpu().numpy(), os_, rtol=5e-3)
+
+
+@pytest.mark.parametrize('mode', ['all', '1'])
+def test_eval_scoring_through_wino44(monkeypatch, mode):
+    """VV_WINO44_EVAL: the eval-mode forward on the folded model with its 3x3 launches routed to vv_conv_wino44 ('all': every one, at a
+    batch the policy would not take; '1' = the default policy at a batch where it takes the 16x16 / 8x8-level launches) against the
+    oracle's scores at the default path's bar and against the F(2x2) path."""
+    import numpy as np
+    from oracle import unet_oracle as O
+    from test_gpu_unet import _build
+    from vec_vad_amd.trainer import FusedTrainer
+    n = 6 if mode == 'all' else 512
+    res = {}
+    for m in (mode, '0'):
+        monkeypatch.setenv('VV_WINO44_EVAL', m)
+        net, sd, tot_of = _build('net4', False)
+        raw, flow = O.seeded_cubes(n, tot_of, 1)
+        net.eval()
+        tr = FusedTrainer(net)
+        r, o = tr.score_cubes(torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda())
+        res[m] = (r.cpu().numpy(), o.cpu().numpy())
+        routed = [l.idx for l in tr.bank.lay.convs if tr.bank._w44(n, l, False, evalm=True)]
+        assert (len(routed) == 14 if m == 'all' else routed == [] if m == '0' else routed == [3, 4, 5, 8, 9, 10, 11, 12]), routed
+    np.testing.assert_allclose(res[mode][0], res['0'][0], rtol=2e-4)
+    np.testing.assert_allclose(res[mode][1], res['0'][1], rtol=2e-4)
+    if mode == 'all':
+        x, x_of = O.cubes_to_inputs(raw, flow)
+        rs, os_ = O.score_pass(sd, O.bank_spec('net4'), x, x_of, n)
+        np.testing.assert_allclose(res[mode][0], rs, rtol=1e-3)
+        np.testing.assert_allclose(res[mode][1], os_, rtol=1e-3)

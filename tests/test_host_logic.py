@@ -465,3 +465,27 @@ def test_embedded_width_layout_roundtrip():
         w = net.get_parameter(conv_key_to_state_name(stems, 'c12.w'))
         (m0, b0), (m1, b1) = _embed_pieces(lay, 'c12.w', tuple(w.shape))
         assert b1[1].start == l12.cin // 2 and m1[1].start == nf and b0[1] == slice(0, nf)
+
+
+def test_wino44_routing_is_opt_in(monkeypatch):
+    """VV_WINO44 (round 5): default = no launch on the Winograd F(4x4,3x3) kernel; '1' = the measured policy (GEMM-K >= 64 and workgroups
+    that fill the chip evenly -- at B = 256 the 16x16-level 64- / 128-channel launches, conv12 and dgrad8); 'all' = every launch."""
+    from vec_vad_amd.bank import UNetBank, UnitSpec
+    units = [UnitSpec('raw', i, i) for i in range(5)] + [UnitSpec('of', 4, 0)]
+    b = UNetBank(units, nf=32, device='cpu')
+    assert not any(b._w44(256, l, d) for l in b.lay.convs for d in (False, True)) and b._w44_pack(256) is None
+    monkeypatch.setenv('VV_WINO44', '1')
+    b = UNetBank(units, nf=32, device='cpu')
+    fwd = sorted(l.idx for l in b.lay.convs if b._w44(256, l, False))
+    dgr = sorted(l.idx for l in b.lay.convs if b._w44(256, l, True))
+    assert fwd == [3, 10, 11, 12] and dgr == [3, 8, 10, 11], (fwd, dgr)
+    assert not any(b._w44(5, l, d) for l in b.lay.convs for d in (False, True))        # small batches: too few workgroups
+    tab, n, mx = b._w44_pack(256)
+    assert n == 8 and mx == 128 * 256
+    monkeypatch.setenv('VV_WINO44', 'all')
+    b = UNetBank(units, nf=32, device='cpu')
+    assert all(b._w44(5, l, False) for l in b.lay.convs) and all(b._w44(5, l, True) for l in b.lay.convs[1:])
+    ws = b.workspace(5)
+    calls = ws.fwd[True].calls
+    assert [c[2] for c in calls if c[2].startswith('pack')] == ['pack_wino', 'pack_tail', 'pack_wino_tail', 'pack_wino44']
+    assert all(c[0] is b.lib.vv_conv_wino44 for c in calls if c[2].startswith('conv') and c[2][4:].isdigit())

@@ -31,6 +31,7 @@ CONV_NO_RING = 128      # VV_CONV_NO_RING: keep the 32x32-level Winograd launche
 BNBWD_Y_BF16 = 8
 BNBWD_PARTIALS_PER_TILE = 16   # partial sums left by the data-gradient launch (ConvParams.bn_partial)
 BNBWD_PARTIALS_PER_CTILE = 32  # ... of vv_conv_mfma (all-bf16 tensors): rows per vv_conv_ntiles
+BNBWD_PARTIALS_PER_TILE44 = 64  # ... of vv_conv_wino44: rows per vv_wino44_ntiles
 WGRAD_X_BF16 = 2
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 

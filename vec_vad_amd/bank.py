@@ -117,6 +117,13 @@ class BankLayout:
             self.pkw['c%d.f' % l.idx] = (off, 0, l.cin, l.cinp, l.cout, 'c%d.w' % l.idx); off += 16 * l.cinp * l.cout
             if l.idx > 0:
                 self.pkw['c%d.d' % l.idx] = (off, 1, l.cout, l.cout, l.cin, 'c%d.w' % l.idx); off += 16 * l.cout * l.cin
+        # Winograd F(4x4,3x3) panels (36 transformed taps; vv_pack_wino44) -- space for every layer, packed only where a launch plan
+        # routes a layer to vv_conv_wino44 (UNetBank._w44)
+        self.pkw44 = OrderedDict()
+        for l in Ls:
+            self.pkw44['c%d.f' % l.idx] = (off, 0, l.cin, l.cinp, l.cout, 'c%d.w' % l.idx); off += 36 * l.cinp * l.cout
+            if l.idx > 0:
+                self.pkw44['c%d.d' % l.idx] = (off, 1, l.cout, l.cout, l.cin, 'c%d.w' % l.idx); off += 36 * l.cout * l.cin
         self.UP = _ceil(off, 4)
         self.cmax = 8 * nf
 
@@ -262,6 +269,15 @@ class UNetBank:
         # LDS-DMA ring kernels of round 5 (fp32: wino_ring_kernel, all-bf16: conv_ring16_kernel; bit-identical results either way)
         self.wino_flag = L.CONV_NO_RING if '0' in (os.environ.get('VV_WINO_RING', '1'), os.environ.get('VV_CONV_RING', '1')) else 0
         self.wgrad_flag = 256                  # vv_wgrad_params.pad0 bit 8: Winograd form of the 3x3 weight gradient
+        # VV_WINO44 (round 5): which fp32 3x3 launches run as Winograd F(4x4,3x3) (vv_conv_wino44: 1.78x fewer matrix-core cycles than
+        # F(2x2), a few 1e-6 of the tensor maximum from it).  '0' (default): none -- measured +0.65 % on the Net4 step with the full-size
+        # gradient test's calibrated bar exceeded; '1': the launches it measured faster on (_w44); 'all':
+        # every launch it takes
+        self.w44_mode = os.environ.get('VV_WINO44', '0').lower()
+        self._w44_tables = {}
+        # VV_WINO44_EVAL: the same choice for the eval-mode forward on the folded model (test.py:312-345 scoring; no gradients, scores
+        # and AUROC judged at 1e-3: a few 1e-6 per layer are noise there).  '1' (default): the policy of _w44; '0': none; 'all'
+        self.w44_eval_mode = os.environ.get('VV_WINO44_EVAL', '1').lower()
         # first reduction pass of the BatchNorm backward inside the data-gradient launch that produces dA (where it is the only producer)
         self.fuse_bn_sums = os.environ.get('VV_FUSE_BN_SUMS', '1') != '0'
         direct = [(k, v) for k, v in lay.pk.items() if not (self.wino and k[0] == 'c')]
@@ -313,6 +329,7 @@ class UNetBank:
             return self
         for n in ('params', 'bufs', 'grads', '_adam_t_dev', '_adam_sc', 'nbt', 'packed', 'chmap', 'oc', 'tsrc', 'tcoff', 'pack_table', 'pack_table_w', 'fold_table', 'ab_ident'):
             setattr(self, n, getattr(self, n).to(device))
+        self._w44_tables, self._w44_eval_table = {}, None
         if self.adam_m is not None:
             self.adam_m, self.adam_v = self.adam_m.to(device), self.adam_v.to(device)
         self.device = device
@@ -429,6 +446,41 @@ class UNetBank:
         ws.out4_valid = False          # True while ws.out4 holds the reconstructions of the LAST forward on this workspace
         return ws
 
+    def _w44(self, B, l, dgrad, evalm=False):
+        """Does the forward (dgrad=False) / data-gradient launch of conv layer l run as Winograd F(4x4,3x3) at batch size B (evalm: in
+        the eval-mode plan)?  Policy
+        from per-launch measurements (tools/ubench_wino.py, profiles/README.md): the kernel wins where the matrix pipe is the bound
+        -- GEMM-K (input channels of the launch) >= 64 -- AND its coarser workgroups (64 tiles of 4x4 pixels x 32 channels, one per CU)
+        still fill the chip evenly: at least two rounds of 256 workgroups with <= 10 % of the last round idle."""
+        mode = self.w44_eval_mode if evalm else self.w44_mode
+        if not self.wino or mode in ('0', 'off') or (dgrad and l.idx == 0):
+            return False
+        K, N = (l.cout, l.cin) if dgrad else (l.cinp, l.cout)
+        if N % 32 or K % 8 or K > 256:
+            return False
+        if mode == 'all':
+            return True
+        wgs = self.Ga * (N // 32) * -(-self.lib.vv_wino44_ntiles(B, l.H) // 2)
+        rounds = wgs / 256.0
+        return K >= 64 and wgs >= 512 and rounds / math.ceil(rounds) >= 0.9
+
+    def _w44_pack(self, B):
+        """device pack table (vv_pack_wino44) of the panels the plans for batch size B use; (tensor, entries, max K*N) or None"""
+        if B not in self._w44_tables:
+            lay = self.lay
+            keys = [('c%d.f' % l.idx) for l in lay.convs if self._w44(B, l, False)] + [('c%d.d' % l.idx) for l in lay.convs if self._w44(B, l, True)]
+            if not keys:
+                self._w44_tables[B] = None
+            else:
+                ents = (L.PackEntry * len(keys))()
+                mx = 0
+                for i, k in enumerate(keys):
+                    off, mode, K, KP, N, src = lay.pkw44[k]
+                    ents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
+                    mx = max(mx, KP * N)
+                self._w44_tables[B] = (torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(self.device), len(keys), mx)
+        return self._w44_tables[B]
+
     def _src_for(self, ws, l):
         """(load mode, src0 view, a, b, src1 view, csplit, chmap) of conv layer l's input."""
         lay, Ga = self.lay, self.Ga
@@ -499,19 +551,26 @@ class UNetBank:
             P.add(lib.vv_pack_wino, (self.pack_table_w.data_ptr() + whn * es, self.pack_w_n - whn, Ga, pbase, U, kbase, UP,
                                      self.pack_w_max), 'pack_wino_tail', stream=ts, record='pack_wino_tail')
             pack_tail.append('pack_wino_tail')
+        w44p = self._w44_pack(B) if train else None
+        if w44p:
+            P.add(lib.vv_pack_wino44, (w44p[0].data_ptr(), w44p[1], Ga, pbase, U, kbase, UP, w44p[2]), 'pack_wino44', stream=ts,
+                  record='pack_wino44')
+            pack_tail.append('pack_wino44')
         abg = lay.cmax
 
         def conv(l):
             mode, s0, a, b, s1, csplit, chmap = self._src_for(ws, l)
             y = ws.y[l.idx]
-            panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
+            w44 = train and self._w44(B, l, False)
+            panel = (lay.pkw44 if w44 else lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
             cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, self.fflag | self.wino_flag, chmap,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U,
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
-            P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx,
+            P.add(lib.vv_conv_wino44 if w44 else lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx,
                   wait=tuple(pack_tail) if l.idx == 2 else ())
-            nt = lib.vv_wino_ntiles(B, l.H) if self.wino else lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag)
+            nt = lib.vv_wino44_ntiles(B, l.H) if w44 else lib.vv_wino_ntiles(B, l.H) if self.wino else \
+                lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag)
             P.add(lib.vv_bn_finalize,
                   (Ga, l.cout, nt, B * l.H * l.H, 1 if train else 0, 0.1, 1e-5, ws.stats.data_ptr(), nt * 2 * l.cout,
                    pbase + 4 * lay.p['c%d.g' % l.idx][0], pbase + 4 * lay.p['c%d.beta' % l.idx][0], U,
@@ -583,6 +642,18 @@ class UNetBank:
         if self.wino:
             L.check(lib.vv_pack_wino(self.pack_table_w.data_ptr(), self.pack_w_n, G, self.params_eval.data_ptr(), lay.U,
                                      self.packed_eval.data_ptr(), lay.UP, self.pack_w_max, st), 'pack_wino (eval)')
+            if self.w44_eval_mode not in ('0', 'off'):
+                if getattr(self, '_w44_eval_table', None) is None:
+                    keys = ['c%d.f' % l.idx for l in lay.convs if l.cinp % 8 == 0 and l.cinp <= 256]
+                    ents = (L.PackEntry * len(keys))()
+                    for i, k in enumerate(keys):
+                        off, mode, K, KP, N, src = lay.pkw44[k]
+                        ents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
+                    self._w44_eval_table = (torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(self.device), len(keys),
+                                            max(lay.pkw44[k][3] * lay.pkw44[k][4] for k in keys))
+                t = self._w44_eval_table
+                L.check(lib.vv_pack_wino44(t[0].data_ptr(), t[1], G, self.params_eval.data_ptr(), lay.U, self.packed_eval.data_ptr(), lay.UP,
+                                           t[2], st), 'pack_wino44 (eval)')
         self._eval_key = key
 
     def _plan_eval(self, ws, B, out4=True):
@@ -629,11 +700,12 @@ class UNetBank:
                                         pb.stride(0), 0), 'pool%d' % l.idx)
             mode, s0, a, b, s1, csplit = src(l)
             y = ws.y[l.idx]
-            panel = (lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
+            w44 = self._w44(B, l, False, evalm=True)
+            panel = (lay.pkw44 if w44 else lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
             cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, L.CONV_RELU | self.wino_flag, None,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U, L.view(y, l.cout, 0, y.stride(0)), None)
             P.keep.append(cp)
-            P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
+            P.add(lib.vv_conv_wino44 if w44 else lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx)
         last = lay.convs[-1]
         y = ws.y[last.idx]
         op = L.OutconvParams(Ga, B, HW0 * HW0, self.nf, y.data_ptr(), y.stride(0), one, zero, abg,
@@ -818,7 +890,8 @@ class UNetBank:
             from_dgrad = i in fused                # ... by the data-gradient launch of layer i + 1
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
                                (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0) |
-                               ((L.BNBWD_PARTIALS_PER_TILE if self.wino else L.BNBWD_PARTIALS_PER_CTILE) if from_dgrad else 0) |
+                               ((L.BNBWD_PARTIALS_PER_TILE44 if self._w44(B, lay.convs[i + 1], True) else L.BNBWD_PARTIALS_PER_TILE if self.wino
+                                 else L.BNBWD_PARTIALS_PER_CTILE) if from_dgrad else 0) |
                                (L.BNBWD_DA_BF16 if self.da16 else 0) | (L.BNBWD_Y_BF16 if self.y16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
                                ws.bnpart.data_ptr())
@@ -831,10 +904,11 @@ class UNetBank:
             # data gradient
             if i > 0:
                 Dl = ws.D[i]
+                w44 = self._w44(B, l, True)
                 cp = L.ConvParams(L.CONV3, L.IN_PLAIN, Ga, B, l.H, l.H, l.cout, l.cout, l.cin,
                                   L.View(dzb.data_ptr(), dzb.stride(0), l.cout, 0), None, None, 0, L.NULL_VIEW, 0,
                                   dgrad_flags(i) | self.wino_flag, None,
-                                  kbase + 4 * (lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
+                                  kbase + 4 * (lay.pkw44 if w44 else lay.pkw if self.wino else lay.pk)['c%d.d' % i][0], UP, None, 0,
                                   L.view(Dl, l.cin, 0, Dl.stride(0)),
                                   # concat layers: per-tile column sums of the data gradient = the transposed conv's bias gradient
                                   ws.dstats.data_ptr() if l.mode == L.IN_CAT else None)
@@ -851,8 +925,8 @@ class UNetBank:
                     cp.bn_gstride, cp.bn_partial = abg, ws.bnpart.data_ptr()
                 P.keep.append(cp)
                 # paired schedule: the MFMA data-gradient runs alone (the side stream has drained) ...
-                P.add(lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i, record='D%d' % i,
-                      pwait=('*side',))
+                P.add(lib.vv_conv_wino44 if w44 else lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'dgrad%d' % i,
+                      record='D%d' % i, pwait=('*side',))
             # weight gradient (side stream: only depends on dy_i and forward products).  Paired schedule: ... and the
             # weight-gradient starts when it is done, sharing the chip with the HBM-bound BatchNorm backward of the
             # next layer only.
@@ -886,7 +960,8 @@ class UNetBank:
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
-            ntd = lib.vv_wino_ntiles(B, m.H) if self.wino else lib.vv_conv_ntiles2(B, m.H, m.H, L.CONV3, dgrad_flags(m.idx))
+            ntd = lib.vv_wino44_ntiles(B, m.H) if self._w44(B, m, True) else lib.vv_wino_ntiles(B, m.H) if self.wino else \
+                lib.vv_conv_ntiles2(B, m.H, m.H, L.CONV3, dgrad_flags(m.idx))
             P.add(lib.vv_bias_from_partials, (Ga, m.cin, ntd, skipc, co, ws.dstats.data_ptr(), ntd * 2 * m.cin)
                   + self._g('t%d.b' % u), 'convT_bias%d' % u)
             y = ws.y[sidx]

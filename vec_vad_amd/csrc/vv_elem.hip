@@ -1393,6 +1393,7 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
   // VV_BNBWD_PARTIALS_PER_TILE: ... by the Winograd data-gradient launch that produced dA (one block per pixel tile)
   const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B
                    : (p->flags & VV_BNBWD_PARTIALS_PER_TILE) ? vv_wino_ntiles(p->B, p->H)
+                   : (p->flags & VV_BNBWD_PARTIALS_PER_TILE44) ? vv_wino44_ntiles(p->B, p->H)
                    : (p->flags & VV_BNBWD_PARTIALS_PER_CTILE) ? vv_conv_ntiles(p->B, p->H, p->W) : bn_nblk_of(p);
   if (nblk <= 0) return VV_ERR_BAD_ARG;
   const int nblk_apply = bn_nblk_of(p);

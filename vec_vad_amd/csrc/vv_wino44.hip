@@ -9,20 +9,30 @@
 // is a few 1e-6 of the tensor's maximum from the direct convolution (F(2x2): a few 1e-7); what that does to the 1e-3 bars of a
 // training trajectory was measured before this kernel was written (profiles/r05_wino44_numerics.txt, tests/numerics_wino44.py).
 //
-// One workgroup = 384 threads = 6 waves = 32 tiles (512 output pixels) x 32 output channels of one UNet; wave = xi (0..5), its six
-// GEMMs (nu = 0..5) live in 96 accumulator registers; two workgroups per CU = three waves per SIMD (<= 168 registers per lane).
+// A group of 384 threads = 6 waves works on 32 tiles (512 output pixels) x 32 output channels of one UNet; wave = xi (0..5), its six
+// GEMMs (nu = 0..5) live in 96 accumulator registers, <= 168 registers per lane = three waves per SIMD.  A WORKGROUP is two such
+// groups on neighbouring pixel tiles (768 threads, separate LDS images, shared barriers): six waves land 2 + 2 + 1 + 1 on the four
+// SIMDs and a second six-wave workgroup did not fit beside them (measured: half the occupancy), twelve land 3 + 3 + 3 + 3.
 // Lane l owns tile l&31, channel half l>>5 (A operand) / output channel l&31 (B operand, result).
-//   * No two waves of a workgroup use the same filter taps: the transformed filter never touches LDS, each lane loads its taps as
+//   * No two waves of a group use the same filter taps: the transformed filter never touches LDS, each lane loads its taps as
 //     8-byte pieces straight from the L2-resident panel (vv_pack_wino44: [36][Kp/8][2 sub-steps][2 halves][N][2]) into the registers
-//     the MFMAs of the previous sub-step have just released.
+//     the two MFMAs of that tap have just released, one sub-step ahead.
 //   * An 8-channel chunk is multiplied in two sub-steps of 4 channels (lane half h: channels 4h+2s, 4h+2s+1), so that the input
-//     transform and the taps of a sub-step take 12 + 12 registers instead of 24 + 24.
-//   * The halo tile [NI][HH][HW] goes global -> registers -> LDS one chunk ahead with the producer's BatchNorm + ReLU applied on the
-//     way in (as in vv_wino.hip); LDS image: four planes (half, sub-step) of 8-byte slots, columns split by x mod 4 so that the 32
-//     tiles of a wave read 32 different bank pairs with one ds_read_b64 (row / image strides padded per level; checked at compile time).
+//     transform and the taps of a sub-step take 12 + 12 registers instead of 24 + 24.  The wave's row of B^T d B is a compile-time
+//     constant of the K loop (one copy of the loop per wave role): immediate LDS offsets, literal coefficients.
+//   * The halo tile [NI][HH][HW] goes global -> registers -> LDS with the producer's BatchNorm + ReLU applied on the way in (as in
+//     vv_wino.hip), requested in the middle of the chunk before; LDS image: four planes (half, sub-step) of 8-byte slots, columns
+//     split by x mod 4 so that the 32 tiles of a wave read 32 different bank pairs (row / image strides padded per level; checked at
+//     compile time).
 //   * Epilogue: every wave applies the column half of A^T . A to its xi; the six waves meet in LDS (two rounds of eight accumulator
 //     registers) and finish (register, output-row pair) units: bias, ReLU (eval), NHWC buffer stores, BatchNorm sum / sum of squares
 //     or the fused first pass of the consumer's BatchNorm backward -- the same contract as wino_conv_kernel.
+// Where it stands (round 5, profiles/README.md): results agree with the direct kernel / float64 to <= 1.4e-5 of the tensor maximum
+// on every level (tests/test_gpu_wino44.py); matrix pipe busy 0.33 - 0.41 (F(2x2): 0.6) -- per MFMA it issues ~10 other instructions
+// (F(2x2): ~4) -- so it is faster than F(2x2) only on the 16x16-level launches with >= 64 input channels and a few others (-12 ..
+// -19 %), +0.65 % on the Net4 step; with those launches routed to it the full-size gradient test's calibrated bar (3 x the fp32
+// reference's own distance from float64) is exceeded.  It is therefore NOT on the default path: UNetBank routes to it only with
+// VV_WINO44=1 (policy) / all.
 #include <type_traits>
 #include "vv_common.h"
 // VV_EXP4 (compile-time bit mask, default 0; any other value computes WRONG results): 1 no MFMAs, 2 no halo loads, 4 no tap reloads,
@@ -32,11 +42,12 @@
 #endif
 namespace {
 
-constexpr int W4N = 384;               // threads per workgroup: one wave per xi
+constexpr int W4N = 384;               // threads per sub-group: one wave per xi
+constexpr int W4G = 2;                 // sub-groups (pixel tiles) per workgroup -- see the kernel's header
 constexpr int W4T = 32;                // tiles per workgroup
 constexpr int SB4_MASK = 0x386;        // may cross a scheduling barrier: VALU, SALU, LDS -- not MFMA, not VMEM
 
-// LDS hand-over between the waves of a workgroup WITHOUT the vector-memory drain a __syncthreads() can carry (DMAs and tap loads stay
+// LDS hand-over between the waves of a workgroup WITHOUT the vector-memory drain a __syncthreads() can carry (halo and tap loads stay
 // in flight across it); the empty asm keeps the compiler from lifting later LDS reads above the barrier
 __device__ __forceinline__ void vv_lds_barrier4() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -76,7 +87,7 @@ struct W4Geo {
 static_assert(W4Geo<32>::ok() && W4Geo<16>::ok() && W4Geo<8>::ok() && W4Geo<4>::ok(), "LDS image: bank conflicts or overlap");
 
 template <int H_>
-__global__ void __launch_bounds__(W4N, 3)
+__global__ void __launch_bounds__(W4N * W4G, 3)
 wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = W4Geo<H_>;
   constexpr int TPI = G_::TPI, TPW = G_::TPW, NI = G_::NI, PARTS = G_::PARTS, HH = G_::HH, HW = G_::HW, HWQ = G_::HWQ;
@@ -85,23 +96,31 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   constexpr int HY0 = PARTS == 1 ? 1 : 0, HR = PARTS == 1 ? HH - 2 : HH;      // halo rows that can lie inside an image
   constexpr int NITEMS = NI * HR * H_ * Q;
   constexpr int NIT = (NITEMS + W4N - 1) / W4N;
-  constexpr int STG8 = 0;
   constexpr int HALO8 = 4 * PLANE;                         // 8-byte slots of the halo image
   constexpr int EX8 = 6 * 8 * 64 * 2;                      // epilogue exchange: [wave][8 regs][64 lanes] float4
-  constexpr int L8 = STG8 + HALO8 > EX8 ? STG8 + HALO8 : EX8;
-  __shared__ v2f lds8[L8 + 6 * 32 + 256];                  // + [2][6 waves][32] BatchNorm partials + [2][<= 256] scale / shift of the input's BatchNorm
+  constexpr int L8 = HALO8 > EX8 ? HALO8 : EX8;
+  // A workgroup is TWO such six-wave groups on neighbouring pixel tiles of one (UNet, N tile), each with its own LDS image; they
+  // share nothing but the barriers.  Why: as workgroups of their own only one fitted a CU (measured: half the expected occupancy,
+  // matrix pipe busy 0.31) -- six waves land 2 + 2 + 1 + 1 on the four SIMDs and a second set of six does not fit the register file
+  // beside them; twelve waves of one workgroup land 3 + 3 + 3 + 3.
+  __shared__ v2f lds_all[W4G][L8 + 6 * 32 + 256];          // + [2][6 waves][32] BatchNorm partials + [2][<= 256] scale / shift of the input's BatchNorm
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int sg = wv / 6;
+  v2f* const lds8 = lds_all[sg];
   float* lds = reinterpret_cast<float*>(lds8);
-  v2f* const halo = lds8 + STG8;
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds8;
+  v2f* const halo = lds8;
 
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
   const int nn = w % NN; w /= NN;      // the N tiles of one pixel tile are neighbours in launch order: they share the halo in L2
-  const int pt = w % NT;
-  const int g = w / NT;
+  const int NTP = (NT + W4G - 1) / W4G;
+  const int pt_ = (w % NTP) * W4G + sg;
+  const bool live = pt_ < NT;          // (odd tile count: the last workgroup's second group repeats the last tile and writes nothing)
+  const int pt = live ? pt_ : NT - 1;
+  const int g = w / NTP;
 
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x - sg * W4N, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int xi = wv - sg * 6;
   const int img0 = (pt / PARTS) * NI, part = pt % PARTS;
   const int y0 = part * (4 * G_::TROWS) - 1;               // conv-input row of halo row 0 (column origin is -1)
   const VVSrc s = vv_make_src(p, g, H_, H_);
@@ -112,10 +131,11 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   // ---- halo staging.  Items = (pixel, channel quad) of the pixels that can lie inside an image: the halo columns 0 and HW - 1
   //      (every workgroup spans the image width) and, where a workgroup spans the image height, the halo rows 0 and HH - 1 are zero
   //      padding for every chunk -- zeroed once, never written again (three items per thread on every level).  An item travels
-  //      global -> LDS landing zone by DMA (buffer_load_dwordx4 ... lds: no staging registers -- 96 accumulators leave no room for
-  //      them at three waves per SIMD), and from there, with the producer's BatchNorm + ReLU applied, into the halo image by the lane
-  //      that transferred it (own counter: no barrier between landing and that pass).  Per item one packed word = image slot << 16 |
-  //      pixel offset inside the tile; the producer's scale / shift of every input channel wait in LDS.
+  //      global -> registers -> LDS like in vv_wino.hip (raw buffer loads, out-of-image items out of range, the producer's BatchNorm +
+  //      ReLU on the way into LDS), with fewer registers held across the MFMA phase: per item ONE packed word = image slot << 16 |
+  //      pixel offset inside the tile, buffer offsets rebuilt per chunk; the producer's scale / shift of every input channel wait in
+  //      LDS instead of in eight registers.  (An LDS-DMA landing zone was built and dropped: with it the tap loads had to become
+  //      inline asm with hand-counted waits, and the compiler copies / spills a register it believes valid while the load is in flight.)
   unsigned valid = 0;
   unsigned itm[NIT];
   const int tile = (img0 * H_ + y0) * H_ - 1;
@@ -215,12 +235,10 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   // wave role): the rows of B^T become immediate LDS offsets and literal constants --
   //   0: 4 d0 - 5 d2 + d4      1: -4 d1 - 4 d2 + d3 + d4      2: 4 d1 - 4 d2 - d3 + d4
   //   3: -2 d1 - d2 + 2 d3 + d4      4: 2 d1 - d2 - 2 d3 + d4      5: 4 d1 - 5 d3 + d5
-  // NEWER = vector-memory instructions this wave issued after the sub-step's six tap loads and before its first MFMA (the DMAs of
-  // the next chunk's halo): tap n may be used once at most 5 - n + NEWER instructions are outstanding.
   // LAST: the sub-step that ends the K loop loads nothing (a load still in flight into a register the compiler considers dead would
   // land in whatever the epilogue keeps there).
-  auto substep = [&](const auto XI_, const int step, const auto SUB_, const auto first, const auto NEWER_, const auto LAST_) {
-    constexpr int XI = decltype(XI_)::value, sub = decltype(SUB_)::value, NEWER = decltype(NEWER_)::value;
+  auto substep = [&](const auto XI_, const int step, const auto SUB_, const auto first, const auto LAST_) {
+    constexpr int XI = decltype(XI_)::value, sub = decltype(SUB_)::value;
     constexpr bool LAST = decltype(LAST_)::value;
     const int nxt = step + 1;
     // (the patch origin is made opaque per sub-step: left to itself the compiler hoists eight or nine derived LDS addresses out of the
@@ -271,10 +289,11 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
     }
 #define W4_Y(n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[n].y, acc[n], 0, 0, 0);
 #endif
-    W4_X(0) W4_X(1) W4_X(2) W4_X(3) W4_X(4) W4_X(5)
-    __builtin_amdgcn_sched_barrier(SB4_MASK);
+    // nu-major: both k steps of a tap back to back, then the tap's reload -- every tap is requested ten MFMAs + one input transform
+    // ahead of its next use (k-step-major order left the last tap four MFMAs: every sub-step waited for an L2 round trip)
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
+      W4_X(n)
       W4_Y(n)
       __builtin_amdgcn_sched_barrier(SB4_MASK);
       if constexpr (!LAST) u[n] = load_u(nxt, n);
@@ -285,17 +304,16 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   };
   const std::true_type yes{};
   const std::false_type no{};
-  const std::integral_constant<int, 0> sub0{}, none{};
+  const std::integral_constant<int, 0> sub0{};
   const std::integral_constant<int, 1> sub1{};
-  const std::integral_constant<int, NIT> dmas{};
   // the K loop of one wave role (every role passes the same barriers).  Order of a wave's vector-memory instructions (they return in
-  // order, one counter): the taps of sub-step 1 go out during sub-step 0, THEN the halo DMAs of the next chunk, then -- during
-  // sub-step 1 -- the taps of the next chunk's sub-step 0: the waits in front of sub-step 1's MFMAs leave the DMAs in flight, the
-  // wait in front of the landing-zone pass (six taps younger) leaves the taps in flight.
+  // order, one counter): the taps of sub-step 1 go out during sub-step 0, THEN the halo loads of the next chunk, then -- during
+  // sub-step 1 -- the taps of the next chunk's sub-step 0: the compiler's counted waits in front of sub-step 1's MFMAs leave the
+  // halo loads in flight, the wait in front of commit() (six taps younger) leaves the taps in flight.
   auto kloop = [&](const auto XI_) {
     if (KQ == 1) {
-      substep(XI_, 0, sub0, yes, none, no);
-      substep(XI_, 1, sub1, no, none, yes);
+      substep(XI_, 0, sub0, yes, no);
+      substep(XI_, 1, sub1, no, yes);
       return;
     }
     auto next_chunk = [&](const int kq) {
@@ -303,19 +321,19 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
       commit(kq * CK);
       vv_lds_barrier4();
     };
-    substep(XI_, 0, sub0, yes, none, no);
+    substep(XI_, 0, sub0, yes, no);
     issue(CK);
-    substep(XI_, 1, sub1, no, dmas, no);
+    substep(XI_, 1, sub1, no, no);
     // (the last chunk is peeled: one loop body, no branch inside it -- with one the accumulators were copied and spilled at the join)
     for (int kq = 1; kq < KQ - 1; ++kq) {
       next_chunk(kq);
-      substep(XI_, 2 * kq, sub0, no, none, no);
+      substep(XI_, 2 * kq, sub0, no, no);
       issue((kq + 1) * CK);
-      substep(XI_, 2 * kq + 1, sub1, no, dmas, no);
+      substep(XI_, 2 * kq + 1, sub1, no, no);
     }
     next_chunk(KQ - 1);
-    substep(XI_, 2 * KQ - 2, sub0, no, none, no);
-    substep(XI_, 2 * KQ - 1, sub1, no, none, yes);
+    substep(XI_, 2 * KQ - 2, sub0, no, no);
+    substep(XI_, 2 * KQ - 1, sub1, no, yes);
   };
 
   issue(0);
@@ -384,7 +402,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
       const int t2 = 8 * (i >> 2) + (i & 3);
       const int im = t2 / TPW, rem = t2 % TPW;
       const int oy = 4 * (part * G_::TROWS + rem / TPI) + 2 * rp, ox = 4 * (rem % TPI);
-      jok[k] = un < 16 && (img0 + im + HIMG * half) < p.B;
+      jok[k] = live && un < 16 && (img0 + im + HIMG * half) < p.B;
       so_[k] = ((img0 + im) * H_ + oy) * H_ + ox;                    // pixel index of the unit's first output (half 0)
       if (bnf) {
 #pragma unroll
@@ -468,7 +486,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
       sp[(6 + xi) * 32 + l31] = s2;
     }
     __syncthreads();
-    if (tid < 32) {
+    if (tid < 32 && live) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -549,9 +567,9 @@ int launch_wino44(const vv_conv_params* p, hipStream_t st) {
   using G_ = W4Geo<H_>;
   const int NT = ((p->B + G_::NI - 1) / G_::NI) * G_::PARTS;
   const int NN = p->Cout / 32;
-  const int total = p->G * NN * NT;
+  const int total = p->G * NN * ((NT + W4G - 1) / W4G);
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((wino44_conv_kernel<H_>), dim3(nper * 8), dim3(W4N), 0, st, *p, NT, NN, total, nper);
+  VV_LAUNCH((wino44_conv_kernel<H_>), dim3(nper * 8), dim3(W4N * W4G), 0, st, *p, NT, NN, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
