@@ -113,7 +113,14 @@ class _Buf:
         return L.View(self.t.data_ptr(), 0, self.cs, coff)
 
     def nchw(self, c0=0, c1=None):
-        return self.t[..., c0:(self.C if c1 is None else c1)].permute(0, 3, 1, 2).contiguous()
+        c1 = self.C if c1 is None else c1
+        if self.cs == 4 and c0 == 0 and self.t.is_cuda:
+            # (the two-channel flow maps: a first-party launch, so a captured forward holds no framework kernel)
+            out = torch.empty(self.B, c1, self.H, self.W, device=self.t.device, dtype=torch.float32)
+            L.check(L.lib().vv_out4_to_nchw(self.B, self.H * self.W, c1, self.t.data_ptr(), out.data_ptr(), c1, 0,
+                                            torch.cuda.current_stream(self.t.device).cuda_stream), 'out4_to_nchw')
+            return out
+        return self.t[..., c0:c1].permute(0, 3, 1, 2).contiguous()
 
 
 class _Runner:
