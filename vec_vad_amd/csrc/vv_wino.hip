@@ -24,6 +24,7 @@
 //   direct kernel.
 // History (profiles/README.md, round 2): the first form held two xi per wave (128 accumulators, 64 tiles, filter panel staged
 // through LDS, two workgroups per CU); this one is 11 % faster over the 27 launches of a Net4 step.
+#include <cstdlib>
 #include <type_traits>
 #include "vv_common.h"
 // VV_EXPM (compile-time bit mask, default 0): elimination switches used to find where the time goes (profiles/README.md) --
@@ -68,8 +69,12 @@ struct WGeo {
   static constexpr int HH = 2 * TROWS + 2, HW = H_ + 2;
 };
 
-template <int H_>
-__global__ void __launch_bounds__(WN, 3)
+// NB = N tiles (32 output channels each) per workgroup.  NB = 2 (round 5): a wave keeps eight GEMMs (128 accumulators, two workgroups per
+// CU) and the input transform, the patch reads and the halo staging of a chunk serve 32 MFMAs instead of 16 -- an fp32 MFMA holds the
+// SIMD's issue port, so a tile costs 64 cycles per MFMA plus ~5 per other instruction of every wave: fewer other
+// instructions per MFMA is the only lever.  Same arithmetic per output in the same order: bit-identical to NB = 1.
+template <int H_, int NB>
+__global__ void __launch_bounds__(WN, NB == 2 ? 2 : 3)
 wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = WGeo<H_>;
   constexpr int TPI = G_::TPI, TPW = G_::TPW, NI = G_::NI, PARTS = G_::PARTS, HH = G_::HH, HW = G_::HW, HWH = HW / 2;
@@ -96,10 +101,10 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   const int y0 = part * (2 * G_::TROWS) - 1;               // conv-input row of halo row 0 (column origin is -1)
   const VVSrc s = vv_make_src(p, g, H_, H_);
   const int Cout = p.Cout, CinP = p.CinP, KQ = CinP >> 3;
-  const int co0 = nn * 32;
+  const int co0 = nn * 32 * NB;
   const float* __restrict__ wg = p.w + (int64_t)g * p.w_gstride;
 
-  // ---- halo staging set-up (as in wino_conv_kernel)
+  // ---- halo staging set-up
   float4 r[NIT];
   int slot[NIT];
   unsigned valid = 0;
@@ -167,8 +172,8 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         lds4[slot[k]] = v;
       }
   };
-  auto load_u = [&](const int c0, const int n) -> v4f {
-    return __builtin_amdgcn_raw_buffer_load_b128(rsW, bvo, bxi + n * bnu + (c0 >> 3) * 2 * Cout * 16, 0);
+  auto load_u = [&](const int c0, const int n, const int nb) -> v4f {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsW, bvo + nb * 512u, bxi + n * bnu + (c0 >> 3) * 2 * Cout * 16, 0);
   };
 
   // ---- this lane's tile and its patch origin in LDS
@@ -182,8 +187,8 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   const int a1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), a2 = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
   const float sg = xi == 1 ? 1.f : -1.f;
 
-  v16f acc[4];
-  v4f u[4];
+  v16f acc[NB][4];
+  v4f u[NB][4];
   // Order of the memory instructions (loads return in order, one counter): the halo loads of the NEXT chunk are issued at the
   // start of a chunk, before this chunk's tap loads; each tap load goes out right after the four MFMAs that read the registers
   // it overwrites, one chunk ahead of its use.  sched_barrier keeps the compiler from sinking the loads to their first use
@@ -208,32 +213,37 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     __builtin_amdgcn_sched_barrier(SB_MASK);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-#if (VV_EXPM & 1)
-      if (decltype(first)::value)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-      acc[n][0] += V[n].x * u[n].x + V[n].y * u[n].y + V[n].z * u[n].z + V[n].w * u[n].w;
+      for (int nb = 0; nb < NB; ++nb) {
+#if (VV_EXPM & 1)
+        if (decltype(first)::value)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[nb][n][i] = 0.f;
+        acc[nb][n][0] += V[n].x * u[nb][n].x + V[n].y * u[nb][n].y + V[n].z * u[nb][n].z + V[n].w * u[nb][n].w;
 #else
-      if constexpr (decltype(first)::value) {   // the accumulators start from the instruction's inline-constant 0
-        const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[n].x, z, 0, 0, 0);
-      } else {
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[n].x, acc[n], 0, 0, 0);
-      }
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[n].y, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[n].z, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[n].w, acc[n], 0, 0, 0);
+        if constexpr (decltype(first)::value) {   // the accumulators start from the instruction's inline-constant 0
+          const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[nb][n].x, z, 0, 0, 0);
+        } else {
+          acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[nb][n].x, acc[nb][n], 0, 0, 0);
+        }
+        acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[nb][n].y, acc[nb][n], 0, 0, 0);
+        acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[nb][n].z, acc[nb][n], 0, 0, 0);
+        acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[nb][n].w, acc[nb][n], 0, 0, 0);
 #endif
 #if !(VV_EXPM & 4)
-      u[n] = load_u(knext, n);
+        u[nb][n] = load_u(knext, n, nb);
 #endif
-      __builtin_amdgcn_sched_barrier(SB_MASK);
+        __builtin_amdgcn_sched_barrier(SB_MASK);
+      }
     }
   };
 
   issue(0);
 #pragma unroll
-  for (int n = 0; n < 4; ++n) u[n] = load_u(0, n);
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) u[nb][n] = load_u(0, n, nb);
   commit();
   __syncthreads();
   const std::true_type yes{};
@@ -258,112 +268,117 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   // ---- epilogue.  Columns in registers:  T[0] = M0 + M1 + M2,  T[1] = M1 - M2 - M3  (M = this wave's xi, indexed by nu);
   //      rows across the four waves through LDS:  Y[0] = T(xi0) + T(xi1) + T(xi2),  Y[1] = T(xi1) - T(xi2) - T(xi3).
   //      Wave w finishes accumulator registers 4w .. 4w+3 = tiles 8w .. 8w+7 (both rows): 16 buffer stores per wave.
-  __syncthreads();                      // all MFMA-phase LDS reads done: LDS becomes the exchange buffer
-  v2f* ex2 = reinterpret_cast<v2f*>(lds) + lane;
+  // (one N tile after the other through the same exchange region)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const v2f t = {acc[0][i] + acc[1][i] + acc[2][i], acc[1][i] - acc[2][i] - acc[3][i]};
-    ex2[(xi * 16 + i) * 64] = t;
-  }
-  constexpr int LP = TPI > 4 ? 8 : (TPI == 4 ? 2 * H_ : H_ * H_);        // pixels between the two lane halves (tile + 4)
-  // Fused first pass of the consumer's BatchNorm backward (vv_conv_params.bn_partial): this wave's 16 values of z go out now and
-  // land while the four xi rows meet in LDS.
-  const bool bnf = p.bn_partial != nullptr;
-  float zq[4][4];
-  float bna = 0.f, bnb = 0.f, bni = 0.f, bnm = 0.f;
-  bool jok[4];
+  for (int nb = 0; nb < NB; ++nb) {
+    const int cob = co0 + nb * 32;
+    __syncthreads();                    // all MFMA-phase LDS reads (nb = 0) / the previous N tile's exchange and sums (nb = 1) are done
+    v2f* ex2 = reinterpret_cast<v2f*>(lds) + lane;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t2 = xi * 8 + j;
-    jok[j] = img0 + t2 / TPW + (TPW == 4 ? half : 0) < p.B;
-  }
-  if (bnf) {
-    const int64_t bo = (int64_t)g * p.bn_gstride + co0 + l31;
-    bna = p.bn_a[bo]; bnb = p.bn_b[bo]; bni = p.bn_invstd[bo];
-    bnm = -p.bn_mean[bo] * bni;                                            // xhat = z invstd - mean invstd
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.bn_z + (int64_t)g * p.bn_z_gstride), 0, 0x7FFFFFFF, 0x00020000);
-    const int vz = (half * LP * Cout + co0 + l31) * 4;
+    for (int i = 0; i < 16; ++i) {
+      const v2f t = {acc[nb][0][i] + acc[nb][1][i] + acc[nb][2][i], acc[nb][1][i] - acc[nb][2][i] - acc[nb][3][i]};
+      ex2[(xi * 16 + i) * 64] = t;
+    }
+    constexpr int LP = TPI > 4 ? 8 : (TPI == 4 ? 2 * H_ : H_ * H_);        // pixels between the two lane halves (tile + 4)
+    // Fused first pass of the consumer's BatchNorm backward (vv_conv_params.bn_partial): this wave's 16 values of z go out now and
+    // land while the four xi rows meet in LDS.
+    const bool bnf = p.bn_partial != nullptr;
+    float zq[4][4];
+    float bna = 0.f, bnb = 0.f, bni = 0.f, bnm = 0.f;
+    bool jok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t2 = xi * 8 + j;
-      const int im = t2 / TPW, rem = t2 % TPW;
-      const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
-      const int so = (((img0 + im) * H_ + oy) * H_ + ox) * Cout * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        zq[j][q] = jok[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, vz, so + ((q >> 1) * H_ + (q & 1)) * Cout * 4, 0))
-                          : 0.f;
+      jok[j] = img0 + t2 / TPW + (TPW == 4 ? half : 0) < p.B;
     }
-  }
-  __syncthreads();
-  const float bias = p.bias ? p.bias[(int64_t)g * p.bias_gstride + co0 + l31] : 0.f;
-  const float lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();     // VV_CONV_RELU: BatchNorm folded into the filter (eval)
-  const int ocs = p.out.cstride;
-  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
-      p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff, 0, 0x7FFFFFFF, 0x00020000);
-  const int vo = (half * LP * ocs + co0 + l31) * 4;
-  const v2f* exw = ex2 + xi * 4 * 64;
-  v2f s12 = {0.f, 0.f}, q12 = {0.f, 0.f};
+    if (bnf) {
+      const int64_t bo = (int64_t)g * p.bn_gstride + cob + l31;
+      bna = p.bn_a[bo]; bnb = p.bn_b[bo]; bni = p.bn_invstd[bo];
+      bnm = -p.bn_mean[bo] * bni;                                            // xhat = z invstd - mean invstd
+      const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.bn_z + (int64_t)g * p.bn_z_gstride), 0, 0x7FFFFFFF, 0x00020000);
+      const int vz = (half * LP * Cout + cob + l31) * 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t2 = xi * 8 + j;                                   // wave-uniform part of the tile index
-    const int im = t2 / TPW, rem = t2 % TPW;
-    const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
-    if (jok[j]) {
-      const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
-      v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
-      // ReLU of the folded eval path (lo = 0; train mode: lo = -inf, a no-op).  Compare + select, not v_max: v_max_f32 returns the
-      // non-NaN operand, which would turn a diverged model's NaN into 0 / -inf where torch's ReLU propagates it
-      ya[0] = ya[0] < lo ? lo : ya[0]; ya[1] = ya[1] < lo ? lo : ya[1];
-      yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
-      const int so = (((img0 + im) * H_ + oy) * H_ + ox) * ocs * 4;
-      const float a0 = ya[0], a1v = ya[1], b0 = yb[0], b1 = yb[1];
-#if (VV_EXPM & 8)
-      if (a0 + a1v + b0 + b1 == 123.456f)
-#endif
-      {
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0), rsO, vo, so, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a1v), rsO, vo, so + ocs * 4, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b0), rsO, vo, so + H_ * ocs * 4, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b1), rsO, vo, so + (H_ + 1) * ocs * 4, 0);
+      for (int j = 0; j < 4; ++j) {
+        const int t2 = xi * 8 + j;
+        const int im = t2 / TPW, rem = t2 % TPW;
+        const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
+        const int so = (((img0 + im) * H_ + oy) * H_ + ox) * Cout * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          zq[j][q] = jok[j] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, vz, so + ((q >> 1) * H_ + (q & 1)) * Cout * 4, 0))
+                            : 0.f;
       }
-      if (bnf) {
-        // dz = dA [a z + b > 0];  partial sums of dz and dz * xhat  (bn_bwd_reduce_kernel<.., 0>, fused)
-        const v2f za = {zq[j][0], zq[j][1]}, zb = {zq[j][2], zq[j][3]};
-        const v2f pa = bna * za + bnb, pb = bna * zb + bnb;
-        const v2f da = {pa.x > 0.f ? ya.x : 0.f, pa.y > 0.f ? ya.y : 0.f}, db = {pb.x > 0.f ? yb.x : 0.f, pb.y > 0.f ? yb.y : 0.f};
-        s12 += da + db;
-        q12 = __builtin_elementwise_fma(da, bni * za + bnm, q12);
-        q12 = __builtin_elementwise_fma(db, bni * zb + bnm, q12);
-      } else {
-        s12 += ya + yb;
-        q12 = __builtin_elementwise_fma(ya, ya, q12);
-        q12 = __builtin_elementwise_fma(yb, yb, q12);
-      }
-    }
-  }
-  float* const sout = bnf ? p.bn_partial : p.stats;
-  if (sout) {
-    float s1 = s12.x + s12.y, s2 = q12.x + q12.y;
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    float* sp = lds + L4 * 4;
-    if (half == 0) {
-      sp[xi * 32 + l31] = s1;
-      sp[(4 + xi) * 32 + l31] = s2;
     }
     __syncthreads();
-    if (tid < 32) {
-      float t1 = 0.f, t2 = 0.f;
+    const float bias = p.bias ? p.bias[(int64_t)g * p.bias_gstride + cob + l31] : 0.f;
+    const float lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();     // VV_CONV_RELU: BatchNorm folded into the filter (eval)
+    const int ocs = p.out.cstride;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+        p.out.ptr + (int64_t)g * p.out.gstride + p.out.coff, 0, 0x7FFFFFFF, 0x00020000);
+    const int vo = (half * LP * ocs + cob + l31) * 4;
+    const v2f* exw = ex2 + xi * 4 * 64;
+    v2f s12 = {0.f, 0.f}, q12 = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        t1 += sp[k * 32 + tid];
-        t2 += sp[(4 + k) * 32 + tid];
+    for (int j = 0; j < 4; ++j) {
+      const int t2 = xi * 8 + j;                                   // wave-uniform part of the tile index
+      const int im = t2 / TPW, rem = t2 % TPW;
+      const int oy = 2 * (part * G_::TROWS + rem / TPI), ox = 2 * (rem % TPI);
+      if (jok[j]) {
+        const v2f t0 = exw[(0 * 16 + j) * 64], t1 = exw[(1 * 16 + j) * 64], t2v = exw[(2 * 16 + j) * 64], t3 = exw[(3 * 16 + j) * 64];
+        v2f ya = t0 + t1 + t2v + bias, yb = t1 - t2v - t3 + bias;
+        // ReLU of the folded eval path (lo = 0; train mode: lo = -inf, a no-op).  Compare + select, not v_max: v_max_f32 returns the
+        // non-NaN operand, which would turn a diverged model's NaN into 0 / -inf where torch's ReLU propagates it
+        ya[0] = ya[0] < lo ? lo : ya[0]; ya[1] = ya[1] < lo ? lo : ya[1];
+        yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
+        const int so = (((img0 + im) * H_ + oy) * H_ + ox) * ocs * 4;
+        const float a0 = ya[0], a1v = ya[1], b0 = yb[0], b1 = yb[1];
+  #if (VV_EXPM & 8)
+        if (a0 + a1v + b0 + b1 == 123.456f)
+  #endif
+        {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0), rsO, vo, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a1v), rsO, vo, so + ocs * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b0), rsO, vo, so + H_ * ocs * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b1), rsO, vo, so + (H_ + 1) * ocs * 4, 0);
+        }
+        if (bnf) {
+          // dz = dA [a z + b > 0];  partial sums of dz and dz * xhat  (bn_bwd_reduce_kernel<.., 0>, fused)
+          const v2f za = {zq[j][0], zq[j][1]}, zb = {zq[j][2], zq[j][3]};
+          const v2f pa = bna * za + bnb, pb = bna * zb + bnb;
+          const v2f da = {pa.x > 0.f ? ya.x : 0.f, pa.y > 0.f ? ya.y : 0.f}, db = {pb.x > 0.f ? yb.x : 0.f, pb.y > 0.f ? yb.y : 0.f};
+          s12 += da + db;
+          q12 = __builtin_elementwise_fma(da, bni * za + bnm, q12);
+          q12 = __builtin_elementwise_fma(db, bni * zb + bnm, q12);
+        } else {
+          s12 += ya + yb;
+          q12 = __builtin_elementwise_fma(ya, ya, q12);
+          q12 = __builtin_elementwise_fma(yb, yb, q12);
+        }
       }
-      float* st = sout + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
-      st[0] = t1;
-      st[Cout] = t2;
+    }
+    float* const sout = bnf ? p.bn_partial : p.stats;
+    if (sout) {
+      float s1 = s12.x + s12.y, s2 = q12.x + q12.y;
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      float* sp = lds + L4 * 4;
+      if (half == 0) {
+        sp[xi * 32 + l31] = s1;
+        sp[(4 + xi) * 32 + l31] = s2;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          t1 += sp[k * 32 + tid];
+          t2 += sp[(4 + k) * 32 + tid];
+        }
+        float* st = sout + ((int64_t)(g * NT + pt) * 2) * Cout + cob + tid;
+        st[0] = t1;
+        st[Cout] = t2;
+      }
     }
   }
 }
@@ -845,10 +860,22 @@ template <int H_>
 int launch_wino(const vv_conv_params* p, hipStream_t st) {
   using G_ = WGeo<H_>;
   const int NT = ((p->B + G_::NI - 1) / G_::NI) * G_::PARTS;
-  const int NN = p->Cout / 32;
+  // two N tiles per workgroup (two workgroups per CU) where that leaves whole rounds of 512 workgroups: at least two, the last one
+  // at least 90 % full; VV_WINO_NB=1 in the environment keeps one N tile everywhere (A/B switch, read once)
+  static const bool nb1 = [] { const char* e = getenv("VV_WINO_NB"); return e && e[0] == '1'; }();
+  bool two = !nb1 && p->Cout % 64 == 0;
+  if (two) {
+    const int64_t wgs = (int64_t)p->G * (p->Cout / 64) * NT;
+    const int64_t rounds = (wgs + 511) / 512;
+    two = wgs >= 1024 && wgs * 10 >= rounds * 512 * 9;
+  }
+  const int NN = p->Cout / (two ? 64 : 32);
   const int total = p->G * NN * NT;
   const int nper = (total + 7) / 8;
-  VV_LAUNCH((wino_conv_kernel<H_>), dim3(nper * 8), dim3(WN), 0, st, *p, NT, NN, total, nper);
+  if (two)
+    VV_LAUNCH((wino_conv_kernel<H_, 2>), dim3(nper * 8), dim3(WN), 0, st, *p, NT, NN, total, nper);
+  else
+    VV_LAUNCH((wino_conv_kernel<H_, 1>), dim3(nper * 8), dim3(WN), 0, st, *p, NT, NN, total, nper);
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
