@@ -992,3 +992,57 @@ def test_grouped_slab_reduction_bitwise_equal_to_per_layer_kernel(monkeypatch, p
         res.append(bank.grads.clone())
     assert torch.equal(res[0], res[1])
     assert float(res[0].abs().max()) > 0
+
+
+def test_wino_two_n_tiles_per_workgroup_bitwise_equal():
+    """wino_conv_kernel<H, 2> (round 5: 64 output channels per workgroup where the grid stays in whole rounds) against the one-N-tile form
+    (VV_WINO_NB=1, read once per process: a child process computes the reference digest) on launch shapes the policy takes -- forward
+    with BatchNorm+ReLU on load, bias, BatchNorm partial sums; data gradient with the fused BatchNorm-backward sums: bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, hashlib, sys, torch
+sys.path.insert(0, %r)
+from vec_vad_amd import _lib as L
+lib = L.lib()
+st = torch.cuda.current_stream().cuda_stream
+h = hashlib.sha256()
+for (H, Cin, Cout, B, G, bnf) in ((8, 64, 128, 512, 2, False), (16, 64, 64, 256, 2, False), (8, 128, 128, 512, 2, True)):
+    g = torch.Generator(device='cpu').manual_seed(H * 131 + Cout)
+    x = torch.randn(G, B * H * H, Cin, generator=g).cuda()
+    w = (torch.randn(G, Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    bias = torch.randn(G, Cout, generator=g).cuda()
+    a = (torch.rand(G, Cin, generator=g) + 0.5).cuda()
+    b = (torch.randn(G, Cin, generator=g) * 0.2).cuda()
+    ent = (L.PackEntry * 1)(L.PackEntry(0, 0, 1 if bnf else 0, Cin, Cin, Cout))
+    tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).cuda()
+    wsrc = w.transpose(1, 2).contiguous() if bnf else w          # mode 1 reads W[co = k][ci = n]
+    pk = torch.zeros(G, 16 * Cin * Cout, device='cuda')
+    L.check(lib.vv_pack_wino(tab.data_ptr(), 1, G, wsrc.data_ptr(), wsrc[0].numel(), pk.data_ptr(), pk.stride(0), Cin * Cout, st), 'pack')
+    nt = lib.vv_wino_ntiles(B, H)
+    y = torch.zeros(G, B * H * H, Cout, device='cuda')
+    s_ = torch.zeros(G, nt, 2, Cout, device='cuda')
+    if bnf:
+        z = torch.randn(G, B * H * H, Cout, generator=g).cuda()
+        a2 = (torch.rand(G, Cout, generator=g) + 0.5).cuda(); b2 = (torch.randn(G, Cout, generator=g) * 0.2).cuda()
+        mean = (torch.randn(G, Cout, generator=g) * 0.1).cuda(); inv = (torch.rand(G, Cout, generator=g) + 0.5).cuda()
+        cp = L.ConvParams(L.CONV3, L.IN_PLAIN, G, B, H, H, Cin, Cin, Cout, L.view(x, Cin, 0, x.stride(0)), None, None, 0, L.NULL_VIEW, 0, 0,
+                          None, pk.data_ptr(), pk.stride(0), None, 0, L.view(y, Cout, 0, y.stride(0)), None,
+                          z.data_ptr(), z.stride(0), a2.data_ptr(), b2.data_ptr(), mean.data_ptr(), inv.data_ptr(), Cout, s_.data_ptr())
+    else:
+        cp = L.ConvParams(L.CONV3, L.IN_ACT, G, B, H, H, Cin, Cin, Cout, L.view(x, Cin, 0, x.stride(0)), a.data_ptr(), b.data_ptr(), Cin,
+                          L.NULL_VIEW, 0, 0, None, pk.data_ptr(), pk.stride(0), bias.data_ptr(), Cout, L.view(y, Cout, 0, y.stride(0)), s_.data_ptr())
+    L.check(lib.vv_conv_wino(C.byref(cp), st), 'conv')
+    torch.cuda.synchronize()
+    h.update(y.cpu().numpy().tobytes()); h.update(s_.cpu().numpy().tobytes())
+    assert float(y.abs().max()) > 0
+print('DIGEST', h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for nb in ('0', '1'):
+        env = dict(os.environ, VV_WINO_NB=nb)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith('DIGEST')][-1])
+    assert digests[0] == digests[1]
