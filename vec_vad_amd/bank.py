@@ -1059,24 +1059,30 @@ class UNetBank:
                                'are stale' % (fused, 'ran' if ran else 'did not run'))
         self.backward_plan(ws, ran).run(self._stream())
 
+    def _score_row_index(self, device):
+        """device index tensors of the raw / flow UNets' rows in ws.score, built once: indexing with a python list uploads it -- a
+        synchronous pageable copy that stalls the host behind the stream -- on every call"""
+        rows = getattr(self, '_score_rows', None)
+        if rows is None or rows[0].device != device:
+            units = self.units[self.g0:self.g0 + self.Ga]
+            mk = lambda role: torch.tensor([i for i, u in enumerate(units) if u.role == role], dtype=torch.long, device=device)
+            rows = self._score_rows = (mk('raw'), mk('of'))
+        return rows
+
     def losses(self, ws):
         """(loss_raw, loss_of) as device scalars from the per-cube squared errors (train.py:385-392)."""
         HWp = HW0 * HW0
         sc = ws.score
-        units = self.units[self.g0:self.g0 + self.Ga]
-        raw_rows = [i for i, u in enumerate(units) if u.role == 'raw']
-        of_rows = [i for i, u in enumerate(units) if u.role == 'of']
-        l_raw = sc[raw_rows].sum() / (ws.B * len(raw_rows) * RAW_C * HWp)
-        l_of = sc[of_rows].sum() / (ws.B * len(of_rows) * OF_C * HWp) if of_rows else None
+        raw_rows, of_rows = self._score_row_index(sc.device)
+        l_raw = sc.index_select(0, raw_rows).sum() / (ws.B * raw_rows.numel() * RAW_C * HWp)
+        l_of = sc.index_select(0, of_rows).sum() / (ws.B * of_rows.numel() * OF_C * HWp) if of_rows.numel() else None
         return l_raw, l_of
 
     def cube_scores(self, ws):
         """per-cube raw / flow squared-error sums ([B] each), train.py:421-426."""
-        units = self.units[self.g0:self.g0 + self.Ga]
-        raw_rows = [i for i, u in enumerate(units) if u.role == 'raw']
-        of_rows = [i for i, u in enumerate(units) if u.role == 'of']
-        r = ws.score[raw_rows].sum(0)
-        o = ws.score[of_rows].sum(0) if of_rows else None
+        rows = self._score_row_index(ws.score.device)
+        r = ws.score.index_select(0, rows[0]).sum(0)
+        o = ws.score.index_select(0, rows[1]).sum(0) if rows[1].numel() else None
         return r, o
 
     def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, grads=None):
