@@ -22,8 +22,8 @@
 //     constant of the K loop (one copy of the loop per wave role): immediate LDS offsets, literal coefficients.
 //   * The halo tile [NI][HH][HW] goes global -> registers -> LDS with the producer's BatchNorm + ReLU applied on the way in (as in
 //     vv_wino.hip), requested in the middle of the chunk before; LDS image: four planes (half, sub-step) of 8-byte slots, columns
-//     split by x mod 4 so that the 32 tiles of a wave read 32 different bank pairs (row / image strides padded per level; checked at
-//     compile time).
+//     split by x mod 4 and row / image strides padded per level so that the 16 lanes a ds_read2_b64 access services together hit 16
+//     different bank pairs (checked at compile time).
 //   * Epilogue: every wave applies the column half of A^T . A to its xi; the six waves meet in LDS (two rounds of eight accumulator
 //     registers) and finish (register, output-row pair) units: bias, ReLU (eval), NHWC buffer stores, BatchNorm sum / sum of squares
 //     or the fused first pass of the consumer's BatchNorm backward -- the same contract as wino_conv_kernel.
@@ -65,9 +65,12 @@ struct W4Geo {
   static constexpr int TROWS = TPW / TPI;                  // tile rows per part
   static constexpr int HH = 4 * TROWS + 2, HW = H_ + 2;
   static constexpr int HWQ = (HW + 3) / 4;                 // slots of one (x mod 4) column class per halo row
-  // 8-byte slots per halo row / per image, padded so that the 32 tiles of a wave hit 32 different bank pairs (ok() below)
-  static constexpr int ROW = H_ == 32 ? 38 : (H_ == 16 ? 21 : (H_ == 8 ? 12 : 8));
-  static constexpr int IMG = H_ == 32 ? HH * ROW : (H_ == 16 ? 400 : (H_ == 8 ? 130 : 49));
+  // 8-byte slots per halo row / per image, padded against LDS bank conflicts of the patch reads.  The compiler pairs them into
+  // ds_read2_b64, which is serviced in groups of 16 consecutive lanes over 32 banks ((a / 4) mod 32): the 16 tiles of such a group
+  // must lie in 16 different slots mod 16 (ok() below).  (The first layout was padded for ds_read_b64's 32-lane / 64-bank rule: on the
+  // 8x8 level SQ_LDS_BANK_CONFLICT was 0.47 of the LDS-active cycles.)
+  static constexpr int ROW = H_ == 32 ? 38 : (H_ == 16 ? 21 : (H_ == 8 ? 14 : 8));
+  static constexpr int IMG = H_ == 32 ? HH * ROW : (H_ == 16 ? 400 : (H_ == 8 ? 146 : 49));
   static constexpr int PLANE = NI * IMG;
   static constexpr int tile_slot(const int l) {            // lane-dependent part of a patch read's slot
     const int tim = l / TPW, rem = l % TPW;
@@ -75,11 +78,13 @@ struct W4Geo {
   }
   static constexpr bool ok() {
     if (ROW < 4 * HWQ || IMG < HH * ROW) return false;
-    unsigned seen = 0;
-    for (int l = 0; l < 32; ++l) {
-      const unsigned bit = 1u << (tile_slot(l) & 31);
-      if (seen & bit) return false;
-      seen |= bit;
+    for (int l0 = 0; l0 < 32; l0 += 16) {
+      unsigned seen = 0;
+      for (int l = l0; l < l0 + 16; ++l) {
+        const unsigned bit = 1u << (tile_slot(l) & 15);
+        if (seen & bit) return false;
+        seen |= bit;
+      }
     }
     return true;
   }
