@@ -224,7 +224,7 @@ def build_net(model, precision, dev):
 def conv_roofline(bank, B, per, precision, overlap, traffic):
     """roofline object of the 3x3-conv family from HIP-event timings {label: [seconds]}."""
     fl = conv_flops(bank.lay, B, bank.Ga)
-    fx = conv_exec_flops(bank.lay, B, bank.Ga, bank.wino, lambda l, d: bank._w44(B, l, d))      # (train-mode plan: VV_WINO44, default none)
+    fx = conv_exec_flops(bank.lay, B, bank.Ga, bank.wino, lambda l, d: bank._w44(B, l, d))      # (train-mode plan: VV_WINO44, default: data gradients)
     by = conv_bytes(bank.lay, B, bank.Ga, 2 if bank.y16 else 4, 2 if bank.dz16 else 4, 2 if bank.da16 else 4)
     t = sum(sum(v) for k, v in per.items() if k in fl)
     n = sum(len(v) for k, v in per.items() if k in fl)
@@ -247,6 +247,19 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
              'accounting': 'achieved / frac = multiply-adds the matrix cores execute (x16/36 of the direct convolution for the '
                            'Winograd form, K padded to the MFMA granule); algorithmic_tflops = SURVEY 8(d) direct-convolution FLOP / time',
              'algorithmic_tflops': f_alg / t / 1e12, 'effective_vs_direct': f_alg / f_exe}
+        w44k = [k for k in per if k in fl and bank._w44(B, bank.lay.convs[int(k.lstrip('convdgrad'))], k.startswith('dgrad'))] if bank.wino else []
+        if w44k:
+            # the launches the bank routes to Winograd F(4x4,3x3) (vv_conv_wino44: x1/4 of the direct multiply-adds) beside the F(2x2)
+            # ones -- the family's `frac` counts what each form executes, so it FALLS when a launch moves to the form that executes less
+            def part(keys):
+                tt = sum(sum(per[k]) for k in keys)
+                nn_ = sum(len(per[k]) for k in keys)
+                return {'launches_timed': nn_, 'avg_launch_us': 1e6 * tt / nn_, 'executed_tflops': sum(fx[k] * len(per[k]) for k in keys) / tt / 1e12,
+                        'frac': sum(fx[k] * len(per[k]) for k in keys) / tt / FP32_MFMA_PEAK,
+                        'algorithmic_tflops': sum(fl[k] * len(per[k]) for k in keys) / tt / 1e12} if nn_ else None
+            r['kernel'] += '; vv_conv_wino44 (F(4x4,3x3)) on ' + ', '.join(sorted(w44k))
+            r['by_form'] = {'f2x2': part([k for k in per if k in fl and k not in w44k]), 'f4x4': part(w44k)}
+            r['frac_of_direct_conv_ceiling'] = f_alg / t / FP32_MFMA_PEAK
         if bank.wino and getattr(bank, 'fuse_bn_sums', False):
             r['also_in_these_launches'] = ('the data-gradient launches whose output has a single consumer (7 of 13 per step) also do the '
                                            'first reduction pass of that BatchNorm backward in their epilogue (z read + two sums per value); '

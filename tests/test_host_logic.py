@@ -467,11 +467,18 @@ def test_embedded_width_layout_roundtrip():
         assert b1[1].start == l12.cin // 2 and m1[1].start == nf and b0[1] == slice(0, nf)
 
 
-def test_wino44_routing_is_opt_in(monkeypatch):
-    """VV_WINO44 (round 5): default = no launch on the Winograd F(4x4,3x3) kernel; '1' = the measured policy (GEMM-K >= 64 and workgroups
-    that fill the chip evenly -- at B = 256 the 16x16-level 64- / 128-channel launches, conv12 and dgrad8); 'all' = every launch."""
+def test_wino44_routing_policy(monkeypatch):
+    """VV_WINO44 (round 5): default 'dgrad' = the data-gradient launches of the measured policy (GEMM-K >= 64 and workgroups that fill the
+    chip evenly -- at B = 256 the 16x16-level 64- / 128-channel launches and dgrad8), forward launches stay on F(2x2); '1' adds the forward
+    launches; '0' none; 'all' every launch; small batches route nothing."""
     from vec_vad_amd.bank import UNetBank, UnitSpec
     units = [UnitSpec('raw', i, i) for i in range(5)] + [UnitSpec('of', 4, 0)]
+    monkeypatch.delenv('VV_WINO44', raising=False)
+    b = UNetBank(units, nf=32, device='cpu')
+    assert not any(b._w44(256, l, False) for l in b.lay.convs)
+    assert sorted(l.idx for l in b.lay.convs if b._w44(256, l, True)) == [3, 8, 10, 11]
+    assert b._w44_pack(256)[1] == 4 and b._w44_pack(5) is None
+    monkeypatch.setenv('VV_WINO44', '0')
     b = UNetBank(units, nf=32, device='cpu')
     assert not any(b._w44(256, l, d) for l in b.lay.convs for d in (False, True)) and b._w44_pack(256) is None
     monkeypatch.setenv('VV_WINO44', '1')

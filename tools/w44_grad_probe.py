@@ -9,7 +9,8 @@ from test_gpu_unet import _build
 from test_gpu_fullsize import _grad_table
 from vec_vad_amd.trainer import FusedTrainer
 torch.set_num_threads(32)
-B=256; seed=17
+import os
+B=256; seed=int(os.environ.get('PROBE_SEED','17'))
 raw, flow = O.seeded_cubes(B, 1, seed)
 x, x_of = O.cubes_to_inputs(raw, flow)
 ref={}
@@ -19,7 +20,7 @@ for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
     opt = O.AdamState(O.param_names(sdo))
     ref[tag] = O.train_step(sdo, O.bank_spec('net4'), x.to(dt), x_of.to(dt), opt)
 g32, g64 = ref['f32'][2], ref['f64'][2]
-for mode in ('0', '1', 'all'):
+for mode in os.environ.get('PROBE_MODES', '0,1,all').split(';'):
     os.environ['VV_WINO44'] = mode
     net, sd, tot_of = _build('net4', False)
     net.train()
@@ -32,4 +33,6 @@ for mode in ('0', '1', 'all'):
         nrm=float(g.norm()); a=float((grads[k]-g).norm())/nrm; b=float((g32[k].double()-g).norm())/nrm
         eh.append(a); er.append(b)
         if a/(3*b+2e-4) > worst[0]: worst=(a/(3*b+2e-4), k, a, b)
+    over=[(round(a/(3*b+2e-4),2),k) for k,a,b in zip([k for k in g64 if not (k.endswith('.0.bias') or k.endswith('.3.bias'))],eh,er) if a>0.9*(3*b+2e-4)]
+    print('   near/over bar:', over)
     print('VV_WINO44=%s: HIP median %.2e max %.2e | fp32 oracle median %.2e max %.2e | worst ratio to bar %.2f at %s (%.2e vs %.2e)' % (mode, np.median(eh), max(eh), np.median(er), max(er), worst[0], worst[1], worst[2], worst[3]), flush=True)

@@ -269,11 +269,15 @@ class UNetBank:
         # LDS-DMA ring kernels of round 5 (fp32: wino_ring_kernel, all-bf16: conv_ring16_kernel; bit-identical results either way)
         self.wino_flag = L.CONV_NO_RING if '0' in (os.environ.get('VV_WINO_RING', '1'), os.environ.get('VV_CONV_RING', '1')) else 0
         self.wgrad_flag = 256                  # vv_wgrad_params.pad0 bit 8: Winograd form of the 3x3 weight gradient
-        # VV_WINO44 (round 5): which fp32 3x3 launches run as Winograd F(4x4,3x3) (vv_conv_wino44: 1.78x fewer matrix-core cycles than
-        # F(2x2), a few 1e-6 of the tensor maximum from it).  '0' (default): none -- measured +0.65 % on the Net4 step with the full-size
-        # gradient test's calibrated bar exceeded; '1': the launches it measured faster on (_w44); 'all':
-        # every launch it takes
-        self.w44_mode = os.environ.get('VV_WINO44', '0').lower()
+        # VV_WINO44 (round 5): which fp32 3x3 launches of a TRAIN step run as Winograd F(4x4,3x3) (vv_conv_wino44: 1.78x fewer matrix-core
+        # cycles than F(2x2); with the interpolation points scaled by 3/4 its rounding error is 1 - 3e-6 of the tensor maximum, 2 - 3 x
+        # F(2x2)'s).  'dgrad' (default): the DATA-GRADIENT launches the policy of _w44 takes -- a data gradient's rounding feeds no ReLU /
+        # max-pool gate and no BatchNorm statistic, and every parameter gradient's distance from float64 is the same to three digits
+        # with and without it (tools/w44_grad_probe.py), while the forward pass -- losses, activations, statistics -- stays bit-identical
+        # to the F(2x2) path; '1': forward launches too (median gradient distance as good, but a cancellation-heavy bias gradient
+        # crosses its calibrated bar on one of the two full-size test batches); 'all': every launch it takes; '0': none;
+        # 'set:f3,d10,...': explicit launches (probing)
+        self.w44_mode = os.environ.get('VV_WINO44', 'dgrad').lower()
         self._w44_tables = {}
         # VV_WINO44_EVAL: the same choice for the eval-mode forward on the folded model (test.py:312-345 scoring; no gradients, scores
         # and AUROC judged at 1e-3: a few 1e-6 per layer are noise there).  '1' (default): the policy of _w44; '0': none; 'all'
@@ -454,6 +458,10 @@ class UNetBank:
         still fill the chip evenly: at least two rounds of 256 workgroups with <= 10 % of the last round idle."""
         mode = self.w44_eval_mode if evalm else self.w44_mode
         if not self.wino or mode in ('0', 'off') or (dgrad and l.idx == 0):
+            return False
+        if mode.startswith('set:'):                      # explicit launches, e.g. VV_WINO44=set:f3,f10,d10 (probing a policy)
+            return ('%s%d' % ('d' if dgrad else 'f', l.idx)) in mode[4:].split(',')
+        if mode == 'dgrad' and not dgrad:
             return False
         K, N = (l.cout, l.cin) if dgrad else (l.cinp, l.cout)
         if N % 32 or K % 8 or K > 256:

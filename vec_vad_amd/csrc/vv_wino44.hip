@@ -6,8 +6,9 @@
 // 36 element-wise products per 16 output pixels = 2.25 matrix-core multiply-adds per output and channel pair, against 4 for
 // F(2x2,3x3) (vv_wino.hip) and 9 for the direct form: 1.78x fewer MFMA cycles than the kernel this one replaces on the layers that
 // are bound by the matrix pipe (>= 64 input channels).  All in fp32.  The transforms multiply by up to 8 (A) / 5 (B), so the result
-// is a few 1e-6 of the tensor's maximum from the direct convolution (F(2x2): a few 1e-7); what that does to the 1e-3 bars of a
-// training trajectory was measured before this kernel was written (profiles/r05_wino44_numerics.txt, tests/numerics_wino44.py).
+// is 1 - 3e-6 of the tensor's maximum from the direct convolution with the interpolation points used here (the textbook points: 4 -
+// 14e-6; F(2x2): a few 1e-7); what the textbook form does to the 1e-3 bars of a training trajectory was measured before this kernel
+// was written (profiles/r05_wino44_numerics.txt, tests/numerics_wino44.py).
 //
 // A group of 384 threads = 6 waves works on 32 tiles (512 output pixels) x 32 output channels of one UNet; wave = xi (0..5), its six
 // GEMMs (nu = 0..5) live in 96 accumulator registers, <= 168 registers per lane = three waves per SIMD.  A WORKGROUP is two such
@@ -27,12 +28,12 @@
 //   * Epilogue: every wave applies the column half of A^T . A to its xi; the six waves meet in LDS (two rounds of eight accumulator
 //     registers) and finish (register, output-row pair) units: bias, ReLU (eval), NHWC buffer stores, BatchNorm sum / sum of squares
 //     or the fused first pass of the consumer's BatchNorm backward -- the same contract as wino_conv_kernel.
-// Where it stands (round 5, profiles/README.md): results agree with the direct kernel / float64 to <= 1.4e-5 of the tensor maximum
-// on every level (tests/test_gpu_wino44.py); matrix pipe busy 0.33 - 0.41 (F(2x2): 0.6) -- per MFMA it issues ~10 other instructions
-// (F(2x2): ~4) -- so it is faster than F(2x2) only on the 16x16-level launches with >= 64 input channels and a few others (-12 ..
-// -19 %), +0.65 % on the Net4 step; with those launches routed to it the full-size gradient test's calibrated bar (3 x the fp32
-// reference's own distance from float64) is exceeded.  It is therefore NOT on the default path: UNetBank routes to it only with
-// VV_WINO44=1 (policy) / all.
+// Where it stands (round 5): results agree with the direct kernel / float64 to 1 - 3e-6 of the tensor maximum on every
+// level (tests/test_gpu_wino44.py; F(2x2): 4e-7 - 1.7e-6); matrix pipe busy 0.33 - 0.45 (F(2x2): 0.6 - 0.7) -- per MFMA it issues ~8 other
+// instructions (F(2x2): ~4) and an fp32 MFMA is only 2 x the packed vector rate -- so it is faster than F(2x2) where GEMM-K >= 64 and its
+// coarse workgroups fill the chip in whole rounds (-7 ... -26 % per launch).  UNetBank routes the data-gradient launches of a train step
+// (their rounding feeds no gate and no statistic: gradient statistics unchanged to three digits) and the eval-mode forward's launches
+// to it by that policy; forward launches of a train step only on request (VV_WINO44=1 | all).
 #include <type_traits>
 #include "vv_common.h"
 // VV_EXP4 (compile-time bit mask, default 0; any other value computes WRONG results): 1 no MFMAs, 2 no halo loads, 4 no tap reloads,
@@ -46,6 +47,16 @@ constexpr int W4N = 384;               // threads per sub-group: one wave per xi
 constexpr int W4G = 2;                 // sub-groups (pixel tiles) per workgroup -- see the kernel's header
 constexpr int W4T = 32;                // tiles per workgroup
 constexpr int SB4_MASK = 0x386;        // may cross a scheduling barrier: VALU, SALU, LDS -- not MFMA, not VMEM
+// Interpolation points of the Toom-Cook construction: (0, +-PA, +-PB, infinity).  The textbook choice (0, +-1, +-2) scaled by 3/4:
+// the same zero pattern and +- symmetry of the three matrices, every constant a dyadic rational (exact in fp32), and a 2.4 x smaller
+// rounding error of the fp32 transforms (single tile, 64 channels: mean 8.3e-7 of the maximum against 2.0e-6; 19 symmetric and
+// asymmetric point sets were compared on the CPU, profiles/r05_wino44_points.txt):
+//   B^T = [a2b2 0 -(a2+b2) 0 1 0; 0 -a b2 -b2 a 1 0; 0 a b2 -b2 -a 1 0; 0 -a2 b -a2 b 1 0; 0 a2 b -a2 -b 1 0; 0 a2b2 0 -(a2+b2) 0 1]
+//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a2 a2 b2 b2 0; 0 a3 -a3 b3 -b3 1]
+//   G   = [1/N0 0 0; (1 +-a a2)/Na; (1 +-b b2)/Nb; 0 0 1],  N0 = a2 b2, Na = 2 a2 (a2 - b2), Nb = 2 b2 (b2 - a2)
+constexpr float PA = 0.75f, PB = 1.5f;
+constexpr float PA2 = PA * PA, PB2 = PB * PB, PA3 = PA2 * PA, PB3 = PB2 * PB;
+constexpr float PA2B2 = PA2 * PB2, PS2 = PA2 + PB2, PAB2 = PA * PB2, PA2B = PA2 * PB;
 
 // LDS hand-over between the waves of a workgroup WITHOUT the vector-memory drain a __syncthreads() can carry (halo and tap loads stay
 // in flight across it); the empty asm keeps the compiler from lifting later LDS reads above the barrier
@@ -91,7 +102,10 @@ struct W4Geo {
 };
 static_assert(W4Geo<32>::ok() && W4Geo<16>::ok() && W4Geo<8>::ok() && W4Geo<4>::ok(), "LDS image: bank conflicts or overlap");
 
-template <int H_>
+// NS ("N share"): the two groups of a workgroup take the two N tiles of ONE pixel tile and share its halo image -- every thread of the
+// workgroup stages half as many items, the halo crosses L2 -> LDS once for 64 output channels; NS = false: two pixel tiles of one N tile
+// (launches with 32 output channels).
+template <int H_, bool NS>
 __global__ void __launch_bounds__(W4N * W4G, 3)
 wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = W4Geo<H_>;
@@ -100,7 +114,8 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   constexpr int CK = 8, Q = 2;
   constexpr int HY0 = PARTS == 1 ? 1 : 0, HR = PARTS == 1 ? HH - 2 : HH;      // halo rows that can lie inside an image
   constexpr int NITEMS = NI * HR * H_ * Q;
-  constexpr int NIT = (NITEMS + W4N - 1) / W4N;
+  constexpr int STN = NS ? W4N * W4G : W4N;                // threads that stage one halo image
+  constexpr int NIT = (NITEMS + STN - 1) / STN;
   constexpr int HALO8 = 4 * PLANE;                         // 8-byte slots of the halo image
   constexpr int EX8 = 6 * 8 * 64 * 2;                      // epilogue exchange: [wave][8 regs][64 lanes] float4
   constexpr int L8 = HALO8 > EX8 ? HALO8 : EX8;
@@ -113,18 +128,28 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   const int sg = wv / 6;
   v2f* const lds8 = lds_all[sg];
   float* lds = reinterpret_cast<float*>(lds8);
-  v2f* const halo = lds8;
+  v2f* const halo = NS ? lds_all[0] : lds8;
 
   int w = vv_xcd_remap(blockIdx.x, nper);
   if (w >= total) return;
-  const int nn = w % NN; w /= NN;      // the N tiles of one pixel tile are neighbours in launch order: they share the halo in L2
-  const int NTP = (NT + W4G - 1) / W4G;
-  const int pt_ = (w % NTP) * W4G + sg;
-  const bool live = pt_ < NT;          // (odd tile count: the last workgroup's second group repeats the last tile and writes nothing)
-  const int pt = live ? pt_ : NT - 1;
-  const int g = w / NTP;
+  int nn, pt, g;
+  bool live = true;
+  if constexpr (NS) {
+    const int NNW = NN / W4G;            // N-tile pairs; NN is even (host)
+    nn = (w % NNW) * W4G + sg; w /= NNW;
+    pt = w % NT;
+    g = w / NT;
+  } else {
+    nn = w % NN; w /= NN;                // the N tiles of one pixel tile are neighbours in launch order: they share the halo in L2
+    const int NTP = (NT + W4G - 1) / W4G;
+    const int pt_ = (w % NTP) * W4G + sg;
+    live = pt_ < NT;                     // (odd tile count: the last workgroup's second group repeats the last tile and writes nothing)
+    pt = live ? pt_ : NT - 1;
+    g = w / NTP;
+  }
 
   const int tid = threadIdx.x - sg * W4N, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int stid = NS ? (int)threadIdx.x : tid;           // this thread among those that stage the image
   const int xi = wv - sg * 6;
   const int img0 = (pt / PARTS) * NI, part = pt % PARTS;
   const int y0 = part * (4 * G_::TROWS) - 1;               // conv-input row of halo row 0 (column origin is -1)
@@ -144,8 +169,8 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   unsigned valid = 0;
   unsigned itm[NIT];
   const int tile = (img0 * H_ + y0) * H_ - 1;
-  const int q4 = (tid % Q) * 4;
-  for (int hp = tid; hp < NI * HH * HW; hp += W4N) {
+  const int q4 = (stid % Q) * 4;
+  for (int hp = stid; hp < NI * HH * HW; hp += STN) {
     const int hx = hp % HW, t = hp / HW;
     const int hy = t % HH, im = t / HH;
     if (hx == 0 || hx == HW - 1 || hy < HY0 || hy >= HY0 + HR) {
@@ -156,11 +181,11 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   }
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
-    const int it = tid + k * W4N;
+    const int it = stid + k * STN;
     const int q = it % Q, hp = it / Q;
     const int hx = hp % H_ + 1, t = hp / H_;
     const int hy = t % HR + HY0, im = t / HR;
-    const bool inr = NITEMS % W4N == 0 || it < NITEMS;
+    const bool inr = NITEMS % STN == 0 || it < NITEMS;
     const int y = y0 + hy;
     const bool ok = inr && (unsigned)y < (unsigned)H_ && (img0 + im) < s.B;
     valid |= ok ? (1u << k) : 0u;
@@ -175,8 +200,8 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   const int bnu = KQ * 2 * bsub;                                                 // bytes between nu panels
   const int bxi = xi * 6 * bnu;
   const int nact = s.mode == VV_IN_ACT ? CinP : (s.mode == VV_IN_CAT ? s.csplit : 0);   // channels [0, nact) carry a BatchNorm + ReLU
-  float4* const ab4 = reinterpret_cast<float4*>(lds8 + L8 + 6 * 32);             // [2][CinP / 4]: scale, shift
-  for (int i = tid; i < (nact >> 2); i += W4N) {
+  float4* const ab4 = reinterpret_cast<float4*>((NS ? lds_all[0] : lds8) + L8 + 6 * 32);      // [2][CinP / 4]: scale, shift
+  for (int i = stid; i < (nact >> 2); i += STN) {
     ab4[i] = *reinterpret_cast<const float4*>(s.a + 4 * i);
     ab4[(CinP >> 2) + i] = *reinterpret_cast<const float4*>(s.b + 4 * i);
   }
@@ -209,7 +234,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int sl = (int)(itm[k] >> 16);
-      if (NITEMS % W4N == 0 || k < NIT - 1 || sl != 0xFFFF) {
+      if (NITEMS % STN == 0 || k < NIT - 1 || sl != 0xFFFF) {
         float4 v = r[k];
         if (act) {                                             // (uniform; the per-item part is a select: invalid items stay zero)
           const float4 a = vv_act4(v, sa, sb);
@@ -238,8 +263,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   // one sub-step: input transform of this wave's row (18 / 24 LDS reads, <= 36 packed VALU), 12 MFMAs, the taps of the next sub-step
   // loaded into the registers the second k step has just released.  XI is a compile-time constant (the K loop below exists once per
   // wave role): the rows of B^T become immediate LDS offsets and literal constants --
-  //   0: 4 d0 - 5 d2 + d4      1: -4 d1 - 4 d2 + d3 + d4      2: 4 d1 - 4 d2 - d3 + d4
-  //   3: -2 d1 - d2 + 2 d3 + d4      4: 2 d1 - d2 - 2 d3 + d4      5: 4 d1 - 5 d3 + d5
+  //   (rows of B^T above; with the textbook points: 0: 4 d0 - 5 d2 + d4, 1: -4 d1 - 4 d2 + d3 + d4, ..., 5: 4 d1 - 5 d3 + d5)
   // LAST: the sub-step that ends the K loop loads nothing (a load still in flight into a register the compiler considers dead would
   // land in whatever the epilogue keeps there).
   auto substep = [&](const auto XI_, const int step, const auto SUB_, const auto first, const auto LAST_) {
@@ -256,26 +280,26 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
     for (int b = 0; b < 6; ++b) {
       const int o = (b & 3) * HWQ + (b >> 2);
       if constexpr (XI == 0) {
-        R[b] = 4.f * pp[o] - 5.f * pp[2 * ROW + o] + pp[4 * ROW + o];
+        R[b] = PA2B2 * pp[o] - PS2 * pp[2 * ROW + o] + pp[4 * ROW + o];
       } else if constexpr (XI == 5) {
-        R[b] = 4.f * pp[ROW + o] - 5.f * pp[3 * ROW + o] + pp[5 * ROW + o];
+        R[b] = PA2B2 * pp[ROW + o] - PS2 * pp[3 * ROW + o] + pp[5 * ROW + o];
       } else {
         const v2f d1 = pp[ROW + o], d2 = pp[2 * ROW + o], d3 = pp[3 * ROW + o], d4 = pp[4 * ROW + o];
-        if constexpr (XI == 1) R[b] = (d4 - 4.f * d2) + (d3 - 4.f * d1);
-        if constexpr (XI == 2) R[b] = (d4 - 4.f * d2) - (d3 - 4.f * d1);
-        if constexpr (XI == 3) R[b] = (d4 - d2) + 2.f * (d3 - d1);
-        if constexpr (XI == 4) R[b] = (d4 - d2) - 2.f * (d3 - d1);
+        if constexpr (XI == 1) R[b] = (d4 - PB2 * d2) + (PA * d3 - PAB2 * d1);
+        if constexpr (XI == 2) R[b] = (d4 - PB2 * d2) - (PA * d3 - PAB2 * d1);
+        if constexpr (XI == 3) R[b] = (d4 - PA2 * d2) + (PB * d3 - PA2B * d1);
+        if constexpr (XI == 4) R[b] = (d4 - PA2 * d2) - (PB * d3 - PA2B * d1);
       }
     }
     v2f V[6];
     {
-      const v2f pq = R[4] - 4.f * R[2], qq = R[3] - 4.f * R[1], rr = R[4] - R[2], ss = R[3] - R[1];
-      V[0] = 4.f * R[0] - 5.f * R[2] + R[4];
+      const v2f pq = R[4] - PB2 * R[2], qq = PA * R[3] - PAB2 * R[1], rr = R[4] - PA2 * R[2], ss = PB * R[3] - PA2B * R[1];
+      V[0] = PA2B2 * R[0] - PS2 * R[2] + R[4];
       V[1] = pq + qq;
       V[2] = pq - qq;
-      V[3] = rr + 2.f * ss;
-      V[4] = rr - 2.f * ss;
-      V[5] = 4.f * R[1] - 5.f * R[3] + R[5];
+      V[3] = rr + ss;
+      V[4] = rr - ss;
+      V[5] = PA2B2 * R[1] - PS2 * R[3] + R[5];
     }
     __builtin_amdgcn_sched_barrier(SB4_MASK);
     // tap n has landed (the asm ties the wait to the register the MFMA reads); written out six times: the count must be a literal
@@ -357,7 +381,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   }
 
   // ---- epilogue.  Columns in registers (M = this wave's xi, indexed by nu):
-  //        T0 = M0 + M1 + M2 + M3 + M4    T1 = (M1 - M2) + 2 (M3 - M4)    T2 = (M1 + M2) + 4 (M3 + M4)    T3 = (M1 - M2) + 8 (M3 - M4) + M5
+  //        T0 = M0 + M1 + M2 + M3 + M4    T1 = a (M1 - M2) + b (M3 - M4)    T2 = a2 (M1 + M2) + b2 (M3 + M4)    T3 = a3 (M1 - M2) + b3 (M3 - M4) + M5
   //      rows across the six waves through LDS, the same combination of T(xi).  Accumulator register i of lane (half, l31) belongs to
   //      tile 8 (i / 4) + 4 half + i % 4: the wave-uniform part of a unit's address uses the tile of half 0, the lanes of half 1 carry
   //      the distance of four tiles (LP pixels) in their offsets.
@@ -391,7 +415,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
       const int i = rd * 8 + ii;
       const float m0 = acc[0][i], m1 = acc[1][i], m2 = acc[2][i], m3 = acc[3][i], m4 = acc[4][i], m5 = acc[5][i];
       const float s12_ = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-      const v4f t = {m0 + s12_ + s34, d12 + 2.f * d34, s12_ + 4.f * s34, d12 + 8.f * d34 + m5};
+      const v4f t = {m0 + s12_ + s34, PA * d12 + PB * d34, PA2 * s12_ + PB2 * s34, PA3 * d12 + PB3 * d34 + m5};
       ex4[(xi * 8 + ii) * 64 + lane] = t;
     }
     // this wave's units of the round: u = (register ii, output-row pair rp); three or two per wave, rotated between the rounds
@@ -429,10 +453,10 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
         v4f ya, yb;
         if (rp == 0) {
           ya = e[0] + sA + sB;
-          yb = dA + 2.f * dB;
+          yb = PA * dA + PB * dB;
         } else {
-          ya = sA + 4.f * sB;
-          yb = dA + 8.f * dB + e[5 * 512];
+          ya = PA2 * sA + PB2 * sB;
+          yb = PA3 * dA + PB3 * dB + e[5 * 512];
         }
         ya += bias;
         yb += bias;
@@ -507,7 +531,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
 
 // U = G g G^T of every (ci, co) filter, in the B-operand panel layout [xi*6+nu][Kp/8][2 sub-steps][2 halves][N][2]:
 // element (t, k, n) at  ((((t * Kp/8 + k/8) * 2 + (k%4)/2) * 2 + (k%8)/4) * N + n) * 2 + k%2.
-//   G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   (G as in the table at the top of this file)
 // mode 0: forward       g[a][b] = W[co = n][ci = k][a][b]
 // mode 1: data gradient g[a][b] = W[co = k][ci = n][2-a][2-b]
 __global__ void __launch_bounds__(VV_WG)
@@ -536,17 +560,20 @@ wino44_pack_kernel(const vv_pack_entry* __restrict__ table, const float* __restr
         gk[a][b] = v;
       }
     // rows of G as (x, y, z) -> G[i][0] x + G[i][1] y + G[i][2] z
-    auto grow = [](const int i, const float x, const float y, const float z) -> float {
+    // (in double: the filter transform then contributes one final rounding, whatever the constants)
+    auto grow = [](const int i, const double x, const double y, const double z) -> double {
+      constexpr double a = PA, b = PB, a2 = a * a, b2 = b * b;
+      constexpr double n0 = a2 * b2, na = 2.0 * a2 * (a2 - b2), nb = 2.0 * b2 * (b2 - a2);
       switch (i) {
-        case 0: return 0.25f * x;
-        case 1: return (-1.f / 6.f) * (x + y + z);
-        case 2: return (-1.f / 6.f) * (x - y + z);
-        case 3: return (1.f / 24.f) * x + (1.f / 12.f) * y + (1.f / 6.f) * z;
-        case 4: return (1.f / 24.f) * x - (1.f / 12.f) * y + (1.f / 6.f) * z;
+        case 0: return x / n0;
+        case 1: return (x + a * y + a2 * z) / na;
+        case 2: return (x - a * y + a2 * z) / na;
+        case 3: return (x + b * y + b2 * z) / nb;
+        case 4: return (x - b * y + b2 * z) / nb;
         default: return z;
       }
     };
-    float rr[6][3];
+    double rr[6][3];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -557,7 +584,7 @@ wino44_pack_kernel(const vv_pack_entry* __restrict__ table, const float* __restr
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) ex[xi * 6 + nu][slot] = grow(nu, rr[xi][0], rr[xi][1], rr[xi][2]);
+      for (int nu = 0; nu < 6; ++nu) ex[xi * 6 + nu][slot] = (float)grow(nu, rr[xi][0], rr[xi][1], rr[xi][2]);
     __syncthreads();
     // thread t = position inside the tap's [sub][half][32 n][2] block of this (kq, nb): runs of 64 floats per (sub, half)
     const int sh = t >> 6, rem = t & 63;
@@ -572,9 +599,15 @@ int launch_wino44(const vv_conv_params* p, hipStream_t st) {
   using G_ = W4Geo<H_>;
   const int NT = ((p->B + G_::NI - 1) / G_::NI) * G_::PARTS;
   const int NN = p->Cout / 32;
-  const int total = p->G * NN * ((NT + W4G - 1) / W4G);
-  const int nper = (total + 7) / 8;
-  VV_LAUNCH((wino44_conv_kernel<H_>), dim3(nper * 8), dim3(W4N * W4G), 0, st, *p, NT, NN, total, nper);
+  if (NN % W4G == 0) {                 // the groups of a workgroup = the two N tiles of one pixel tile (shared halo image)
+    const int total = p->G * (NN / W4G) * NT;
+    const int nper = (total + 7) / 8;
+    VV_LAUNCH((wino44_conv_kernel<H_, true>), dim3(nper * 8), dim3(W4N * W4G), 0, st, *p, NT, NN, total, nper);
+  } else {                             // ... = two pixel tiles of one N tile
+    const int total = p->G * NN * ((NT + W4G - 1) / W4G);
+    const int nper = (total + 7) / 8;
+    VV_LAUNCH((wino44_conv_kernel<H_, false>), dim3(nper * 8), dim3(W4N * W4G), 0, st, *p, NT, NN, total, nper);
+  }
   VV_CHECK_LAUNCH();
   return VV_OK;
 }
