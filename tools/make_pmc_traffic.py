@@ -35,8 +35,9 @@ def main():
         kernels.append({'kernel': k, 'launches': nf[k], 'FETCH_SIZE_KB_per_launch': round(f, 1), 'WRITE_SIZE_KB_per_launch': round(w, 1),
                         'hbm_bytes_per_launch_corrected': int((2 * f + w) * 1024)})
     # the 3x3 forward + data-gradient family: Winograd kernels (fp32), or the direct KIND = 0 kernel + the persistent bf16 kernel
-    fam = [k for k in kernels if k['kernel'].startswith('wino_conv_kernel') or k['kernel'].startswith('wino_ring_kernel')] or \
-          [k for k in kernels if re.match(r'conv_mfma_kernel<\d+, \d+, \d+, \d+, 0,', k['kernel']) or k['kernel'].startswith('conv_gemm16p_kernel')]
+    fam = [k for k in kernels if k['kernel'].startswith(('wino_conv_kernel', 'wino_ring_kernel', 'wino44_conv_kernel'))] or \
+          [k for k in kernels if re.match(r'conv_mfma_kernel<\d+, \d+, \d+, \d+, 0,', k['kernel']) or
+           k['kernel'].startswith(('conv_gemm16p_kernel', 'conv_ring16_kernel'))]
     n = sum(k['launches'] for k in fam)
     out = {
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline',
