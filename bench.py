@@ -83,6 +83,7 @@ def conv_bytes(lay, B, G, y_bytes=4, dy_bytes=4, da_bytes=4):
     return by
 
 
+_F44_BYTES = {}       # profile name -> HBM bytes per launch of the F(4x4) launches of the same counter passes, or None
 _STEP_BYTES = {}      # profile name -> whole-step HBM bytes of the same counter passes (train steps only), or None
 
 
@@ -94,6 +95,7 @@ def pmc_traffic(name):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             _STEP_BYTES[name] = d.get('hbm_bytes_per_train_step')
+            _F44_BYTES[name] = (d.get('conv_family_f4x4') or {}).get('hbm_bytes_per_launch_corrected')
             return (d.get('conv_family') or d['conv_mfma_family'])['hbm_bytes_per_launch_corrected'], _profile_tag(n, d)
         except Exception:
             continue
@@ -226,13 +228,18 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
     fl = conv_flops(bank.lay, B, bank.Ga)
     fx = conv_exec_flops(bank.lay, B, bank.Ga, bank.wino, lambda l, d: bank._w44(B, l, d))      # (train-mode plan: VV_WINO44, default: data gradients)
     by = conv_bytes(bank.lay, B, bank.Ga, 2 if bank.y16 else 4, 2 if bank.dz16 else 4, 2 if bank.da16 else 4)
-    t = sum(sum(v) for k, v in per.items() if k in fl)
-    n = sum(len(v) for k, v in per.items() if k in fl)
+    # fp32: the launches the bank routes to Winograd F(4x4,3x3) (vv_conv_wino44, another kernel executing x1/4 instead of x16/36 of the
+    # direct multiply-adds) are reported beside the dominant F(2x2) kernel family, not mixed into its roofline
+    w44k = [k for k in per if k in fl and bank._w44(B, bank.lay.convs[int(k.lstrip('convdgrad'))], k.startswith('dgrad'))] \
+        if (precision == 'fp32' and bank.wino) else []
+    fam = [k for k in per if k in fl and k not in w44k]
+    t = sum(sum(per[k]) for k in fam)
+    n = sum(len(per[k]) for k in fam)
     if not n or t <= 0:
         return None
-    f_alg = sum(fl[k] * len(v) for k, v in per.items() if k in fl)
-    f_exe = sum(fx[k] * len(v) for k, v in per.items() if k in fl)
-    b_alg = sum(by[k] * len(v) for k, v in per.items() if k in fl)
+    f_alg = sum(fl[k] * len(per[k]) for k in fam)
+    f_exe = sum(fx[k] * len(per[k]) for k in fam)
+    b_alg = sum(by[k] * len(per[k]) for k in fam)
     common = {'launches_timed': n, 'avg_launch_us': 1e6 * t / n, 'algorithmic_gflop_per_launch': f_alg / n / 1e9,
               'algorithmic_mbytes_per_launch': b_alg / n / 1e6, 'traffic': traffic[0], 'traffic_source': traffic[1],
               # the launches above were timed in eager steps on ONE stream (overlap == 'none') or on the eager two-stream
@@ -247,19 +254,18 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
              'accounting': 'achieved / frac = multiply-adds the matrix cores execute (x16/36 of the direct convolution for the '
                            'Winograd form, K padded to the MFMA granule); algorithmic_tflops = SURVEY 8(d) direct-convolution FLOP / time',
              'algorithmic_tflops': f_alg / t / 1e12, 'effective_vs_direct': f_alg / f_exe}
-        w44k = [k for k in per if k in fl and bank._w44(B, bank.lay.convs[int(k.lstrip('convdgrad'))], k.startswith('dgrad'))] if bank.wino else []
         if w44k:
-            # the launches the bank routes to Winograd F(4x4,3x3) (vv_conv_wino44: x1/4 of the direct multiply-adds) beside the F(2x2)
-            # ones -- the family's `frac` counts what each form executes, so it FALLS when a launch moves to the form that executes less
-            def part(keys):
-                tt = sum(sum(per[k]) for k in keys)
-                nn_ = sum(len(per[k]) for k in keys)
-                return {'launches_timed': nn_, 'avg_launch_us': 1e6 * tt / nn_, 'executed_tflops': sum(fx[k] * len(per[k]) for k in keys) / tt / 1e12,
-                        'frac': sum(fx[k] * len(per[k]) for k in keys) / tt / FP32_MFMA_PEAK,
-                        'algorithmic_tflops': sum(fl[k] * len(per[k]) for k in keys) / tt / 1e12} if nn_ else None
-            r['kernel'] += '; vv_conv_wino44 (F(4x4,3x3)) on ' + ', '.join(sorted(w44k))
-            r['by_form'] = {'f2x2': part([k for k in per if k in fl and k not in w44k]), 'f4x4': part(w44k)}
-            r['frac_of_direct_conv_ceiling'] = f_alg / t / FP32_MFMA_PEAK
+            t4 = sum(sum(per[k]) for k in w44k)
+            n4 = sum(len(per[k]) for k in w44k)
+            x4, a4 = sum(fx[k] * len(per[k]) for k in w44k), sum(fl[k] * len(per[k]) for k in w44k)
+            r['f4x4_launches'] = {'kernel': 'wino44_conv_kernel<H, NS>: the same convolution as Winograd F(4x4,3x3) (x1/4 of the direct multiply-adds) on '
+                                            + ', '.join(sorted(w44k)), 'launches_timed': n4, 'avg_launch_us': 1e6 * t4 / n4,
+                                  'achieved': x4 / t4 / 1e12, 'frac': x4 / t4 / FP32_MFMA_PEAK, 'algorithmic_tflops': a4 / t4 / 1e12,
+                                  'algorithmic_mbytes_per_launch': sum(by[k] * len(per[k]) for k in w44k) / n4 / 1e6,
+                                  'traffic': _F44_BYTES.get('r05_pmc_hbm_traffic.json')}
+            r['all_3x3_launches'] = {'launches_timed': n + n4, 'avg_launch_us': 1e6 * (t + t4) / (n + n4),
+                                     'executed_frac': (f_exe + x4) / (t + t4) / FP32_MFMA_PEAK,
+                                     'algorithmic_tflops': (f_alg + a4) / (t + t4) / 1e12}
         if bank.wino and getattr(bank, 'fuse_bn_sums', False):
             r['also_in_these_launches'] = ('the data-gradient launches whose output has a single consumer (7 of 13 per step) also do the '
                                            'first reduction pass of that BatchNorm backward in their epilogue (z read + two sums per value); '
@@ -424,7 +430,8 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
         rec['roofline']['step_traffic_bytes'] = _STEP_BYTES[pname]
         rec['roofline']['step_hbm_gbytes_per_s'] = _STEP_BYTES[pname] / (dt / steps) / 1e9
     if rec['roofline'] is not None and graph:
-        n_fam = sum(1 for label, _, _ in ev[:n_in] if label in fl)
+        f44 = lambda label: precision == 'fp32' and bank.wino and bank._w44(B, bank.lay.convs[int(label.lstrip('convdgrad'))], label.startswith('dgrad'))
+        n_fam = sum(1 for label, _, _ in ev[:n_in] if label in fl and not f44(label))
         rec['roofline']['launches_timed_where'] = ('%d inside the timed region (its first %d step(s) run the eager loop), %d in %d further '
                                                    'eager event step(s) right after it' % (n_fam, n_ev, rec['roofline']['launches_timed'] - n_fam, ev_extra))
     if precision == 'bf16':

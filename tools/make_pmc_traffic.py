@@ -35,7 +35,7 @@ def main():
         kernels.append({'kernel': k, 'launches': nf[k], 'FETCH_SIZE_KB_per_launch': round(f, 1), 'WRITE_SIZE_KB_per_launch': round(w, 1),
                         'hbm_bytes_per_launch_corrected': int((2 * f + w) * 1024)})
     # the 3x3 forward + data-gradient family: Winograd kernels (fp32), or the direct KIND = 0 kernel + the persistent bf16 kernel
-    fam = [k for k in kernels if k['kernel'].startswith(('wino_conv_kernel', 'wino_ring_kernel', 'wino44_conv_kernel'))] or \
+    fam = [k for k in kernels if k['kernel'].startswith(('wino_conv_kernel', 'wino_ring_kernel'))] or \
           [k for k in kernels if re.match(r'conv_mfma_kernel<\d+, \d+, \d+, \d+, 0,', k['kernel']) or
            k['kernel'].startswith(('conv_gemm16p_kernel', 'conv_ring16_kernel'))]
     n = sum(k['launches'] for k in fam)
@@ -47,6 +47,11 @@ def main():
                         'hbm_bytes_per_launch_corrected': int(sum(k['hbm_bytes_per_launch_corrected'] * k['launches'] for k in fam) / max(n, 1))},
         'kernels': kernels[:60],
     }
+    f44 = [k for k in kernels if k['kernel'].startswith('wino44_conv_kernel')]     # the launches routed to Winograd F(4x4,3x3): their own record
+    if f44:
+        n44 = sum(k['launches'] for k in f44)
+        out['conv_family_f4x4'] = {'kernels': sorted(set(k['kernel'] for k in f44)), 'launches': n44,
+                                   'hbm_bytes_per_launch_corrected': int(sum(k['hbm_bytes_per_launch_corrected'] * k['launches'] for k in f44) / n44)}
     # optional 4th argument: number of forward passes the profiled command ran (FlowNet2: every pass is the same work) -> whole-run
     # HBM bytes per pass.  A UNet bench process is NOT uniform (train steps + forward-only passes + one-off set-up), so for it the
     # per-step total is derived from the once-per-step kernels: train steps = launches of adam_bucketed_kernel, forward passes =
