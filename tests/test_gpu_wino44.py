@@ -21,7 +21,9 @@ def _pack(lib, L, fn, w, G, mode, K, N, taps, st):
 
 
 @pytest.mark.parametrize('H,Cin,Cout,B', [(32, 16, 32, 3), (32, 64, 32, 2), (32, 32, 64, 1), (16, 64, 64, 5), (16, 128, 64, 2), (8, 256, 128, 9),
-                                           (8, 128, 128, 8), (4, 128, 256, 33), (4, 256, 256, 70), (16, 32, 64, 1)])
+                                           (8, 128, 128, 8), (4, 128, 256, 33), (4, 256, 256, 70), (16, 32, 64, 1),
+                                           # two pixel tiles per workgroup with an odd tile count (the second group idles) / with three N tiles
+                                           (16, 64, 32, 5), (16, 64, 96, 3), (8, 32, 96, 7)])
 def test_wino44_matches_direct_conv_and_float64(H, Cin, Cout, B):
     """forward panel (BatchNorm+ReLU-on-load input, bias, BatchNorm partial sums) and data-gradient panel (plain input), ragged last
     workgroup (B not a multiple of the images per workgroup), every level"""
