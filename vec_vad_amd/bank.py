@@ -450,6 +450,23 @@ class UNetBank:
         ws.out4_valid = False          # True while ws.out4 holds the reconstructions of the LAST forward on this workspace
         return ws
 
+    @staticmethod
+    def _ks_bf16(groups, ntiles):
+        """k-split of a bf16 weight-gradient launch (one workgroup per CU): the largest split that keeps the launch in ONE round of 256
+        workgroups -- unless one round leaves more than a third of the chip idle (the 160-workgroup launches of the 4x4 level and the
+        first transposed conv at G = 10): then up to VV_WGRAD_BF16_ROUNDS (default 2) rounds, choosing the split with the smallest
+        rounds x ceil(tiles / split) + 1."""
+        one = max(1, min(ntiles, 256 // groups))
+        rmax = int(os.environ.get('VV_WGRAD_BF16_ROUNDS', '2'))
+        if groups * one * 3 > 256 * 2 or rmax <= 1:
+            return one
+        best, cost = one, -(-ntiles // one) + 1
+        for ks in range(one + 1, min(ntiles, 256 * rmax // groups) + 1):
+            c = -(-groups * ks // 256) * (-(-ntiles // ks) + 1)
+            if c < cost:
+                best, cost = ks, c
+        return best
+
     def _w44(self, B, l, dgrad, evalm=False):
         """Does the forward (dgrad=False) / data-gradient launch of conv layer l run as Winograd F(4x4,3x3) at batch size B (evalm: in
         the eval-mode plan)?  Policy
@@ -776,7 +793,7 @@ class UNetBank:
                 # (the flags of the launch go with the query: the all-bf16 weight gradient runs the LDS-ring kernel, whose tiling differs)
                 wfl = (L.WGRAD_DY_BF16 | L.WGRAD_X_BF16) if (self.dz16 and self.y16) else 0
                 if lib.vv_wgrad_bf16_plan(L.CONV3 | (wfl << 8), B, l.H, l.H, l.cinp, l.cout, C.byref(ntb), C.byref(nblk), C.byref(kw)):
-                    ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))      # one workgroup per CU, one round
+                    ks = self._ks_bf16(Ga * nblk.value, ntb.value)
                     wplan['c%d' % l.idx] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['c%d' % l.idx][1])
         for u, (_, H, ci, co) in enumerate(lay.convT):
@@ -787,7 +804,7 @@ class UNetBank:
             if self.cflag and self.bf16_wgrad:
                 ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()
                 if lib.vv_wgrad_bf16_plan(L.CONVT_FWD, B, H, H, ci, co, C.byref(ntb), C.byref(nblk), C.byref(kw)):
-                    ks = max(1, min(ntb.value, 256 // (Ga * nblk.value)))
+                    ks = self._ks_bf16(Ga * nblk.value, ntb.value)
                     wplan['t%d' % u] = (ks, nci * nco * ks * kw.value, kw.value)
             wmax = max(wmax, wplan['t%d' % u][1])
         # weight-gradient slabs: one region per layer (the reductions of a whole gradient bucket run as ONE grouped launch after the
