@@ -83,6 +83,81 @@ def conv_bytes(lay, B, G, y_bytes=4, dy_bytes=4, da_bytes=4):
     return by
 
 
+def wgrad_exec_flops(bank, B):
+    """multiply-adds the matrix cores execute in the weight-gradient launches: the 3x3 layers in Winograd F(2x2,3x3) form (fp32 path:
+    x16/36, K padded), the transposed convs and every bf16 launch direct."""
+    lay, G = bank.lay, bank.Ga
+    k = WINO_EXEC if (bank.wino_wgrad and not bank.cflag) else 1.0
+    fx = {'wgrad%d' % l.idx: 2.0 * B * l.H * l.H * 9 * l.cinp * l.cout * G * k for l in lay.convs}
+    fa = {'wgrad%d' % l.idx: 2.0 * B * l.H * l.H * 9 * l.cin * l.cout * G for l in lay.convs}
+    for u, (_, H, ci, co) in enumerate(lay.convT):
+        fx['wgradT%d' % u] = fa['wgradT%d' % u] = 2.0 * B * H * H * 9 * ci * co * G
+    return fx, fa
+
+
+def wgrad_bytes(bank, B):
+    """algorithmic HBM bytes of the same launches: dy read once + the layer input read once (slabs / weights not counted)."""
+    lay, G = bank.lay, bank.Ga
+    yb, dzb, dab = (2 if bank.y16 else 4), (2 if bank.dz16 else 4), (2 if bank.da16 else 4)
+    by = {'wgrad%d' % l.idx: 1.0 * B * l.H * l.H * G * (dzb * l.cout + yb * (l.cinp if l.idx == 0 else l.cin)) for l in lay.convs}
+    for u, (_, H, ci, co) in enumerate(lay.convT):
+        by['wgradT%d' % u] = 1.0 * B * H * H * G * (yb * ci + dab * 4 * co)
+    return by
+
+
+def bn_bwd_bytes(bank, B):
+    """algorithmic HBM bytes of the BatchNorm-backward launches: the apply pass reads dA and z and writes dz, a separate
+    reduce pass reads dA and z."""
+    lay, G = bank.lay, bank.Ga
+    yb, dzb, dab = (2 if bank.y16 else 4), (2 if bank.dz16 else 4), (2 if bank.da16 else 4)
+    by = {}
+    for l in lay.convs:
+        n = 1.0 * B * l.H * l.H * l.cout * G
+        by['bn_bwd_apply%d' % l.idx] = n * (dab + yb + dzb)
+        by['bn_bwd_reduce%d' % l.idx] = n * (dab + yb)
+    return by
+
+
+def family_rooflines(bank, B, per, precision):
+    """roofline.wgrad (matrix cores, or HBM for the bf16 path) and roofline.bn_bwd (HBM) from the same eager event steps."""
+    out = {}
+    fx, fa = wgrad_exec_flops(bank, B)
+    wb = wgrad_bytes(bank, B)
+    fam = [k for k in per if k in fx]
+    t, n = sum(sum(per[k]) for k in fam), sum(len(per[k]) for k in fam)
+    if n and t > 0:
+        steps_ev = max(len(per[k]) for k in fam)
+        x = sum(fx[k] * len(per[k]) for k in fam)
+        a = sum(fa[k] * len(per[k]) for k in fam)
+        b = sum(wb[k] * len(per[k]) for k in fam)
+        red = [k for k in per if k.startswith('wgrad_reduce') or k.startswith('wgradT_reduce')]
+        tr = sum(sum(per[k]) for k in red)
+        r = {'launches_timed': n, 'avg_launch_us': 1e6 * t / n, 'family_ms_per_step': 1e3 * t / steps_ev,
+             'slab_reductions_ms_per_step': 1e3 * tr / steps_ev, 'algorithmic_tflops': a / t / 1e12,
+             'algorithmic_mbytes_per_launch': b / n / 1e6, 'hbm_gbytes_per_s_algorithmic': b / t / 1e9}
+        if precision == 'fp32':
+            r.update({'bound': 'mfma', 'kernel': 'wgrad_wino_kernel (3x3 layers, Winograd F(2x2,3x3) weight gradient) + wgrad_mfma_kernel '
+                      '(transposed convs, direct 9-tap) on v_mfma_f32_32x32x2_f32', 'achieved': x / t / 1e12, 'peak': FP32_MFMA_PEAK / 1e12,
+                      'unit': 'TFLOP/s', 'frac': x / t / FP32_MFMA_PEAK, 'accounting': 'executed multiply-adds (as the headline roofline)'})
+        else:
+            r.update({'bound': 'hbm', 'kernel': 'wgrad_ring_kernel / wgrad_bf16_kernel (bf16 operands, fp32 accumulation)', 'achieved': b / t / 1e9,
+                      'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'mfma_tflops': a / t / 1e12})
+        out['wgrad'] = r
+    bb = bn_bwd_bytes(bank, B)
+    fam = [k for k in per if k in bb]
+    t, n = sum(sum(per[k]) for k in fam), sum(len(per[k]) for k in fam)
+    if n and t > 0:
+        steps_ev = max(len(per[k]) for k in fam)
+        b = sum(bb[k] * len(per[k]) for k in fam)
+        ap = [k for k in fam if 'apply' in k]
+        out['bn_bwd'] = {'bound': 'hbm', 'kernel': 'bn_bwd_apply_kernel (dz = f(dA, z, sums): reads dA + z, writes dz) + bn_bwd_reduce_kernel (the layers '
+                         'whose sums no producing launch leaves behind: reads dA + z)', 'achieved': b / t / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                         'frac': b / t / HBM_PEAK, 'launches_timed': n, 'avg_launch_us': 1e6 * t / n, 'family_ms_per_step': 1e3 * t / steps_ev,
+                         'apply_launches_per_step': len(ap), 'reduce_launches_per_step': len(fam) - len(ap),
+                         'algorithmic_mbytes_per_launch': b / n / 1e6}
+    return out
+
+
 _F44_BYTES = {}       # profile name -> HBM bytes per launch of the F(4x4) launches of the same counter passes, or None
 _STEP_BYTES = {}      # profile name -> whole-step HBM bytes of the same counter passes (train steps only), or None
 
@@ -320,11 +395,13 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     hook = lambda label, a, b: ev.append((label, a, b))
     n_ev = steps if not graph else min(ev_steps, steps)
     trainer.event_hook = hook if n_ev > 0 else None
-    trainer.event_labels = set(fl.keys()) if not breakdown else None
+    fam_labels = set(wgrad_exec_flops(bank, B)[0]) | set(bn_bwd_bytes(bank, B)) | {'wgrad_reduce0', 'wgrad_reduce4', 'wgradT_reduce0'}
+    trainer.event_labels = (set(fl.keys()) | fam_labels) if not breakdown else None
     diag_comm = trainer.buckets is not None and not graph
     if diag_comm:                      # per-bucket collective timings need the eager loop (events between the launches)
         trainer.buckets.timing = []
-        trainer.comm_timing = []
+    if trainer.buckets is not None:    # exposed communication: one event pair around the last bucket + the wait for all three, recorded
+        trainer.comm_timing = []       # between the hipGraph segments (graph mode) or behind the last backward launch (eager loop)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -356,11 +433,17 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     trainer.event_hook = None
     comm = None
     if trainer.buckets is not None and not diag_comm:
+        exposed = [a.elapsed_time(b) * 1e3 for a, b in (trainer.comm_timing or [])]
         comm = {'ranks': world, 'backend': dist.get_backend() if dist is not None else None,
                 'buckets': [{'bucket': k, 'columns': [trainer.buckets.bounds[k], trainer.buckets.bounds[k + 1]],
                              'mbytes': 4e-6 * bank.G * (trainer.buckets.bounds[k + 1] - trainer.buckets.bounds[k])} for k in (2, 1, 0)],
+                'exposed_comm_us_per_step': sum(exposed) / len(exposed) if exposed else None,
+                'exposed_comm_steps_timed': len(exposed),
                 'note': 'in-place all-reduce of three contiguous ranges of the bucket-major gradient buffer, launched between the '
-                        'hipGraph segments of the step; per-bucket timings need the eager loop: bench.py --no-graph'}
+                        'hipGraph segments of the step; exposed = main-stream time from the end of the last backward segment to the arrival of '
+                        'the last sums (one HIP event pair around _finish_exchange, outside every captured segment: launch of the 3 % bucket + '
+                        'wait for all three); per-bucket timings need the eager loop: bench.py --no-graph'}
+        trainer.comm_timing = None
     if trainer.buckets is not None and diag_comm:
         bt = {}
         for k, a, b in trainer.buckets.timing:
@@ -425,6 +508,8 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
                       'frac_of_%s_mfma_peak_whole_step_algorithmic' % tag: value / world * train_flop / peak,
                       'loss_raw': float(l_raw), 'loss_of': float(l_of) if l_of is not None else 0.0},
            'roofline': conv_roofline(bank, B, per, precision, overlap, traffic)}
+    if rec['roofline'] is not None:
+        rec['roofline'].update(family_rooflines(bank, B, per, precision))
     if rec['roofline'] is not None and pname and _STEP_BYTES.get(pname):
         # whole train step, same counter passes: HBM bytes per step and the rate that implies at this run's step time
         rec['roofline']['step_traffic_bytes'] = _STEP_BYTES[pname]
@@ -619,6 +704,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='cubes per GPU per step (32 with --gpus 8 = DataParallel split of 256)')
+    ap.add_argument('--dp-split-of', type=int, default=256, help='N > 1: global batch of the second, DataParallel-faithful record (one batch of '
+                    'this size split over the ranks, train.py:373-375); 0 = headline only')
     ap.add_argument('--pool', type=int, default=4096, help='device-resident synthetic cubes per GPU')
     ap.add_argument('--model', default='net4', choices=['net4', 'full'])
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
@@ -666,6 +753,16 @@ def main():
     rec = run_unet(args.model, args.precision, args.batch, args.steps, args.warmup, dev, rank, world, dist, args.overlap,
                    args.breakdown, args.pool, graph=not args.no_graph, measure_forward=not args.no_forward_timing,
                    ev_extra=0 if args.no_forward_timing else 4)
+    # N > 1: the second record SURVEY 8(d) asks for beside the weak-scaling headline -- the reference's own split (train.py:373-375:
+    # nn.DataParallel scatters ONE 256-cube batch over the GPUs => 256 / N cubes per rank and step, per-rank BatchNorm statistics)
+    rec_dp = None
+    dpg = args.dp_split_of
+    if world > 1 and not args.no_secondary and dpg > 0 and dpg % world == 0 and dpg // world != args.batch:
+        try:
+            rec_dp = run_unet(args.model, args.precision, dpg // world, min(50, max(args.steps, 4)), 5, dev, rank, world, dist, args.overlap,
+                              False, min(args.pool, 1024), graph=not args.no_graph, measure_forward=False, ev_extra=0)
+        except Exception as e:              # must not take the headline down
+            rec_dp = {'value': None, 'error': repr(e)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -676,6 +773,14 @@ def main():
            'roofline': rec['roofline'], 'execution': rec['execution']}
     if 'comm' in rec:
         out['comm'] = rec['comm']
+    out['config']['scaling_mode'] = 'weak: %d cubes per GPU and step, global batch %d' % (args.batch, args.batch * world)
+    if rec_dp is not None:
+        rec_dp['label'] = ('DataParallel-faithful strong split (train.py:373-375): ONE global batch of %d cubes over %d ranks = %d cubes per '
+                           'rank and step, per-rank BatchNorm statistics; value = whole-job cubes/s' % (dpg, world, dpg // world))
+        out.setdefault('configs', {})['dp_faithful_global_batch_%d' % dpg] = rec_dp
+        out['config'].update({'dp_faithful_cubes_per_s': rec_dp.get('value'), 'dp_faithful_ms_per_step': rec_dp.get('ms_per_step'),
+                              'dp_faithful_exposed_comm_us': (rec_dp.get('comm') or {}).get('exposed_comm_us_per_step'),
+                              'weak_exposed_comm_us': (rec.get('comm') or {}).get('exposed_comm_us_per_step')})
     if world == 1 and not args.no_secondary:
         sec = {}
         for name, fn in (('full_b512_bf16', lambda: run_unet('full', 'bf16', 512, 20, 5, dev, 0, 1, None, 'none', False, 2048,
@@ -697,7 +802,7 @@ def main():
         for nm, per in (('net4_b32', 'BASELINE configs[2] (batch 256 over 8 GPUs)'), ('net4_b16', "config.cfg's batch_size = 128 over 8 GPUs")):
             sec[nm]['baseline_config'] = 'per-rank workload of %s, measured on 1 GPU without the gradient exchange' % per
         sec['flownet2_1024x448']['baseline_config'] = 'configs[4]: FlowNet2 correlation+conv forward on 1024x436 frame pairs, 1xMI355X'
-        out['configs'] = sec
+        out.setdefault('configs', {}).update(sec)
         # scalar copies of the secondary headlines inside `config` (the driver's parsed record keeps top-level objects only)
         def _g(name, key):
             v = sec.get(name, {}).get(key)

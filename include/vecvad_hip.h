@@ -506,6 +506,9 @@ const char* vv_version(void);
  * VV_ERR_LAUNCH the HIP runtime's own text for the hipError_t carried in bits 8..); never printed by the library */
 const char* vv_status_string(int status);
 int vv_device_arch_ok(void); /* 1 when the current device is gfx950 */
+/* compute units of the current device (256 on an MI355X in SPX mode; 256 when there is no device to ask): what the persistent kernels
+ * size their grids with and what a host-side launch policy (k-splits, kernel routing) should use instead of a constant */
+int vv_num_cus(void);
 /* sizeof of a parameter struct as THIS library was compiled (which: 0 vv_view, 1 vv_conv_params, 2 vv_wgrad_params, 3 vv_pack_entry,
  * 4 vv_reduce_entry, 5 vv_fold_entry, 6 vv_bnbwd_params, 7 vv_outconv_params, 8 vv_conv2d_params; anything else: -1).  A binding
  * (cgo / ctypes) checks its own mirror of the struct against it once at load: vv_conv_params grew at its end in round 4. */

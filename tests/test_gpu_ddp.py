@@ -331,7 +331,7 @@ def test_bench_two_ranks_on_one_gpu_prints_one_valid_line():
     port = 31900 + (os.getpid() % 1000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--batch', '16',
-           '--pool', '64', '--no-cpu-baseline']
+           '--pool', '64', '--no-cpu-baseline', '--dp-split-of', '8']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -343,7 +343,15 @@ def test_bench_two_ranks_on_one_gpu_prints_one_valid_line():
     assert d['comm']['ranks'] == 2 and len(d['comm']['buckets']) == 3
     assert 0 < d['comm']['per_rank_cubes_per_s']['min'] <= d['comm']['per_rank_cubes_per_s']['max']
     assert '4 segment' in d['execution']['mode'], d['execution']
-    assert 'configs' not in d and np.isfinite(d['config']['loss_raw'])
+    assert np.isfinite(d['config']['loss_raw'])
+    # graph mode reports the exposed communication (one event pair around the last bucket + wait, between the captured segments)
+    assert d['comm']['exposed_comm_steps_timed'] >= 6 and d['comm']['exposed_comm_us_per_step'] > 0
+    # ... and the second, DataParallel-faithful record beside the weak-scaling headline: one 8-cube batch over 2 ranks
+    assert list(d['configs']) == ['dp_faithful_global_batch_8'], list(d.get('configs', {}))
+    dp = d['configs']['dp_faithful_global_batch_8']
+    assert dp['config']['batch_per_gpu'] == 4 and dp['config']['global_batch'] == 8 and dp['value'] > 0
+    assert d['config']['dp_faithful_cubes_per_s'] == dp['value'] and 'weak: 16 cubes per GPU' in d['config']['scaling_mode']
+    assert dp['comm']['exposed_comm_us_per_step'] > 0
 
 
 def test_bench_eight_ranks_on_one_gpu_dataparallel_split():
@@ -358,7 +366,7 @@ def test_bench_eight_ranks_on_one_gpu_dataparallel_split():
     port = 32900 + (os.getpid() % 1000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '3', '--batch', '4',
-           '--pool', '32', '--no-cpu-baseline']
+           '--pool', '32', '--no-cpu-baseline', '--dp-split-of', '0']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]

@@ -27,22 +27,34 @@ def test_train_then_test_scripts_match_reference(tmp_path, monkeypatch, precisio
     own fp32-vs-fp64 spread through the same 6 Adam steps is ~3e-4 on the scores
     (tests/test_oracle_golden.py::test_oracle_fp32_fp64_spread_after_training).  z-normalised frame scores abs <= 5e-3: the
     normalisation (s - mu) / sigma amplifies a relative per-cube error by mu / sigma = 106 (raw) + 35 (flow) on this training
-    set (sigma is 1 % of mu), so 5e-3 on z is a per-cube agreement of 3.5e-5 -- 30x tighter than the per-cube bar; observed
-    1.3e-3 at worst (1 of 240 frames above 1e-3), i.e. per-cube ~1e-5.  The 240-frame golden has graded anomalies
-    (normal and anomalous scores overlap, AUROC 0.768): one swapped pair moves its AUROC by 1.2e-4, so the AUROC bar is a real
-    statement there; on the 10-frame golden it only says the ranking is identical.
-    bf16 (`[mi355x] precision = bf16`, BASELINE config 4): bars at ~2x what round 3 observed against the REFERENCE's fp32 golden
-    (gpurun_out/observed.jsonl: per-cube training scores 6.4e-4 / 2.2e-4, first loss 5.3e-5, z-normalised frame scores 9.9e-3 on the
-    240-frame golden, AUROC 2.1e-4): training scores 2e-3, loss 2e-4, frame scores 2e-2, AUROC 1e-3 -- the fp32 path's own bars
-    except for the frame scores (x4: the z-normalisation amplifies a per-cube deviation by mu / sigma ~ 140).
-    Round 4, why the bf16 training-score bar is 2e-3 and not the fp32 path's 1e-3: after 6 Adam steps the bf16 path sits 6.4e-4 from
-    the reference's fp32 scores with the round-3 conv kernel and 1.26e-3 with the round-4 one (VV_CONV_GEMM16=0 / 1), although the
-    two kernels' convolution outputs are BIT-EQUAL (tests/test_gpu_bf16.py): they sum the BatchNorm partial sums in a different
-    order, scale / shift move by 1e-7 relative, a handful of activations on a bf16 rounding boundary flip by one ulp (2^-8), and
-    six training steps on 8-cube batches carry that to a coherent ~1e-3 shift of all 24 scores.  That spread between two correct
-    implementations IS the resolution of this comparison; the config's own criterion is the AUROC bar below."""
+    set (sigma is 1 % of mu), so 5e-3 on z is a per-cube agreement of 3.5e-5 -- 30x tighter than the per-cube bar.
+    OBSERVED (round 6, one box, gpurun_out/observed.jsonl = profiles/r06_parity_switches.jsonl; worst of the 10- and 240-frame goldens):
+
+        switch                               train_raw   train_of   frame (f240)   AUROC
+        default (F(2x2) Winograd fwd+dgrad)   3.19e-4     3.58e-5    3.84e-3        6.9e-5
+        VV_FUSE_BN_SUMS=0                     2.40e-4     3.16e-5    3.51e-3        6.9e-5
+        VV_WINO44=0 | dgrad                   (no effect: at 8-cube batches the policy routes no launch to F(4x4))
+        VV_WINOGRAD_WGRAD=0                   3.05e-4     3.49e-5    3.85e-3        6.9e-5
+        VV_WINOGRAD=0 (direct 3x3 kernels)    1.82e-4     4.08e-5    9.39e-4        6.9e-5
+
+    i.e. the 3.8e-3 on the z-normalised frame scores is the Winograd FORWARD / data-gradient form (a few ulp per layer, tested <= 2e-5
+    of the tensor maximum against the direct kernel) carried through six Adam steps and multiplied by mu / sigma ~ 141: a per-cube
+    agreement of 2.7e-5.  It has been there since the Winograd path became the default (round 2; the "1.3e-3" this docstring quoted
+    until round 5 was measured on the direct kernels of round 1 and never updated); neither the fused BatchNorm-backward sums nor
+    F(4x4) moved it.  The frame bar stays at 5e-3 = 1.3 x observed (tighter than 2 x observed); the per-cube bar is the north star's.
+    The 240-frame golden has graded anomalies (normal and anomalous scores overlap, AUROC 0.768): one swapped pair moves its AUROC
+    by 1.2e-4, so the AUROC bar is a real statement there; on the 10-frame golden it only says the ranking is identical.
+    bf16 (`[mi355x] precision = bf16`, BASELINE config 4), against the REFERENCE's fp32 golden.  OBSERVED (round 6, same run): training
+    scores 1.32e-3 / 1.45e-4, first loss 5.9e-5, z-normalised frame scores 6.55e-3 (7.25e-3 with VV_FUSE_BN_SUMS=0), AUROC 6.9e-5.  Bars =
+    2 x observed, rounded: training scores 2e-3 (unchanged since round 4), loss 1.2e-4 (was 2e-4), frame scores 1.4e-2 (was 2e-2), AUROC 1e-3
+    (the config's own criterion).  Why the bf16 training-score bar is 2e-3 and not the fp32 path's 1e-3 (round 4):
+    after 6 Adam steps the bf16 path sits 6.4e-4 from the reference's fp32 scores with the round-3 conv kernel and 1.26e-3 with the
+    round-4 one (VV_CONV_GEMM16=0 / 1), although the two kernels' convolution outputs are BIT-EQUAL (tests/test_gpu_bf16.py): they sum
+    the BatchNorm partial sums in a different order, scale / shift move by 1e-7 relative, a handful of activations on a bf16 rounding
+    boundary flip by one ulp (2^-8), and six training steps on 8-cube batches carry that to a coherent ~1e-3 shift of all 24 scores.
+    That spread between two correct implementations IS the resolution of this comparison."""
     monkeypatch.setenv('VV_PRECISION', precision)
-    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=5e-3, auc=1e-3), 'bf16': dict(train=2e-3, loss=2e-4, frame=2e-2, auc=1e-3)}[precision]
+    tol = {'fp32': dict(train=1e-3, loss=1e-3, frame=5e-3, auc=1e-3), 'bf16': dict(train=2e-3, loss=1.2e-4, frame=1.4e-2, auc=1e-3)}[precision]
     from oracle import unet_oracle as O
     import train as T
     import test as S

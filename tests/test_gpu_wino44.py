@@ -215,3 +215,32 @@ def test_eval_scoring_through_wino44(monkeypatch, mode):
         rs, os_ = O.score_pass(sd, O.bank_spec('net4'), x, x_of, n)
         np.testing.assert_allclose(res[mode][0], rs, rtol=1e-3)
         np.testing.assert_allclose(res[mode][1], os_, rtol=1e-3)
+
+
+def test_wino44_first_layers_wait_for_their_side_stream_pack(monkeypatch):
+    """with VV_WINO44=all the forward launches of conv0 / conv1 read F(4x4) panels that vv_pack_wino44 writes on the SIDE
+    stream of the captured two-stream forward; only the third conv joined that stream.  Captured steps with the side stream stalled in
+    front of each of its launches (FusedTrainer.debug_delay) must give the parameters of the one-stream order, bit for bit."""
+    from oracle import unet_oracle as O
+    from test_gpu_unet import _build
+    from vec_vad_amd.trainer import FusedTrainer
+    monkeypatch.setenv('VV_WINO44', 'all')
+    raw, flow = O.seeded_cubes(12, 1, 5)
+    rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+    outs = []
+    for overlap, delay in (('0', None), ('free', (1, 400000))):
+        monkeypatch.setenv('VV_GRAPH_OVERLAP', overlap)
+        net, _, _ = _build('net4', False)
+        net.train()
+        tr = FusedTrainer(net)
+        tr.debug_delay = delay
+        for s in range(4):          # eager, capturing, two replays: every step packs the panels of freshly updated weights
+            tr.step_cubes(rawd, flowd, torch.arange(12, device='cuda'))
+        torch.cuda.synchronize()
+        if delay:
+            cap = [c for k, c in tr._graphs.items() if k[0] == 'train'][0]
+            assert cap.schedule == 'free'
+            labels = [(c[2], m) for c, m in zip(cap.ws.fwdq[True].calls, cap.ws.fwdq[True].meta)]
+            assert dict(labels)['conv0'][1] == ('pack_wino44',) and dict(labels)['pack_wino44'][0] == 1
+        outs.append(tr.bank.params.clone())
+    assert torch.equal(outs[0], outs[1])

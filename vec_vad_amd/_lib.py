@@ -165,6 +165,7 @@ _SIGS = {
     'vv_abi_sizeof': (c_i32, [c_i32]),
     'vv_status_string': (C.c_char_p, [c_i32]),
     'vv_device_arch_ok': (c_i32, []),
+    'vv_num_cus': (c_i32, []),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -171,6 +171,7 @@ class UNetBank:
     def __init__(self, units, nf=32, tot_raw_num=5, tot_of_num=1, padding=False, active=None, device='cuda',
                  lambda_raw=1.0, lambda_of=1.0):
         self.lib = L.lib()
+        self.ncu = int(self.lib.vv_num_cus())      # compute units of the device: the launch policies below count rounds of this many workgroups
         self.units = list(units)
         self.G = len(self.units)
         self.nf, self.tot_raw, self.tot_of, self.padding = nf, tot_raw_num, tot_of_num, padding
@@ -279,6 +280,7 @@ class UNetBank:
         # 'set:f3,d10,...': explicit launches (probing)
         self.w44_mode = os.environ.get('VV_WINO44', 'dgrad').lower()
         self._w44_tables = {}
+        self._w44_eval_used = set()      # forward panels some eval plan routes to F(4x4): the only ones prepare_eval packs
         # VV_WINO44_EVAL: the same choice for the eval-mode forward on the folded model (test.py:312-345 scoring; no gradients, scores
         # and AUROC judged at 1e-3: a few 1e-6 per layer are noise there).  '1' (default): the policy of _w44; '0': none; 'all'
         self.w44_eval_mode = os.environ.get('VV_WINO44_EVAL', '1').lower()
@@ -450,19 +452,19 @@ class UNetBank:
         ws.out4_valid = False          # True while ws.out4 holds the reconstructions of the LAST forward on this workspace
         return ws
 
-    @staticmethod
-    def _ks_bf16(groups, ntiles):
+    def _ks_bf16(self, groups, ntiles):
         """k-split of a bf16 weight-gradient launch (one workgroup per CU): the largest split that keeps the launch in ONE round of 256
         workgroups -- unless one round leaves more than a third of the chip idle (the 160-workgroup launches of the 4x4 level and the
         first transposed conv at G = 10): then up to VV_WGRAD_BF16_ROUNDS (default 2) rounds, choosing the split with the smallest
         rounds x ceil(tiles / split) + 1."""
-        one = max(1, min(ntiles, 256 // groups))
+        ncu = self.ncu
+        one = max(1, min(ntiles, ncu // groups))
         rmax = int(os.environ.get('VV_WGRAD_BF16_ROUNDS', '2'))
-        if groups * one * 3 > 256 * 2 or rmax <= 1:
+        if groups * one * 3 > ncu * 2 or rmax <= 1:
             return one
         best, cost = one, -(-ntiles // one) + 1
-        for ks in range(one + 1, min(ntiles, 256 * rmax // groups) + 1):
-            c = -(-groups * ks // 256) * (-(-ntiles // ks) + 1)
+        for ks in range(one + 1, min(ntiles, ncu * rmax // groups) + 1):
+            c = -(-groups * ks // ncu) * (-(-ntiles // ks) + 1)
             if c < cost:
                 best, cost = ks, c
         return best
@@ -486,8 +488,8 @@ class UNetBank:
         if mode == 'all':
             return True
         wgs = self.Ga * (N // 32) * -(-self.lib.vv_wino44_ntiles(B, l.H) // 2)
-        rounds = wgs / 256.0
-        return K >= 64 and wgs >= 512 and rounds / math.ceil(rounds) >= 0.9
+        rounds = wgs / float(self.ncu)
+        return K >= 64 and wgs >= 2 * self.ncu and rounds / math.ceil(rounds) >= 0.9
 
     def _w44_pack(self, B):
         """device pack table (vv_pack_wino44) of the panels the plans for batch size B use; (tensor, entries, max K*N) or None"""
@@ -593,7 +595,10 @@ class UNetBank:
                               L.view(y, l.cout, 0, y.stride(0)), ws.stats.data_ptr() if train else None)
             P.keep.append(cp)
             P.add(lib.vv_conv_wino44 if w44 else lib.vv_conv_wino if self.wino else lib.vv_conv_mfma, (C.byref(cp),), 'conv%d' % l.idx,
-                  wait=tuple(pack_tail) if l.idx == 2 else ())
+                  # the third conv joins the side-stream packs; a launch of the FIRST TWO layers routed to F(4x4) (VV_WINO44=all | set:f0,f1)
+                  # reads a panel of that side-stream pack too and waits for it on its own (under the two-stream schedules it
+                  # read stale panels)
+                  wait=tuple(pack_tail) if l.idx == 2 else (('pack_wino44',) if (w44 and l.idx < 2) else ()))
             nt = lib.vv_wino44_ntiles(B, l.H) if w44 else lib.vv_wino_ntiles(B, l.H) if self.wino else \
                 lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag)
             P.add(lib.vv_bn_finalize,
@@ -668,17 +673,18 @@ class UNetBank:
             L.check(lib.vv_pack_wino(self.pack_table_w.data_ptr(), self.pack_w_n, G, self.params_eval.data_ptr(), lay.U,
                                      self.packed_eval.data_ptr(), lay.UP, self.pack_w_max, st), 'pack_wino (eval)')
             if self.w44_eval_mode not in ('0', 'off'):
-                if getattr(self, '_w44_eval_table', None) is None:
-                    keys = ['c%d.f' % l.idx for l in lay.convs if l.cinp % 8 == 0 and l.cinp <= 256]
+                if getattr(self, '_w44_eval_table', None) is None and self._w44_eval_used:
+                    keys = sorted(self._w44_eval_used)
                     ents = (L.PackEntry * len(keys))()
                     for i, k in enumerate(keys):
                         off, mode, K, KP, N, src = lay.pkw44[k]
                         ents[i] = L.PackEntry(lay.p[src][0], off, mode, K, KP, N)
                     self._w44_eval_table = (torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(self.device), len(keys),
                                             max(lay.pkw44[k][3] * lay.pkw44[k][4] for k in keys))
-                t = self._w44_eval_table
-                L.check(lib.vv_pack_wino44(t[0].data_ptr(), t[1], G, self.params_eval.data_ptr(), lay.U, self.packed_eval.data_ptr(), lay.UP,
-                                           t[2], st), 'pack_wino44 (eval)')
+                t = getattr(self, '_w44_eval_table', None)
+                if t is not None:
+                    L.check(lib.vv_pack_wino44(t[0].data_ptr(), t[1], G, self.params_eval.data_ptr(), lay.U, self.packed_eval.data_ptr(), lay.UP,
+                                               t[2], st), 'pack_wino44 (eval)')
         self._eval_key = key
 
     def _plan_eval(self, ws, B, out4=True):
@@ -726,6 +732,9 @@ class UNetBank:
             mode, s0, a, b, s1, csplit = src(l)
             y = ws.y[l.idx]
             w44 = self._w44(B, l, False, evalm=True)
+            if w44 and ('c%d.f' % l.idx) not in self._w44_eval_used:      # a panel no earlier plan used: repack on the next prepare_eval
+                self._w44_eval_used.add('c%d.f' % l.idx)
+                self._w44_eval_table, self._eval_key = None, None
             panel = (lay.pkw44 if w44 else lay.pkw if self.wino else lay.pk)['c%d.f' % l.idx][0]
             cp = L.ConvParams(L.CONV3, mode, Ga, B, l.H, l.H, l.cin, l.cinp, l.cout, s0, a, b, abg, s1, csplit, L.CONV_RELU | self.wino_flag, None,
                               kbase + 4 * panel, UP, pbase + 4 * lay.p['c%d.b' % l.idx][0], U, L.view(y, l.cout, 0, y.stride(0)), None)
@@ -783,9 +792,9 @@ class UNetBank:
             if self.wino_wgrad and not self.cflag:
                 # three workgroups per CU; 768 slots also at small batches (swept 256 / 384 / 512 / 768 at B = 32 and 256: fewer slabs
                 # shorten the grouped reduction but lengthen the weight-gradient launches by more)
-                ks = _pick_ksplit(Ga * nci * nco, nt, ncu=768, max_wg=3072)
+                ks = _pick_ksplit(Ga * nci * nco, nt, ncu=3 * self.ncu, max_wg=12 * self.ncu)
             else:
-                ks = _pick_ksplit(Ga * nci * nco, nt)
+                ks = _pick_ksplit(Ga * nci * nco, nt, ncu=self.ncu, max_wg=4 * self.ncu)
             wplan['c%d' % l.idx] = (ks, nci * nco * ks)
             if self.cflag and self.bf16_wgrad:
                 # bf16 weight gradient: HBM bound, one workgroup (up to 512 registers per lane) per CU
@@ -799,7 +808,7 @@ class UNetBank:
         for u, (_, H, ci, co) in enumerate(lay.convT):
             nci, nco = ci // 32, co // 32
             nt = lib.vv_wgrad_ntiles(L.CONVT_FWD, B, H, H)
-            ks = _pick_ksplit(Ga * nci * nco, nt)
+            ks = _pick_ksplit(Ga * nci * nco, nt, ncu=self.ncu, max_wg=4 * self.ncu)
             wplan['t%d' % u] = (ks, nci * nco * ks)
             if self.cflag and self.bf16_wgrad:
                 ntb, nblk, kw = C.c_int32(), C.c_int32(), C.c_int32()

@@ -35,6 +35,11 @@ __device__ __forceinline__ void vv_static_for(F&& f) {
     if (e__ != hipSuccess) return VV_HIP_STATUS(e__);       \
   } while (0)
 
+// compute units of the current device (vv_elem.hip, cached): the persistent kernels size their grids with it (one / two / VV_RING16_OCC
+// workgroups per CU), the host policies (vec_vad_amd/bank.py) their k-splits and Winograd F(4x4) routing -- 256 on an MI355X in SPX mode,
+// fewer on a partitioned device (CPX) or another part
+extern "C" int vv_num_cus(void);
+
 // vv_conv_bf16.hip: the GEMM-shaped 3x3 kernel of the all-bf16 launches (forward: VV_CONV_ALLSRC_BF16, data gradient: also
 // VV_CONV_SRC_BF16; output bf16).  vv_conv_mfma routes to it, vv_conv_ntiles2 reports its (256-pixel) tiles, under ONE predicate.
 int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st);

@@ -17,12 +17,6 @@
 #include "vv_common.h"
 // steps of distance between an LDS fragment read and its MFMAs in the bf16 kernels (measured on BASELINE config 4: 1 -> 41.1 k
 // cubes/s, 2 -> 40.5 k, 3 -> 38.6 k: the ring costs registers, and the kernels are bound by LDS bandwidth, not by its latency)
-// VV_EXPC (compile-time bit mask, default 0): elimination switches (every non-zero value computes WRONG results): 1 no MFMAs,
-// 2 global loads of the first chunk only, 4 LDS commit of the first chunk only, 8 no output stores, 16 no LDS fragment reads
-// after the first step of a chunk.
-#ifndef VV_EXPC
-#define VV_EXPC 0
-#endif
 #ifndef VV_PD_BF
 #define VV_PD_BF 1
 #endif
@@ -181,14 +175,8 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   issue(0);
   for (int c0 = 0; c0 < CinP; c0 += CK) {
     if (c0) __syncthreads();            // every wave finished reading the previous chunk
-#if (VV_EXPC & 4)
-    if (c0 == 0)
-#endif
     commit();
     __syncthreads();
-#if (VV_EXPC & 2)
-    if (false)
-#endif
     if (c0 + CK < CinP) issue(c0 + CK);
 
     {
@@ -231,9 +219,6 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 #pragma unroll
           for (int n = 0; n < NR; ++n) {
             const int an = KIND == VV_CONVT_FWD ? phc : n;
-#if (VV_EXPC & 1)
-            acc[m][an][0] += fa[cur][m].x * fb[cur][n].x;
-#else
             if constexpr (BF) {
               acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fa[cur][m]),
                                                                    __builtin_bit_cast(v8bf, fb[cur][n]), acc[m][an], 0, 0, 0);
@@ -243,10 +228,6 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
               acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].z, fb[cur][n].z, acc[m][an], 0, 0, 0);
               acc[m][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m].w, fb[cur][n].w, acc[m][an], 0, 0, 0);
             }
-#endif
-#if (VV_EXPC & 16)
-            if (false)
-#endif
             if (it + PD < NIT) {
               const int last = (m == MR - 1 && n == NR - 1);
               // spread MR+NR reads over MR*NR MFMA groups (the last group takes whatever is left)
@@ -327,9 +308,6 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         const int pp = it / QN;
         const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
         const int img = img0 + im;
-#if (VV_EXPC & 8)
-        if (acc[0][0][0] == 123.456f)
-#endif
         if (img < p.B) {
           const uint4 v = *reinterpret_cast<const uint4*>(lo + pp * ORS + (tid % QN) * 8);
           *reinterpret_cast<uint4*>(obase + ((int64_t)(img * OH + ty0 + r) * OW + tx0 + c) * ocs) = v;
@@ -390,9 +368,6 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const int pp = wave * (32 * MR) + m * 32 + row;
       const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
       const int img = img0 + im;
-#if (VV_EXPC & 8)
-      if (acc[m][0][i] == 123.456f)
-#endif
       if (img < p.B) {
         if constexpr (KIND == VV_CONVT_FWD) {
           const int64_t e = ((int64_t)(img * OH + 2 * (ty0 + r)) * OW + 2 * (tx0 + c)) * ocs + co0 + l31;

@@ -26,9 +26,6 @@
 // Tiles are the fp32 kernel's (vv_conv_ntiles): 8x32 / 16x16 / 4 images of 8x8 / 16 images of 4x4.
 #include "vv_common.h"
 
-#ifndef VV_EXPG
-#define VV_EXPG 0          // elimination switches (wrong results): 1 no MFMAs, 2 no B loads after the prologue, 4 no A staging after chunk 0, 8 no stores
-#endif
 
 namespace {
 
@@ -259,9 +256,6 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   auto xoff = [&](const int ch) -> int { return (TN > osplit && ch >= osplit) ? o1d - osplit * 2 : 0; };
   auto tile_xoff = [&](const int nn) -> int { return (TN <= osplit && nn * TN >= osplit) ? o1d - osplit * 2 : 0; };
   float* const pstats = p.stats;
-#if (VV_EXPG & 512)
-  float* const pdbg = p.bn_partial;                                    // per-role cycle counters of a PROFILING build only (bench scripts pass a scratch tensor)
-#endif
   constexpr int TPI = TW / TH;                                         // tiles per image: H == W == TW on every level (vv_conv_gemm16)
   static_assert(TW % TH == 0 && (TPI & (TPI - 1)) == 0, "a tile is TH full rows of a TW x TW image");
   UnitStep ustep;
@@ -269,14 +263,8 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
   const int Cout = p.Cout, CinP = p.CinP, KGT = CinP >> 4;
   const int nchunk = CinP / CK;
   const int F = ntile * nchunk;                                        // chunk iterations of this workgroup
-#if (VV_EXPG & 512)
-  long long tA = 0, tB = 0, tC = 0, tD = 0, t0_ = __builtin_readcyclecounter(), ta = 0, tb0;
-#define PT(acc_) do { tb0 = __builtin_readcyclecounter(); acc_ += tb0 - ta; ta = tb0; } while (0)
-#define PT0() ta = __builtin_readcyclecounter()
-#else
 #define PT(acc_)
 #define PT0()
-#endif
 
   if (producer) {
     // =========================================================== producers
@@ -372,11 +360,7 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         if (NITEMS % NTH == 0 || k < NIT - 1 || slot[k] != 0xFFFFFFFFu) {
-#if (VV_EXPG & 2048)
-          uint4 h = make_uint4(k, slot[k], k, k);          // elimination: the halo loads are never waited for
-#else
           uint4 h = r[S_][k];
-#endif
           if (act[S_]) {                   // (wave-uniform)  padding items were loaded as zeros and must stay zeros: mask, no branch
             const uint2 lo = vv_pack_bf16x4(vv_act4(vv_unpack_bf16x4(make_uint2(h.x, h.y)), sa[S_], sb[S_]));
             const uint2 hi = vv_pack_bf16x4(vv_act4(vv_unpack_bf16x4(make_uint2(h.z, h.w)), sa2[S_], sb2[S_]));
@@ -481,20 +465,12 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       begin_tile();                                                    // the last tile
       do_parts(NPARTS);
     }
-#if (VV_EXPG & 512)
-    if (t == 0 && pdbg) {
-      float* d = pdbg + blockIdx.x * 8 + 4;
-      d[0] = (float)tA; d[1] = (float)tB; d[2] = (float)tC; d[3] = (float)tD; (void)t0_;
-    }
-#endif
     return;
   }
 
   // =========================================================== consumers
   const int wm = wave / WN, wn = wave % WN;
-#if !(VV_EXPG & 1024)
   __builtin_amdgcn_s_setprio(1);
-#endif
   int abase[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
@@ -714,12 +690,6 @@ conv_gemm16p_kernel(const vv_conv_params p, const int NT, const int NN, const in
       PT(tC);
     }
   }
-#if (VV_EXPG & 512)
-  if (tid == 0 && pdbg) {
-    float* d = pdbg + blockIdx.x * 8;
-    d[0] = (float)tA; d[1] = (float)tB; d[2] = (float)tC; d[3] = (float)(__builtin_readcyclecounter() - t0_);
-  }
-#endif
 }
 
 template <int TH, int TW, int NI, int WM, int MR, int NR, int CK, int OUTB, int NB, int RS, int BRES, int PW = 4>
@@ -741,9 +711,7 @@ int launch_p(const vv_conv_params* p, hipStream_t st, const int ncu) {
 // NB3: three LDS tile buffers fit beside the output region(s) of every N-tile width at this level
 template <int TH, int TW, int NI, int CK, bool NB3, int RS, int PW = 4>
 int dispatch_p(const vv_conv_params* p, hipStream_t st) {
-  int dev = 0, ncu = 0;                                                // one persistent workgroup per CU
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-    ncu = 256;
+  const int ncu = vv_num_cus();                                        // one persistent workgroup per CU
   constexpr int NB = NB3 ? 3 : 2;
   // (eight producer waves = three waves per SIMD, 168 registers: the 128-wide tiles and the 64-channel resident filter do not fit)
   if constexpr (PW == 4) {
@@ -763,9 +731,7 @@ int dispatch_p(const vv_conv_params* p, hipStream_t st) {
 
 int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st) {
   if (p->H != p->W || p->CinP % 16 || p->Cout % 32) return VV_ERR_UNSUPPORTED;
-#if !(VV_EXPG & 512)
   if (p->bn_partial) return VV_ERR_UNSUPPORTED;      // the BatchNorm-backward sums are an epilogue of conv_mfma_kernel's 32-wide launches only
-#endif
   if (p->in_mode != VV_IN_PLAIN && p->in_mode != VV_IN_ACT && p->in_mode != VV_IN_CAT) return VV_ERR_UNSUPPORTED;
   // 16-byte items of 8 channels: every channel offset / stride a multiple of 8 elements
   if (p->src0.cstride % 8 || p->src0.coff % 8 || p->out.cstride % 8 || p->out.coff % 8) return VV_ERR_BAD_ARG;
@@ -779,9 +745,6 @@ int vv_conv_gemm16(const vv_conv_params* p, hipStream_t st) {
   }
   const bool ck32 = p->CinP % 32 == 0 && (p->in_mode != VV_IN_CAT || p->csplit % 32 == 0);
   switch (p->H) {      // (32x32: vv_conv_mfma keeps those launches on conv_mfma_kernel, see the header)
-#if (VV_EXPG & 4096)
-    case 32: return ck32 ? dispatch_p<8, 32, 1, 32, false, 2, 8>(p, st) : dispatch_p<8, 32, 1, 16, true, 2, 8>(p, st);
-#endif
     case 16: return ck32 ? dispatch_p<16, 16, 1, 32, false, 2>(p, st) : dispatch_p<16, 16, 1, 16, true, 2>(p, st);
     case 8: return ck32 ? dispatch_p<8, 8, 4, 32, false, 2>(p, st) : dispatch_p<8, 8, 4, 16, true, 2>(p, st);
     case 4: return dispatch_p<4, 4, 16, 16, false, 2>(p, st);

@@ -346,7 +346,7 @@ int launch_ring16(const vv_conv_params* p, hipStream_t st) {
   const int NT = p->B * 4;
   const int NN = p->Cout / 32;
   const int total = p->G * NN * NT;
-  const int slots = VV_RING16_OCC * 256;
+  const int slots = VV_RING16_OCC * vv_num_cus();
   const int ipw = (total + slots - 1) / slots;
   const int nwg = (total + ipw - 1) / ipw;
   if (p->bn_partial)

@@ -1667,6 +1667,16 @@ extern "C" const char* vv_status_string(int status) {
   }
 }
 
+extern "C" int vv_num_cus(void) {
+  static int cached[16] = {0};           // per device ordinal; hipDeviceGetAttribute is legal during stream capture
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < 16 && cached[dev] > 0) return cached[dev];
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 256;
+  if (dev >= 0 && dev < 16) cached[dev] = ncu;
+  return ncu;
+}
+
 extern "C" int vv_device_arch_ok(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;

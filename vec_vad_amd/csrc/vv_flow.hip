@@ -183,18 +183,12 @@ correlation_nhwc_kernel(const float* __restrict__ f1, const float* __restrict__ 
   bool work = false;
 #pragma unroll
   for (int d = 0; d < DPW; ++d) work = work || rowvalid(1 + wave * DPW + d);
-#if defined(VV_EXP_CORR) && VV_EXP_CORR == 1
-  work = false;          // experiment: staging only
-#endif
 
   issue(0);
   for (int c0 = 0; c0 < C; c0 += CK) {
     __syncthreads();                       // previous chunk fully consumed (first pass: zero fill done)
     commit();
     __syncthreads();
-#if defined(VV_EXP_CORR) && VV_EXP_CORR == 2
-    if (false)               // experiment: no global loads after the first chunk
-#endif
     if (c0 + CK < C) issue(c0 + CK);
     if (work) {
       // per channel group: 6 window blocks (4, 4, 4, 4, 4, 2 positions) in a software pipeline -- the reads of block g+1 are

@@ -596,15 +596,9 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     __builtin_amdgcn_s_barrier();                                // tile 0 is ready
     for (int it = 0; it < ntl; ++it) {
       // the consumers are multiplying tile `it`; the slot of tile it-1 is free: refill it NBUF-1 tiles ahead, then finish tile it+1
-#if defined(VV_EXPR) && (VV_EXPR == 3 || VV_EXPR == 4)
-      issue(ks + (it + NBUF - 1) * KS, (it + NBUF - 1) % NBUF, false);                // elimination run: no HBM traffic
-#else
       issue(ks + (it + NBUF - 1) * KS, (it + NBUF - 1) % NBUF, it + NBUF - 1 < ntl);
-#endif
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NLW) : "memory");       // this wave's pieces of tile it+1 have landed
-#if !defined(VV_EXPR) || (VV_EXPR != 2 && VV_EXPR != 4)
       if (it + 1 < ntl) activate(ks + (it + 1) * KS, (it + 1) % NBUF);
-#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -638,9 +632,6 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
     const int slot = it % NBUF;
     const vv_lds_t xt = lbase + slot * TB + xoff;
     const vv_lds_t yt = lbase + slot * TB + yoff;
-#if defined(VV_EXPR) && VV_EXPR == 1
-    if (true) {} else                                           // elimination run: no operand reads, no MFMAs
-#endif
     if constexpr (TW == 4) {
       // 4x4 level: a K step is one image; the lane's 8 pixels are rows 2*half, 2*half+1 (first / second read), column j
       constexpr int NKS = NI / KW;
@@ -696,13 +687,8 @@ wgrad_ring_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
             // (dy first: the next step's first six MFMAs need only it of these eight reads -- their halo rows are older)
             bq[(k + 1) & 1] = vv_tr8(yp, (k + 1) * TW * 64, ((k + 1) * TW + 4) * 64);
             win[(k + 3) % 4][0] = vv_tr8(xp, ro + 0 * 64, ro + 4 * 64);
-#if defined(VV_EXPR) && VV_EXPR == 7
-            win[(k + 3) % 4][1] = win[(k + 3) % 4][0];             // elimination run: one halo-row read instead of three
-            win[(k + 3) % 4][2] = win[(k + 3) % 4][0];
-#else
             win[(k + 3) % 4][1] = vv_tr8(xp, ro + 1 * 64, ro + 5 * 64);
             win[(k + 3) % 4][2] = vv_tr8(xp, ro + 2 * 64, ro + 6 * 64);
-#endif
           }
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)

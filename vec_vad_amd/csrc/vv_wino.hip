@@ -27,17 +27,8 @@
 #include <cstdlib>
 #include <type_traits>
 #include "vv_common.h"
-// VV_EXPM (compile-time bit mask, default 0): elimination switches used to find where the time goes (profiles/README.md) --
-// every value other than 0 computes WRONG results: 1 no MFMAs, 2 no halo loads, 4 no tap reloads, 8 no output stores,
-// 32 no LDS commit.
-#ifndef VV_EXPM
-#define VV_EXPM 0
-#endif
-// VV_EXPR (bit mask, default 0): the same for wino_ring_kernel -- 1 no MFMAs, 2 no HBM reads (every DMA lane out of range), 4 no output
-// stores, 8 no epilogue, 16 no activation pass, 32 no chunk barriers.  VV_RING_D: prefetch distance.
-#ifndef VV_EXPR
-#define VV_EXPR 0
-#endif
+// VV_RING_D: prefetch distance of wino_ring_kernel.  (The elimination builds profiles/README.md quotes -- kernels with the MFMAs, the loads,
+// the stores ... compiled out -- are not part of the shipped text: they are at git 536a9ae, switches VV_EXPM / VV_EXPR / VV_EXPC / VV_EXPG / VV_EXP4.)
 #ifndef VV_RING_D
 #define VV_RING_D 4
 #endif
@@ -152,18 +143,13 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
     const int second = __builtin_amdgcn_readfirstlane((int)((s.mode == VV_IN_CAT) && c0 >= s.csplit));
     if (second != cur_second) set_source(second != 0);
-#if !(VV_EXPM & 2)
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[k], c0 * 4 + soff0, 0);
       r[k] = make_float4(v.x, v.y, v.z, v.w);
     }
-#endif
   };
   auto commit = [&]() {
-#if (VV_EXPM & 32)
-    return;
-#endif
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
       if (NITEMS % WN == 0 || k < NIT - 1 || slot[k] >= 0) {
@@ -215,12 +201,6 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     for (int n = 0; n < 4; ++n) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-#if (VV_EXPM & 1)
-        if (decltype(first)::value)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[nb][n][i] = 0.f;
-        acc[nb][n][0] += V[n].x * u[nb][n].x + V[n].y * u[nb][n].y + V[n].z * u[nb][n].z + V[n].w * u[nb][n].w;
-#else
         if constexpr (decltype(first)::value) {   // the accumulators start from the instruction's inline-constant 0
           const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[nb][n].x, z, 0, 0, 0);
@@ -230,10 +210,7 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[nb][n].y, acc[nb][n], 0, 0, 0);
         acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].z, u[nb][n].z, acc[nb][n], 0, 0, 0);
         acc[nb][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].w, u[nb][n].w, acc[nb][n], 0, 0, 0);
-#endif
-#if !(VV_EXPM & 4)
         u[nb][n] = load_u(knext, n, nb);
-#endif
         __builtin_amdgcn_sched_barrier(SB_MASK);
       }
     }
@@ -333,9 +310,6 @@ wino_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         yb[0] = yb[0] < lo ? lo : yb[0]; yb[1] = yb[1] < lo ? lo : yb[1];
         const int so = (((img0 + im) * H_ + oy) * H_ + ox) * ocs * 4;
         const float a0 = ya[0], a1v = ya[1], b0 = yb[0], b1 = yb[1];
-  #if (VV_EXPM & 8)
-        if (a0 + a1v + b0 + b1 == 123.456f)
-  #endif
         {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0), rsO, vo, so, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a1v), rsO, vo, so + ocs * 4, 0);
@@ -489,7 +463,7 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
                                             0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      voff[k] = (live && xok[k] && !(yflag[k] & ym) && !(VV_EXPR & 2)) ? (unsigned)(tileoff + rel[k]) : 0x80000000u;
+      voff[k] = (live && xok[k] && !(yflag[k] & ym)) ? (unsigned)(tileoff + rel[k]) : 0x80000000u;
   };
   int slotd = 0;               // ring slot the next DMA pair fills
   auto dma_chunk = [&](const int c) {
@@ -562,7 +536,7 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW - STORES_MIN) : "memory");
-    if (act_mode && !(VV_EXPR & 16)) {
+    if (act_mode) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         if (xok[k] && !(yflag[k] & ym)) {
@@ -643,15 +617,6 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const bool last = c == KQ - 1;
       const int slotn = slotc + 1 == NBUF ? 0 : slotc + 1;
       auto mfma_k = [&](const int k) {
-#if (VV_EXPR & 1)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          if (c == 0 && k == 0)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-          acc[n][0] += V[n][k] * u[c][n][k];
-        }
-#else
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           if (c == 0 && k == 0) {
@@ -661,7 +626,6 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n][k], u[c][n][k], acc[n], 0, 0, 0);
           }
         }
-#endif
       };
       // (the four GEMMs' MFMAs interleaved, k step outermost: consecutive matrix instructions write DIFFERENT accumulators, each
       //  accumulator sees its k steps in the order x, y, z, w -- bit-identical to the per-tile kernel's nu-major issue)
@@ -677,9 +641,7 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       __builtin_amdgcn_sched_barrier(0);
       mfma_k(2);
       __builtin_amdgcn_sched_barrier(0);
-#if !(VV_EXPR & 32)
       vv_lds_barrier();                          // chunk j + 1 is complete in LDS; the column sums of the tile before are too
-#endif
       if (c == 0 && pend) flush_stats();
       if (!(last && cross)) fetch(slotn);
       __builtin_amdgcn_sched_barrier(0);
@@ -690,11 +652,6 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
     if (cross) restart = true;
 
-#if (VV_EXPR & 8)
-    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.456f) sp[tid] = 1.f;
-    advance(gc, nc, ptc);
-    continue;
-#endif
     // ---- epilogue (wino_conv_kernel's, on its own LDS region: the ring keeps filling underneath)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -733,9 +690,6 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
         yb[0] = yb[0] < 0.f ? 0.f : yb[0]; yb[1] = yb[1] < 0.f ? 0.f : yb[1];
       }
       const int so = ((img * H_ + oy) * H_ + ox) * ocs * 4;
-#if (VV_EXPR & 4)
-      if (ya[0] + ya[1] + yb[0] + yb[1] == 123.456f)
-#endif
       {
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[0]), rsO, vo, so, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ya[1]), rsO, vo, so + ocs * 4, 0);
@@ -835,7 +789,7 @@ int launch_wino_ring(const vv_conv_params* p, hipStream_t st) {
   const int NT = p->B * 8;
   const int NN = p->Cout / 32;
   const int total = p->G * NN * NT;
-  const int slots = 2 * 256;
+  const int slots = 2 * vv_num_cus();
   const int ipw = (total + slots - 1) / slots;
   const int nwg = (total + ipw - 1) / ipw;
   if (p->bn_partial)          // (data-gradient launches: never with the eval path's ReLU)

@@ -36,11 +36,6 @@
 // to it by that policy; forward launches of a train step only on request (VV_WINO44=1 | all).
 #include <type_traits>
 #include "vv_common.h"
-// VV_EXP4 (compile-time bit mask, default 0; any other value computes WRONG results): 1 no MFMAs, 2 no halo loads, 4 no tap reloads,
-// 8 no output stores
-#ifndef VV_EXP4
-#define VV_EXP4 0
-#endif
 namespace {
 
 constexpr int W4N = 384;               // threads per sub-group: one wave per xi
@@ -219,7 +214,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
     for (int k = 0; k < NIT; ++k) {
       // (branch-free: bit 31 set = out of range = zeros; a ?: here became a branch around every load)
       const unsigned vo_ = ((unsigned)((tile + (int)(itm[k] & 0xFFFFu)) * cs + q4) * 4u) |
-                           (((((valid >> k) & 1u) ^ 1u) | ((VV_EXP4 & 2) ? 1u : 0u)) << 31);
+                           ((((valid >> k) & 1u) ^ 1u) << 31);
       const v4f v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo_, soff, 0);
       r[k] = make_float4(v.x, v.y, v.z, v.w);
     }
@@ -248,11 +243,7 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
   };
   v2f u[6];
   auto load_u = [&](const int step, const int n) -> v2f {    // step = chunk * 2 + sub-step
-#if (VV_EXP4 & 4)
-    return (v2f){1.f, 1.f};
-#else
     return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsW, bvo, bxi + n * bnu + step * bsub, 0));
-#endif
   };
 
   // ---- this lane's tile and its patch origin in LDS
@@ -303,12 +294,6 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
     }
     __builtin_amdgcn_sched_barrier(SB4_MASK);
     // tap n has landed (the asm ties the wait to the register the MFMA reads); written out six times: the count must be a literal
-#if (VV_EXP4 & 1)
-#define W4_X(n)                                                                                        \
-    if (decltype(first)::value) { _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[n][i] = 0.f; }     \
-    acc[n][0] += V[n].x * u[n].x;
-#define W4_Y(n) acc[n][0] += V[n].y * u[n].y;
-#else
 #define W4_X(n)                                                                                        \
     if constexpr (decltype(first)::value) {                                                             \
       const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   \
@@ -317,7 +302,6 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
       acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].x, u[n].x, acc[n], 0, 0, 0);                    \
     }
 #define W4_Y(n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n].y, u[n].y, acc[n], 0, 0, 0);
-#endif
     // nu-major: both k steps of a tap back to back, then the tap's reload -- every tap is requested ten MFMAs + one input transform
     // ahead of its next use (k-step-major order left the last tap four MFMAs: every sub-step waited for an L2 round trip)
 #pragma unroll
@@ -469,9 +453,6 @@ wino44_conv_kernel(const vv_conv_params p, const int NT, const int NN, const int
         }
         if (jok[k]) {
           const int so = so_[k] * ocs * 4;
-#if (VV_EXP4 & 8)
-          if (ya[0] + yb[1] == 123.456f)
-#endif
           {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

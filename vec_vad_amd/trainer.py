@@ -271,7 +271,9 @@ class FusedTrainer:
 
     # ---- hipGraph capture of a whole step
     def _graph_ok(self):
-        return (self.use_graph and not self.overlap and self.event_hook is None and self.comm_timing is None
+        # (comm_timing does not prevent the replay: _finish_exchange runs eagerly BETWEEN the captured segments, so its event pair
+        # is recorded outside every capture; the per-bucket timing of GradBuckets wraps the collectives themselves and needs the eager loop)
+        return (self.use_graph and not self.overlap and self.event_hook is None
                 and (self.buckets is None or self.buckets.timing is None) and self.bank.device.type == 'cuda')
 
     def _graph_dual(self, B):
