@@ -12,6 +12,7 @@
 // (bitwise reproducible) and scatters into the PyTorch parameter layout.
 //
 // Replaces the autograd weight gradients of nn.Conv2d / nn.ConvTranspose2d (model/unet.py:10,13,54; cuDNN).
+#include <cstdlib>
 #include "vv_common.h"
 
 namespace {
@@ -26,9 +27,10 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
   constexpr int AHH = CT ? TH : TH + 2, AHW = CT ? TW : TW + 2;
   constexpr int BHH = CT ? 2 * TH + 1 : TH, BHW = CT ? 2 * TW + 1 : TW;
   constexpr int ASZ = NI * AHH * AHW * 32, BSZ = NI * BHH * BHW * 32, TSZ = ASZ + BSZ;
-  // 3x3 convolutions: two LDS tile buffers, the staging of tile t+1 (loads, BN+ReLU, LDS writes) is spread over the MFMA
-  // loop of tile t.  Transposed convolutions (larger dy halo tiles, 4 % of the weight-gradient time) keep one buffer.
-  constexpr bool DB = !CT && 2 * TSZ * 4 <= 160 * 1024;
+  // Two LDS tile buffers where they fit: the staging of tile t+1 (loads, BN+ReLU, LDS writes) is spread over the MFMA loop of tile t.
+  // 3x3 convolutions always; transposed convolutions with the 64-pixel tiles of round 6 (their dy halo tile is (2TH+1) x (2TW+1) pixels:
+  // 50 KB per buffer at 64 pixels, 88 - 99 KB at 128, where the one-buffer form below stays: commit and MFMA phases take turns).
+  constexpr bool DB = 2 * TSZ * 4 <= 160 * 1024;
   __shared__ float lds[DB ? 2 * TSZ : TSZ];
   float* lA = lds;
   float* lB = lds + ASZ;
@@ -113,8 +115,8 @@ wgrad_mfma_kernel(const vv_wgrad_params p, const int NT, const int NCI, const in
       const int img0 = (pt / tpi) * NI;
       const int trem = pt % tpi;
       const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
-      stA.begin(sa, img0, ty0 - 1, tx0 - 1, cit * 32, tid, p.CinP, live);
-      stB.begin(sb, img0, ty0, tx0, cot * 32, tid, 1 << 30, live);
+      stA.begin(sa, img0, CT ? ty0 : ty0 - 1, CT ? tx0 : tx0 - 1, cit * 32, tid, p.CinP, live);
+      stB.begin(sb, img0, CT ? 2 * ty0 - 1 : ty0, CT ? 2 * tx0 - 1 : tx0, cot * 32, tid, 1 << 30, live);
     };
     begin_tile(ks, true);
     vv_static_for<0, NPA>([&](auto K) { stA.template load_piece<K.value>(sa, -1, tid); });
@@ -547,6 +549,13 @@ wgrad_reduce_grouped_kernel(const vv_reduce_entry* __restrict__ table, const int
   }
 }
 
+// VV_WGRADT_TILE64 (default 1): the transposed convs' weight gradient walks 64-pixel k-split tiles on the double-buffered pipeline;
+// 0 = the 128-pixel tiles / one LDS buffer of rounds 1 - 5 (A/B on one box; read once per process)
+inline bool wgradT_tile64() {
+  static const int v = [] { const char* e = getenv("VV_WGRADT_TILE64"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v != 0;
+}
+
 struct WGeo { int TH, TW, NI; };
 inline bool wgeo(int kind, int H, int W, WGeo* t) {
   if (H != W) return false;
@@ -555,6 +564,10 @@ inline bool wgeo(int kind, int H, int W, WGeo* t) {
     if (H == 16) { *t = {16, 16, 1}; return true; }
     if (H == 8) { *t = {8, 8, 2}; return true; }
     if (H == 4) { *t = {4, 4, 8}; return true; }
+  } else if (wgradT_tile64()) {
+    if (H == 16) { *t = {4, 16, 1}; return true; }
+    if (H == 8) { *t = {4, 8, 2}; return true; }
+    if (H == 4) { *t = {4, 4, 4}; return true; }
   } else {
     if (H == 16) { *t = {8, 16, 1}; return true; }
     if (H == 8) { *t = {8, 8, 2}; return true; }
@@ -616,6 +629,12 @@ extern "C" int vv_wgrad_mfma(const vv_wgrad_params* p, vv_stream stream) {
       case 16: return launch_w<16, 16, 1, VV_CONV3>(p, st);
       case 8: return launch_w<8, 8, 2, VV_CONV3>(p, st);
       case 4: return launch_w<4, 4, 8, VV_CONV3>(p, st);
+    }
+  } else if (wgradT_tile64()) {
+    switch (p->H) {
+      case 16: return launch_w<4, 16, 1, VV_CONVT_FWD>(p, st);
+      case 8: return launch_w<4, 8, 2, VV_CONVT_FWD>(p, st);
+      case 4: return launch_w<4, 4, 4, VV_CONVT_FWD>(p, st);
     }
   } else {
     switch (p->H) {
