@@ -138,6 +138,9 @@ int vv_conv_mfma(const vv_conv_params* p, vv_stream stream);
 /* number of pixel tiles the kernel uses for this (B,H,W): rows of the `stats` partial array */
 int vv_conv_ntiles(int32_t B, int32_t H, int32_t W);
 /* the same for a launch with these `kind` / pad0 `flags` (the bf16 3x3 kernels use 128-pixel tiles on the 8x8 / 4x4 levels) */
+/* pixel tiles of a VV_CONVT_DGRAD launch of vv_conv_mfma (H x W = its output = the transposed conv's INPUT resolution; flags: the
+ * launch's pad0, only VV_CONV_BF16 matters) = the rows of bn_partial such a launch leaves; -1 for an unsupported size */
+int vv_convt_dgrad_ntiles(int32_t B, int32_t H, int32_t W, int32_t flags);
 int vv_conv_ntiles2(int32_t B, int32_t H, int32_t W, int32_t kind, int32_t flags);
 
 /* Weight-gradient (autograd of nn.Conv2d / nn.ConvTranspose2d wrt weight; cuDNN in the reference).
@@ -260,6 +263,8 @@ int vv_bn_finalize(int32_t G, int32_t C, int32_t ntiles, int64_t count, int32_t 
 #define VV_BNBWD_PARTIALS_PER_TILE 16  /* vv_bn_bwd_apply: `partial` holds [G][vv_wino_ntiles(B,H)][2][C] written by the data-gradient
                                           launch that produced dA (vv_conv_params.bn_partial): no vv_bn_bwd_reduce pass for that layer */
 #define VV_BNBWD_PARTIALS_PER_CTILE 32 /* the same for a data-gradient launch of vv_conv_mfma (all-bf16 tensors): [G][vv_conv_ntiles(B,H,W)][2][C] */
+#define VV_BNBWD_PARTIALS_PER_TTILE 128  /* ... of the transposed conv's data gradient (vv_conv_mfma, VV_CONVT_DGRAD, fp32 kernel):
+                                           [G][vv_convt_dgrad_ntiles(B,H,W,0)][2][C] */
 #define VV_BNBWD_PARTIALS_PER_TILE44 64 /* the same for a data-gradient launch of vv_conv_wino44: [G][vv_wino44_ntiles(B,H)][2][C] */
 typedef struct vv_bnbwd_params {
   int32_t G, B, H, W, C;

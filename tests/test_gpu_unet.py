@@ -282,7 +282,7 @@ def test_hipgraph_step_and_scoring_bitwise_equal_to_eager(monkeypatch, precision
             ws = tr.step_cubes(rawd, flowd, p)
             losses.append(torch.stack([x for x in tr.losses(ws) if x is not None]).clone())
         cap = [c for k, c in tr._graphs.items() if k[0] == 'train' and c != 'warm']
-        assert (len(cap) == 1 and len(cap[0].segments) == 1 and cap[0].launches > 100) if graph else not cap
+        assert (len(cap) == 1 and len(cap[0].segments) == 1 and cap[0].launches >= 95) if graph else not cap
         assert tr.bank.adam_t == 7 and int(tr.bank._adam_t_dev.item()) == 7
         net.eval()
         sc = []
@@ -323,6 +323,42 @@ def test_bn_backward_sums_fused_into_data_gradient(monkeypatch):
         a, b = grads[0][:, off:off + n].double(), grads[1][:, off:off + n].double()
         worst = max(worst, ((a - b).norm() / a.norm().clamp_min(1e-30)).item())
     assert 0.0 < worst <= 1e-5, worst          # > 0: the two paths really are different code
+
+
+def test_bn_backward_sums_fused_into_transposed_conv_data_gradient(monkeypatch):
+    """Round 6: layers 7 / 9 / 11 feed only a transposed conv, so their dA is that transposed conv's data gradient (vv_conv_mfma,
+    VV_CONVT_DGRAD) -- its epilogue leaves sum dz, sum dz * xhat per 128-pixel tile (VV_BNBWD_PARTIALS_PER_TTILE) and the three
+    vv_bn_bwd_reduce passes go.  VV_FUSE_BN_SUMS_T=0 keeps them.  Same sums in another order: gradients agree to fp32 round-off
+    (bar 1e-5 of a tensor's norm, the Winograd fusion's bar); bit-identical upstream of the first fused launch; ragged batches (B = 37:
+    partial tiles on the 8x8 / 4x4 levels, B = 3: a single partial tile)."""
+    from oracle import unet_oracle as O
+    from vec_vad_amd.trainer import FusedTrainer
+    for B in (37, 3):
+        raw, flow = O.seeded_cubes(B, 1, 11)
+        rawd, flowd = torch.from_numpy(raw).cuda(), torch.from_numpy(flow).cuda()
+        grads, nred = [], []
+        for fuse in ('0', '1'):
+            monkeypatch.setenv('VV_FUSE_BN_SUMS_T', fuse)
+            net, _, _ = _build('net4', False)
+            net.train()
+            tr = FusedTrainer(net)
+            tr.step_cubes(rawd, flowd, torch.arange(B, device='cuda'))
+            torch.cuda.synchronize()
+            grads.append(tr.bank.grads_gu())
+            ws = tr.bank.workspace(B)
+            nred.append([c[2] for c in tr.bank.backward_plan(ws, fused=tr.bank.fuse_outconv).calls if c[2].startswith('bn_bwd_reduce')])
+        assert nred[0] == ['bn_bwd_reduce11', 'bn_bwd_reduce9', 'bn_bwd_reduce7', 'bn_bwd_reduce5', 'bn_bwd_reduce3', 'bn_bwd_reduce1']
+        assert nred[1] == ['bn_bwd_reduce5', 'bn_bwd_reduce3', 'bn_bwd_reduce1']
+        lay = tr.bank.lay
+        worst = 0.0
+        for key, (off, shape) in lay.p.items():
+            n = int(torch.tensor(shape).prod())
+            a, b = grads[0][:, off:off + n].double(), grads[1][:, off:off + n].double()
+            d = ((a - b).norm() / a.norm().clamp_min(1e-30)).item()
+            if key.split('.')[0] in ('c12', 'c13', 'o', 't2'):
+                assert d == 0.0, (key, d)            # computed before the first fused launch (dgradT2) has any effect
+            worst = max(worst, d)
+        assert 0.0 < worst <= 1e-5, (B, worst)
 
 
 

@@ -32,6 +32,7 @@ BNBWD_Y_BF16 = 8
 BNBWD_PARTIALS_PER_TILE = 16   # partial sums left by the data-gradient launch (ConvParams.bn_partial)
 BNBWD_PARTIALS_PER_CTILE = 32  # ... of vv_conv_mfma (all-bf16 tensors): rows per vv_conv_ntiles
 BNBWD_PARTIALS_PER_TILE44 = 64  # ... of vv_conv_wino44: rows per vv_wino44_ntiles
+BNBWD_PARTIALS_PER_TTILE = 128  # ... of the transposed conv's data gradient (fp32 kernel): rows per vv_convt_dgrad_ntiles(B, H, W, 0)
 WGRAD_X_BF16 = 2
 WGRAD_DY_BF16 = 1      # vv_wgrad_params.pad0 for vv_wgrad_bf16
 
@@ -115,6 +116,7 @@ _SIGS = {
     'vv_pack_wino44': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'vv_conv_ntiles': (c_i32, [c_i32, c_i32, c_i32]),
     'vv_conv_ntiles2': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    'vv_convt_dgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     'vv_wgrad_mfma': (c_i32, [C.POINTER(WgradParams), c_vp]),
     'vv_wgrad_ntiles': (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     'vv_wgrad_bf16': (c_i32, [C.POINTER(WgradParams), c_vp]),

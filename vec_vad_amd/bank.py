@@ -538,7 +538,9 @@ class UNetBank:
         # rows: BatchNorm-backward blocks, or the pixel tiles of whichever conv kernel leaves the fused sums (Winograd tiles in fp32,
         # vv_conv_mfma's tiles for the bf16 32x32 launches: VV_BNBWD_PARTIALS_PER_TILE / _PER_CTILE) -- sized for all of them explicitly
         ws.bnpart = f(Ga, max(max(n, lib.vv_wino_ntiles(B, l.H), lib.vv_conv_ntiles(B, l.H, l.H),
-                                  lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag)) * 2 * l.cout for n, l in zip(nblk, lay.convs)))
+                                  lib.vv_conv_ntiles2(B, l.H, l.H, L.CONV3, self.fflag),
+                                  lib.vv_convt_dgrad_ntiles(B, l.H, l.H, 0))
+                              * 2 * l.cout for n, l in zip(nblk, lay.convs)))
         ws.ocpart = f(Ga, B, 4 * self.nf + 4)
 
     def backward_plan(self, ws, fused):
@@ -901,6 +903,18 @@ class UNetBank:
             return j
 
         fused = {fused_producer(l) for l in lay.convs} - {None}
+        # round 6: conv layers whose activation feeds ONLY a transposed conv (7 / 9 / 11): dA is that transposed conv's data gradient
+        # (vv_conv_mfma, VV_CONVT_DGRAD), which leaves the first BatchNorm-backward pass in its epilogue -- fp32 path only (the all-bf16
+        # form of that launch was measured slower than launch + separate pass on config 4); VV_FUSE_BN_SUMS_T=0 keeps the separate
+        # reduce pass for these three (A/B)
+        fused_t = {}
+        if self.fuse_bn_sums and os.environ.get('VV_FUSE_BN_SUMS_T', '1') != '0' and not self.cflag:
+            for u, (sidx, _, _, _) in enumerate(lay.convT):
+                others = any(m.mode == L.IN_CAT and m.skip == sidx for m in lay.convs) or any(m.mode == L.IN_POOL and m.src == sidx for m in lay.convs) \
+                    or any(m.mode == L.IN_ACT and m.src == sidx for m in lay.convs)
+                if not others and sidx != last.idx:
+                    fused_t[u] = sidx
+        fused |= set(fused_t.values())
 
         def dgrad_flags(i):
             # pad0 of layer i's data-gradient launch (also decides its tile count: vv_conv_ntiles2)
@@ -924,7 +938,8 @@ class UNetBank:
             from_dgrad = i in fused                # ... by the data-gradient launch of layer i + 1
             bp = L.BnBwdParams(Ga, B, l.H, l.H, l.cout,
                                (L.BNBWD_DZ_BF16 if dz16 else 0) | (L.BNBWD_PARTIALS_PER_CUBE if from_outconv else 0) |
-                               ((L.BNBWD_PARTIALS_PER_TILE44 if self._w44(B, lay.convs[i + 1], True) else L.BNBWD_PARTIALS_PER_TILE if self.wino
+                               ((L.BNBWD_PARTIALS_PER_TTILE if i in fused_t.values() else
+                                 L.BNBWD_PARTIALS_PER_TILE44 if self._w44(B, lay.convs[i + 1], True) else L.BNBWD_PARTIALS_PER_TILE if self.wino
                                  else L.BNBWD_PARTIALS_PER_CTILE) if from_dgrad else 0) |
                                (L.BNBWD_DA_BF16 if self.da16 else 0) | (L.BNBWD_Y_BF16 if self.y16 else 0), y.data_ptr(), y.stride(0), self._p(ws.ab[0, i]), self._p(ws.ab[1, i]),
                                self._p(ws.ab[2, i]), self._p(ws.ab[3, i]), abg, dA, dpool, dpg, dzb.data_ptr(), dzb.stride(0),
@@ -992,6 +1007,12 @@ class UNetBank:
             cp = L.ConvParams(L.CONVT_DGRAD, L.IN_PLAIN, Ga, B, H, H, co, co, ci, dy, None, None, 0, L.NULL_VIEW, 0,
                               self.cflag | (((L.CONV_ALLSRC_BF16 if self.y16 else L.CONV_SRC_BF16) | L.CONV_OUT_BF16) if self.da16 else 0), None,
                               kbase + 4 * lay.pk['t%d.d' % u][0], UP, None, 0, L.view(DT, ci, 0, DT.stride(0)), None)
+            if u in fused_t:                   # the first pass of layer sidx's BatchNorm backward rides on this launch's epilogue
+                yj = ws.y[sidx]
+                cp.bn_z, cp.bn_z_gstride = yj.data_ptr(), yj.stride(0)
+                cp.bn_a, cp.bn_b = self._p(ws.ab[0, sidx]), self._p(ws.ab[1, sidx])
+                cp.bn_mean, cp.bn_invstd = self._p(ws.ab[2, sidx]), self._p(ws.ab[3, sidx])
+                cp.bn_gstride, cp.bn_partial = abg, ws.bnpart.data_ptr()
             P.keep.append(cp)
             P.add(lib.vv_conv_mfma, (C.byref(cp),), 'dgradT%d' % u, pwait=('*side',))
             ntd = lib.vv_wino44_ntiles(B, m.H) if self._w44(B, m, True) else lib.vv_wino_ntiles(B, m.H) if self.wino else \

@@ -37,7 +37,7 @@ struct Geo {
 // S16 (with BF, plain input): src0 holds bf16 elements -- a dy that BatchNorm backward stored as bf16; copied, not converted.
 // MR: 32-pixel row blocks per wave (2 = 256-pixel tiles; 1 = 128-pixel tiles, four workgroups per CU: the bf16 kernels on the 8x8 / 4x4
 // levels, where a launch has few, long workgroups and is bound by the chunk round trips)
-template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, int S16, int MR>      // S16: 0 fp32 sources, 1 plain bf16 src0, 2 ALL sources bf16, 3 = 2 + bn_partial
+template <int TH, int TW, int NI, int NR, int KIND, int CK, bool BF, int S16, int MR>      // S16: 0 fp32 sources, 1 plain bf16 src0, 2 ALL sources bf16, 3 = 2 + bn_partial, 4 = fp32 stride-2 gather + bn_partial
 __global__ void __launch_bounds__(VV_WG, (MR == 1 && BF) ? 4 : ((BF && KIND == VV_CONVT_DGRAD) ? 1 : ((NR == 1 && KIND != VV_CONVT_FWD && !(BF && NI >= 4)) ? 3 : 2)))
 conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int total, const int nper) {
   using G_ = Geo<KIND, TH, TW>;
@@ -115,6 +115,24 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr bool BNF = BF && NR == 1 && KIND == VV_CONV3 && S16 == 3;      // its own instantiation: as a run-time option it cost
                                                                             // every 32-wide launch of the 32x32 level 20 % (registers, code in the epilogue)
   static_assert(S16 != 3 || BNF, "S16 == 3: the 32-wide 3x3 launch with BatchNorm-backward sums");
+  // BNT (round 6, S16 == 4): the fp32 data gradient of a transposed conv IS dA of the conv layer in front of it (its only consumer:
+  // layers 7 / 9 / 11), so the first pass of that layer's BatchNorm backward rides on this launch's epilogue the way it rides on the
+  // Winograd data gradients (vv_wino.hip): lane = channel, the lane's 16 z values (its 16 output pixels) requested ahead of the K loop.
+  // (The all-bf16 form of the same launch -- z as 16-byte items, sums in the LDS store loop like S16 == 3 -- was built and measured on
+  // config 4: 138 / 113 / 98 us per launch became 264 / 189 / 146 for 116 us of reduce passes saved; not kept, profiles/README.md.)
+  constexpr bool BNT = !BF && KIND == VV_CONVT_DGRAD && NR == 1 && MR == 1 && S16 == 4;
+  static_assert(S16 != 4 || BNT, "S16 == 4: the fp32 stride-2 gather (128-pixel tiles, 32-wide N tiles) with BatchNorm-backward sums");
+  float zt[BNT ? 16 : 1];
+  if constexpr (BNT) {
+    const float* zb = p.bn_z + (int64_t)g * p.bn_z_gstride + co0 + l31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+      const int pp = wave * 32 + row;
+      const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
+      zt[i] = img0 + im < p.B ? zb[((int64_t)((img0 + im) * H + ty0 + r) * W + tx0 + c) * Cout] : 0.f;
+    }
+  }
   constexpr int BN_QN = NR * 4, BN_NOUT = 128 * MR * BN_QN / VV_WG;
   const bool bnf = BNF && p.bn_partial != nullptr;
   uint4 zq[BNF ? BN_NOUT : 1];
@@ -133,7 +151,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
 
   // ---- software pipeline over the K chunks: activation tile (BatchNorm+ReLU deferred to commit) and weight panel of
   // chunk c+1 are in flight in registers while chunk c runs on the matrix cores; nothing but LDS is read in the MFMA loop.
-  VVStagerB<NI, HH, HW, S, (S16 >= 2 ? CK / 2 : CK)> stA;      // all-bf16 sources: 16-byte items of 8 channels
+  VVStagerB<NI, HH, HW, S, ((BF && S16 >= 2) ? CK / 2 : CK)> stA;      // all-bf16 sources: 16-byte items of 8 channels
   stA.init(s, ox0, tid);            // every tile spans full rows (TW == W): the column origin is tile independent
   unsigned boff[NBT];
   float4 rb[NBT];
@@ -150,8 +168,8 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   }
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7FFFFFFF, 0x00020000);
   auto issue = [&](const int c0) {
-    if constexpr (S16 >= 2) stA.prefetch16w(s, img0, oy0, ox0, c0, tid);
-    else if constexpr (S16 == 1) stA.prefetch16(s, img0, oy0, ox0, c0, tid);
+    if constexpr (BF && S16 >= 2) stA.prefetch16w(s, img0, oy0, ox0, c0, tid);
+    else if constexpr (BF && S16 == 1) stA.prefetch16(s, img0, oy0, ox0, c0, tid);
     else stA.prefetch(s, img0, oy0, ox0, c0, tid);
     const int so = (BF ? (c0 >> 4) : (c0 >> 3)) * 2 * Cout * 16;
 #pragma unroll
@@ -161,8 +179,8 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
     }
   };
   auto commit = [&]() {
-    if constexpr (S16 >= 2) stA.commit16w(lds, tid);
-    else if constexpr (S16 == 1) stA.commit_raw16(lds, tid);
+    if constexpr (BF && S16 >= 2) stA.commit16w(lds, tid);
+    else if constexpr (BF && S16 == 1) stA.commit_raw16(lds, tid);
     else if constexpr (BF) stA.commit_bf16(lds, tid);
     else stA.commit(lds, tid);
 #pragma unroll
@@ -260,6 +278,7 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   // VV_CONV_RELU: clamp at 0, else at -inf = a no-op that leaves every value bit-identical (the flag test hoisted out of the
   // store loops: tested per element it cost the 64-wide bf16 data gradient at 32x32 85 us of 270)
   const float relu_lo = (p.pad0 & VV_CONV_RELU) ? 0.f : -__builtin_inff();
+  float bta = 0.f, btb = 0.f, bt1 = 0.f, bt2 = 0.f;      // BNT: scale / shift of the lane's channel, its two sums
   bool tile_out = false;
   if constexpr (BF && KIND != VV_CONVT_FWD) tile_out = o16;
   if (tile_out) {
@@ -360,6 +379,10 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       }
     }
   } else {
+  if constexpr (BNT) {
+    const int64_t o = (int64_t)g * p.bn_gstride + co0 + l31;
+    bta = p.bn_a[o]; btb = p.bn_b[o];
+  }
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -368,6 +391,12 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       const int pp = wave * (32 * MR) + m * 32 + row;
       const int im = pp / (TH * TW), r = (pp / TW) % TH, c = pp % TW;
       const int img = img0 + im;
+      if constexpr (BNT) {
+        // dz = dA [a z + b > 0]; sum dz and sum dz * z per channel (xhat's shift and scale once per workgroup, below)
+        const float d = (img < p.B && fmaf(bta, zt[i], btb) > 0.f) ? acc[m][0][i] + bias[0] : 0.f;
+        bt1 += d;
+        bt2 = fmaf(d, zt[i], bt2);
+      }
       if (img < p.B) {
         if constexpr (KIND == VV_CONVT_FWD) {
           const int64_t e = ((int64_t)(img * OH + 2 * (ty0 + r)) * OW + 2 * (tx0 + c)) * ocs + co0 + l31;
@@ -396,6 +425,23 @@ conv_mfma_kernel(const vv_conv_params p, const int NT, const int NN, const int t
       }
     }
 
+  }
+  if constexpr (BNT) {
+    // the lane pair of a channel, then the four waves through LDS in wave order: one row [sum dz | sum dz xhat] per pixel tile
+    // (vv_bn_bwd_apply reads it with VV_BNBWD_PARTIALS_PER_TTILE: rows = this launch's tiles)
+    bt1 += __shfl_xor(bt1, 32);
+    bt2 += __shfl_xor(bt2, 32);
+    __syncthreads();                      // every wave is done with the staging buffers
+    if (half == 0) { lds[wave * 64 + l31] = bt1; lds[wave * 64 + 32 + l31] = bt2; }
+    __syncthreads();
+    if (tid < 32) {
+      const float t1 = (lds[tid] + lds[64 + tid]) + (lds[128 + tid] + lds[192 + tid]);
+      const float t2 = (lds[32 + tid] + lds[96 + tid]) + (lds[160 + tid] + lds[224 + tid]);
+      const int64_t o = (int64_t)g * p.bn_gstride + co0 + tid;
+      float* bp = p.bn_partial + ((int64_t)(g * NT + pt) * 2) * Cout + co0 + tid;
+      bp[0] = t1;
+      bp[Cout] = p.bn_invstd[o] * (t2 - p.bn_mean[o] * t1);
+    }
   }
   if (p.stats) {
     __syncthreads();
@@ -501,6 +547,15 @@ extern "C" int vv_conv_ntiles(int32_t B, int32_t H, int32_t W) {
   return ((B + t.NI - 1) / t.NI) * (H / t.TH) * (W / t.TW);
 }
 
+extern "C" int vv_convt_dgrad_ntiles(int32_t B, int32_t H, int32_t W, int32_t flags) {
+  // pixel tiles of a VV_CONVT_DGRAD launch of vv_conv_mfma (H x W = its OUTPUT = the transposed conv's input resolution): the rows
+  // of bn_partial the fp32 launch leaves.  fp32: 128-pixel tiles; bf16 kernels: 256-pixel tiles (no sums there)
+  if (H != W || (H != 16 && H != 8 && H != 4)) return -1;
+  const int px = (flags & VV_CONV_BF16) ? 256 : 128;
+  const int per_img = H * W;
+  return per_img >= px ? B * (per_img / px) : (B + px / per_img - 1) / (px / per_img);
+}
+
 extern "C" int vv_conv_ntiles2(int32_t B, int32_t H, int32_t W, int32_t kind, int32_t flags) {
   if (vv_gemm16_flags(kind, flags)) return vv_conv_ntiles(B, H, W);          // vv_conv_bf16.hip: 256-pixel tiles everywhere
   if ((flags & VV_CONV_BF16) && kind == VV_CONV3 && H == W && H == 16) return B * 2;
@@ -519,7 +574,12 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
   if ((p->pad0 & VV_CONV_OUT_BF16) && !bf) return VV_ERR_BAD_ARG;
   if ((p->pad0 & VV_CONV_ALLSRC_BF16) && (!bf || p->in_mode == VV_IN_POOL || p->in_mode == VV_IN_CUBE)) return VV_ERR_BAD_ARG;
   if (p->CinP % 8) return VV_ERR_BAD_ARG;
-  if (p->bn_partial) {
+  if (p->bn_partial && !bf && p->kind == VV_CONVT_DGRAD) {
+    // fp32 stride-2 gather (the transposed conv's data gradient = dA of the conv layer in front of it): sums per 128-pixel tile,
+    // rows = vv_convt_dgrad_ntiles(B, H, W, 0)
+    if (p->stats || p->out1.ptr || (p->H != 16 && p->H != 8 && p->H != 4) || p->H != p->W) return VV_ERR_UNSUPPORTED;
+    if (!p->bn_z || !p->bn_a || !p->bn_b || !p->bn_mean || !p->bn_invstd) return VV_ERR_BAD_ARG;
+  } else if (p->bn_partial) {
     // BatchNorm-backward partial sums in the epilogue: all-bf16 3x3 launches of the kernel in this file with 32-wide N tiles (the
     // bank's 32 -> 32 channel data gradients on the 32x32 level; vv_conv_wino has its own form for the fp32 path)
     if (!(bf && (p->pad0 & VV_CONV_OUT_BF16) && (p->pad0 & VV_CONV_ALLSRC_BF16) && p->kind == VV_CONV3)) return VV_ERR_UNSUPPORTED;
@@ -552,6 +612,11 @@ extern "C" int vv_conv_mfma(const vv_conv_params* p, vv_stream stream) {
       return bf ? dispatch<VV_CONVT_FWD, 16, true>(p, st) : dispatch<VV_CONVT_FWD, 16, false>(p, st);
     case VV_CONVT_DGRAD:
       if (bf && p->CinP % 16) return VV_ERR_BAD_ARG;
+      if (!bf && p->bn_partial) {          // (validated above) the tiles of dispatch<VV_CONVT_DGRAD, 8, false>, with the sums
+        if (p->H == 16) return launch<8, 16, 1, 1, VV_CONVT_DGRAD, 8, false, 4, 1>(p, st);
+        if (p->H == 8) return launch<8, 8, 2, 1, VV_CONVT_DGRAD, 8, false, 4, 1>(p, st);
+        return launch<4, 4, 8, 1, VV_CONVT_DGRAD, 8, false, 4, 1>(p, st);
+      }
       if (sm == 2) return dispatch<VV_CONVT_DGRAD, 8, true, 2>(p, st);
       if (sm == 1) return dispatch<VV_CONVT_DGRAD, 8, true, 1>(p, st);
       return bf ? dispatch<VV_CONVT_DGRAD, 8, true>(p, st) : dispatch<VV_CONVT_DGRAD, 8, false>(p, st);

@@ -1394,7 +1394,8 @@ extern "C" int vv_bn_bwd_apply(const vv_bnbwd_params* p, const float* gamma, int
   const int nblk = (p->flags & VV_BNBWD_PARTIALS_PER_CUBE) ? p->B
                    : (p->flags & VV_BNBWD_PARTIALS_PER_TILE) ? vv_wino_ntiles(p->B, p->H)
                    : (p->flags & VV_BNBWD_PARTIALS_PER_TILE44) ? vv_wino44_ntiles(p->B, p->H)
-                   : (p->flags & VV_BNBWD_PARTIALS_PER_CTILE) ? vv_conv_ntiles(p->B, p->H, p->W) : bn_nblk_of(p);
+                   : (p->flags & VV_BNBWD_PARTIALS_PER_CTILE) ? vv_conv_ntiles(p->B, p->H, p->W)
+                   : (p->flags & VV_BNBWD_PARTIALS_PER_TTILE) ? vv_convt_dgrad_ntiles(p->B, p->H, p->W, 0) : bn_nblk_of(p);
   if (nblk <= 0) return VV_ERR_BAD_ARG;
   const int nblk_apply = bn_nblk_of(p);
   const int64_t M = (int64_t)p->B * p->H * p->W;
