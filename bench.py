@@ -563,7 +563,7 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     return rec
 
 
-def run_scoring(dev, B=512, n=8192, reps=3):
+def run_scoring(dev, B=2048, n=8192, reps=3):      # B = config.cfg's [mi355x] score_batch
     """Eval-mode scoring pass (test.py:312-345 / train.py:413-427): device-resident cubes -> per-cube raw / flow scores."""
     from vec_vad_amd.trainer import FusedTrainer
     net, tot_of = build_net('net4', 'fp32', dev)

@@ -166,7 +166,7 @@ def paint_frame(scores, bboxes, h, w):
 
 
 def score_frames(net_set, stats_raw, stats_of, foreground_set, foreground_set2, bbox_set, h, w, w_raw, w_of, useFlow,
-                 device, score_batch=512, scene_idx=None, result_dir=None, log=print, return_device=False):
+                 device, score_batch=2048, scene_idx=None, result_dir=None, log=print, return_device=False):
     """Per-frame anomaly scores.  ``net_set[(s,)hh][ww]`` is a list with 0 or 1 eval-mode networks;
     ``stats_*[(s,)hh][ww]`` = (mean, std) of the training scores.
 

@@ -414,7 +414,7 @@ w_of =0.5
     p.write_text(flat)
     c = T.read_config(str(p))
     assert (c['dataset_name'], c['h_block'], c['w_block'], c['tot_of_num'], c['rawRange']) == ('avenue', 2, 3, 1, 3)
-    assert c['padding'] is True and c['lambda_of'] == 2.0 and c['w_of'] == 0.5 and c['shuffle_seed'] == 0 and c['score_batch'] == 512
+    assert c['padding'] is True and c['lambda_of'] == 2.0 and c['w_of'] == 0.5 and c['shuffle_seed'] == 0 and c['score_batch'] == 2048
 
 
 def test_graph_cache_keeps_two_cube_stores():

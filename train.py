@@ -78,7 +78,7 @@ def read_config(path='config.cfg'):
              lambda_raw=cp.getfloat(method, 'lambda_raw'), lambda_of=cp.getfloat(method, 'lambda_of'),
              w_raw=cp.getfloat(method, 'w_raw'), w_of=cp.getfloat(method, 'w_of'), nf=cp.getint(method, 'nf'),
              shuffle_seed=cp.getint('mi355x', 'shuffle_seed', fallback=0),
-             score_batch=cp.getint('mi355x', 'score_batch', fallback=512),
+             score_batch=cp.getint('mi355x', 'score_batch', fallback=2048),
              save_score_masks=cp.getboolean('mi355x', 'save_score_masks', fallback=True),
              overlap_wgrad=cp.getboolean('mi355x', 'overlap_wgrad', fallback=False),
              precision=cp.get('mi355x', 'precision', fallback='fp32').strip().lower())

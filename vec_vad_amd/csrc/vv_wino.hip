@@ -400,6 +400,9 @@ wino_ring_kernel(const vv_conv_params p, const int NT, const int NN, const int t
   constexpr int RING4 = NBUF * CH4;
   constexpr int SP4 = RING4 + EX4;                         // [2][4][64] floats: BatchNorm partials of the four waves' lanes
   constexpr int AB4 = SP4 + 128;                           // [2][KQ * 2] float4: a, b of the producing layer's BatchNorm
+  // COMPILER DEPENDENCY: the counted waits below assume the epilogue's output stores stay >= STORES_MIN separate VMEM instructions per
+  // wave.  tests/test_build_invariants.py checks that on the emitted assembly at every build (no GPU needed); VV_WINO_RING=0 /
+  // VV_CONV_NO_RING routes the same launches to the per-tile kernel, whose waits are the compiler's own.
   constexpr int STORES_MIN = 16;                           // VMEM instructions every wave issues in every epilogue, at least
   constexpr int VMW = 2 * (D - 1) + STORES_MIN * E;        // allowed outstanding when chunk j must have landed (see above)
   static_assert(D % KQ == 0 && VMW <= 63, "ring geometry");
