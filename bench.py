@@ -166,7 +166,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of the conv family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); None when no such profile is committed.  This is a
     number read from profiles/, not something this run measured (PMC collection needs rocprofv3 around the process)."""
-    for n in (name, name.replace('r05_', 'r04_'), name.replace('r05_', 'r03_'), name.replace('r05_', 'r02_'), name.replace('r05_', 'r01_')):
+    for n in [name] + [name.replace('r06_', 'r0%d_' % k) for k in (5, 4, 3, 2, 1)]:
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             _STEP_BYTES[name] = d.get('hbm_bytes_per_train_step')
@@ -337,7 +337,7 @@ def conv_roofline(bank, B, per, precision, overlap, traffic):
                                             + ', '.join(sorted(w44k)), 'launches_timed': n4, 'avg_launch_us': 1e6 * t4 / n4,
                                   'achieved': x4 / t4 / 1e12, 'frac': x4 / t4 / FP32_MFMA_PEAK, 'algorithmic_tflops': a4 / t4 / 1e12,
                                   'algorithmic_mbytes_per_launch': sum(by[k] * len(per[k]) for k in w44k) / n4 / 1e6,
-                                  'traffic': _F44_BYTES.get('r05_pmc_hbm_traffic.json')}
+                                  'traffic': _F44_BYTES.get('r06_pmc_hbm_traffic.json')}
             r['all_3x3_launches'] = {'launches_timed': n + n4, 'avg_launch_us': 1e6 * (t + t4) / (n + n4),
                                      'executed_frac': (f_exe + x4) / (t + t4) / FP32_MFMA_PEAK,
                                      'algorithmic_tflops': (f_alg + a4) / (t + t4) / 1e12}
@@ -493,9 +493,9 @@ def run_unet(model, precision, B, steps, warmup, dev, rank, world, dist, overlap
     # the committed PMC passes: default workload (net4, B=256) and BASELINE config 4 (full, B=512, bf16)
     pname = None
     if model == 'net4' and B == 256:
-        pname = 'r05_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')
+        pname = 'r06_pmc_hbm_traffic%s.json' % ('' if precision == 'fp32' else '_bf16')
     elif model == 'full' and B == 512 and precision == 'bf16':
-        pname = 'r05_pmc_hbm_traffic_bf16_full_b512.json'
+        pname = 'r06_pmc_hbm_traffic_bf16_full_b512.json'
     traffic = pmc_traffic(pname) if pname else (None, None)
     rec = {'value': value, 'unit': 'cubes/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
            'dtype': 'f32' if precision == 'fp32' else 'bf16 operands, f32 accumulate',
@@ -608,7 +608,7 @@ def run_scoring(dev, B=2048, n=8192, reps=3):      # B = config.cfg's [mi355x] s
 
 
 def _fn2_traffic():
-    for n in ('r05_pmc_hbm_traffic_flownet2.json', 'r04_pmc_hbm_traffic_flownet2.json', 'r03_pmc_hbm_traffic_flownet2.json'):
+    for n in ('r06_pmc_hbm_traffic_flownet2.json', 'r05_pmc_hbm_traffic_flownet2.json', 'r04_pmc_hbm_traffic_flownet2.json', 'r03_pmc_hbm_traffic_flownet2.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', n)))
             return d['total_hbm_bytes_per_run_corrected'], _profile_tag(n, d)
