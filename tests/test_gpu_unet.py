@@ -926,7 +926,12 @@ def test_embedded_width_matches_oracle_eval_train_and_state(kind, nf, n):
         l_hip = [float(v) for v in tr.losses(ws)]
         l_ref = O.train_step(sd_o, spec, x, x_of, opt)[:2]
         np.testing.assert_allclose(l_hip, l_ref, rtol=1e-3)
+    # a direct read through parameters() must see the trained values too, not the copies from before the steps
+    k0, p0 = next(iter(net.named_parameters()))
+    first = p0.detach().cpu().clone()
+    assert not torch.equal(first, sd[k0]), 'parameters() returned the stale pre-training copy'
     got = net.state_dict()                  # pulls the trained blocks out of the engine's tensors
+    assert torch.equal(first, got[k0].cpu())
     assert _param_rel_l2(got, sd_o) < 2e-2
     for k, v in got.items():
         assert v.shape == sd_o[k].shape, k

@@ -338,6 +338,20 @@ class _SelfCompleteBase(nn.Module):
         self._sync()
         return super().state_dict(*args, **kwargs)
 
+    # Embedded models (features_root other than 32 / 64): the module's tensors are COPIES of blocks of the engine's, so after the
+    # fused trainer's steps they are stale until something pulls them.  state_dict() / forward() / _apply() do; a direct read through
+    # parameters() / buffers() (an external optimizer's constructor, a norm, torch.save of p.data) must see the trained values
+    # too.  No-ops for the 32- / 64-wide models, whose parameters are views of the engine's buffers.
+    def named_parameters(self, *args, **kwargs):
+        if getattr(self, '_embedded', False):
+            self._sync()
+        return super().named_parameters(*args, **kwargs)
+
+    def named_buffers(self, *args, **kwargs):
+        if getattr(self, '_embedded', False):
+            self._sync()
+        return super().named_buffers(*args, **kwargs)
+
     def load_state_dict(self, *args, **kwargs):
         r = super().load_state_dict(*args, **kwargs)
         self._sync()
